@@ -1,0 +1,174 @@
+"""In-process shim that imports the *reference's own* hot-path modules on CPU.
+
+TEST INFRASTRUCTURE ONLY.  It exists to (1) pin the numpy oracle
+(`oracle/hyperreel_oracle.py`) against the real reference and (2) generate the
+golden fixtures under `tests/golden/`.  It needs `/root/reference`, which only
+exists in the authoring container -- nothing in the product, the `-m gpu`
+tests, `smoke()` or `bench.py` imports this file.
+
+What it does:
+  1. puts /root/reference first on sys.path and registers a synthetic `nlf`
+     package so sub-modules import without executing nlf/__init__.py (which
+     pulls in Lightning/Hydra);
+  2. stubs import-time-only third-party modules with MagicMock;
+  3. rewrites device='cuda' -> 'cpu' and makes .cuda() a no-op;
+  4. provides an attr-dict in place of OmegaConf plus the *_epoch(s) ->
+     *_iter(s) rewrite of nlf/__init__.py:305-315.
+No reference file is copied or edited.
+"""
+import copy
+import sys
+import types
+from types import SimpleNamespace
+from unittest.mock import MagicMock
+
+import torch
+import yaml
+
+REF = "/root/reference"
+
+
+class AttrDict(dict):
+    """dict with attribute access, recursive (stands in for OmegaConf DictConfig)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return AttrDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def to_attr(o):
+    if isinstance(o, dict):
+        return AttrDict({k: to_attr(v) for k, v in o.items()})
+    if isinstance(o, list):
+        return [to_attr(v) for v in o]
+    return o
+
+
+def epoch_to_iter(cfg, iters_per_epoch):
+    """nlf/__init__.py:305-315 + utils/config_utils.py:32-38 (lambda_config)."""
+    keys = ['max_freq', 'wait', 'stop', 'falloff', 'window', 'no_bias',
+            'window_bias', 'window_bias_start', 'decay', 'warmup']
+    finds = [f'{k}_epoch' for k in keys] + [f'{k}_epochs' for k in keys]
+
+    def walk(c, find_key):
+        if isinstance(c, dict):
+            for key in list(c.keys()):
+                if key == find_key:
+                    v = c[key]
+                    if isinstance(v, list):
+                        c[key.replace('epoch', 'iter')] = [[x * iters_per_epoch for x in li] for li in v]
+                    else:
+                        c[key.replace('epoch', 'iter')] = v * iters_per_epoch
+                else:
+                    walk(c[key], find_key)
+
+    for f in finds:
+        walk(cfg, f)
+    return cfg
+
+
+_installed = False
+
+
+def install():
+    global _installed
+    if _installed:
+        return
+    _installed = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # The HuggingFace `datasets` package must not shadow anything we import; we
+    # never import the reference's datasets/ here.
+    nlf = types.ModuleType('nlf')
+    nlf.__path__ = [REF + '/nlf']
+    sys.modules['nlf'] = nlf
+    for name in ['pytorch3d', 'pytorch3d.transforms', 'kornia', 'cv2', 'torchvision',
+                 'torchvision.transforms', 'skimage', 'skimage.measure', 'skimage.metrics',
+                 'plyfile', 'lpips', 'imageio', 'scipy.signal']:
+        if name not in sys.modules or name.startswith(('pytorch3d', 'kornia', 'cv2', 'torchvision',
+                                                         'skimage', 'plyfile', 'lpips')):
+            sys.modules[name] = MagicMock()
+    # .cuda() no-ops
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.nn.Module.to = _module_to
+
+
+def _decuda(a):
+    if isinstance(a, str) and 'cuda' in a:
+        return 'cpu'
+    if isinstance(a, torch.device) and a.type == 'cuda':
+        return torch.device('cpu')
+    return a
+
+
+class _CpuMode(torch.overrides.TorchFunctionMode):
+    def __torch_function__(self, func, types_, args=(), kwargs=None):
+        kwargs = {k: _decuda(v) for k, v in (kwargs or {}).items()}
+        args = tuple(_decuda(a) for a in args)
+        return func(*args, **kwargs)
+
+
+_orig_module_to = torch.nn.Module.to
+
+
+def _module_to(self, *args, **kwargs):
+    args = tuple(_decuda(a) for a in args)
+    kwargs = {k: _decuda(v) for k, v in kwargs.items()}
+    return _orig_module_to(self, *args, **kwargs)
+
+
+def cpu_mode():
+    return _CpuMode()
+
+
+def load_model_cfg(name, overrides=None, iters_per_epoch=4000):
+    with open(f'{REF}/conf/experiment/model/{name}.yaml') as f:
+        cfg = to_attr(yaml.safe_load(f))
+    if overrides:
+        overrides(cfg)
+    epoch_to_iter(cfg, iters_per_epoch)
+    return cfg
+
+
+def make_system(dataset):
+    """Stub of the INRSystem attributes the hot-path constructors read."""
+    td = SimpleNamespace(**dataset)
+    return SimpleNamespace(
+        dm=SimpleNamespace(train_dataset=td),
+        cfg=to_attr({'dataset': {'collection': dataset.get('collection', 'synthetic'),
+                                 'name': dataset.get('name', 'synthetic')}}),
+    )
+
+
+def build_reference(cfg, dataset, net_chunk=16384, seed=0):
+    """Returns the reference's RenderLightfield (eval mode, iter=1e7) on CPU."""
+    install()
+    torch.manual_seed(seed)
+    with cpu_mode():
+        from nlf.models.models import LightfieldModel
+        from nlf.rendering import RenderLightfield
+        system = make_system(dataset)
+        model = LightfieldModel(cfg, system=system)
+        fn = RenderLightfield(model, None, cfg.render, net_chunk=net_chunk).eval()
+        model.set_iter(10_000_000)
+    return fn
+
+
+def run_reference(fn, rays, chunk=16384, **render_kwargs):
+    from nlf.rendering import render_chunked
+    with cpu_mode(), torch.no_grad():
+        return render_chunked(rays, fn, render_kwargs, chunk)
+
+
+def run_reference_embed(fn, rays, **render_kwargs):
+    with cpu_mode(), torch.no_grad():
+        return fn.embed(rays, **render_kwargs)
