@@ -1,0 +1,207 @@
+"""Synthetic scenes: seeded random weights in the reference's state_dict layout, and rays.
+
+There is no network for datasets or checkpoints, so benchmarks and tests render
+random-weight scenes.  Weights follow the distributions
+of the reference's own initialisers:
+
+  MLP           nn.Linear default (Kaiming-uniform, a=sqrt(5)): U(+-1/sqrt(fan_in))
+                for weight and bias (nlf/nets/mlp.py:127-154; weight_init `none`)
+  density       relu:     1e-2 * clamp(U(0,1), 1e-2, 1e8)   (tensorf_base.py:973-987)
+                softplus: 0.1 * N(0,1)                      (:957-971)
+                'dense' variant: U(0, 0.5) so that alpha spans (0,1) and the
+                transmittance / compositing path is exercised
+  appearance    0.1 * N(0,1)                                (tensorf_base.py:932-944)
+  basis_mat     nn.Linear default, no bias                  (tensorf_base.py:907-909)
+
+The generator is numpy's PCG64 so the same seed reproduces the same scene on
+the authoring container (where goldens are made) and on the GPU box.
+
+Rays: `random_rays` mirrors the Gaussian sampler of datasets/random.py:111-125;
+`pinhole_rays` follows utils/ray_utils.py:98-135 + datasets/base.py:485-518
+(pixel centres +0.5, -z forward, normalised directions, optional cam_id/time).
+"""
+import math
+
+import numpy as np
+
+from .config import n_to_reso
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+MAT_MODE_TIME = [[2, 3], [1, 3], [0, 3]]
+
+EMB = 'model.embedding_model.embeddings.'
+NET = 'model.color_model.net.'
+
+
+def mlp_in_channels(pred_cfg):
+    """RayPredictionEmbedding.in_channels (nlf/embedding/ray.py:231-262)."""
+    total = 0
+    for p in pred_cfg['params'].values():
+        n_in = p['end'] - p['start']
+        par = p['param']
+        n = par.get('n_dims', par.get('in_channels', n_in))
+        pe = p.get('pe')
+        if pe is not None:
+            k = 2 * pe['n_freqs']
+            n = n * (k if pe.get('exclude_identity', False) else k + 1)
+        total += n
+    return total
+
+
+def mlp_layer_shapes(cfg):
+    """[(out, in)] of the D+2 Linear layers (nlf/nets/mlp.py:127-147)."""
+    emb = cfg['embedding']['embeddings']
+    pred = next(e for e in emb.values() if e['type'] == 'ray_prediction')
+    net = pred['net']
+    n_in = mlp_in_channels(pred)
+    W = net['hidden_channels']
+    D = net['depth'] - 2
+    skips = list(net.get('skips', []))
+    n_out = pred['z_channels'] * sum(o['channels'] for o in pred['outputs'].values())
+    shapes = []
+    for i in range(D + 2):
+        if i == 0:
+            shapes.append((W, n_in))
+        elif i == D + 1:
+            shapes.append((n_out, W))
+        elif i in skips:
+            shapes.append((W, W + n_in))
+        else:
+            shapes.append((W, W))
+    return shapes
+
+
+def _uniform(rng, shape, bound):
+    return ((rng.random(shape, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)) * np.float32(bound)).astype(np.float32)
+
+
+def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_scale=0.1):
+    """{reference state_dict key: float32 ndarray} for a random-weight scene.
+
+    grid_size: [Nx, Ny, Nz]; defaults to the config's final resolution.
+    density: 'dense' | 'default' (the reference initialiser).
+    app_scale: std of the appearance planes/lines (reference: 0.1; tests use 1.0 so
+    that decoded colours span the whole [0,1] range instead of hugging 0.5)."""
+    rng = np.random.default_rng(seed)
+    net = cfg['color']['net']
+    if grid_size is None:
+        grid_size = n_to_reso(net['N_voxel_final'], net['aabb'])
+    N = [int(v) for v in grid_size]
+    sd = {}
+    emb = cfg['embedding']['embeddings']
+    pred_idx = [i for i, e in enumerate(emb.values()) if e['type'] == 'ray_prediction'][0]
+    shapes = mlp_layer_shapes(cfg)
+    for i, (o, n_in) in enumerate(shapes):
+        mid = '.0' if i < len(shapes) - 1 else ''
+        b = 1.0 / math.sqrt(n_in)
+        sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.weight'] = _uniform(rng, (o, n_in), b)
+        sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.bias'] = _uniform(rng, (o,), b)
+
+    act = net.get('fea2denseAct', 'softplus')
+
+    def dens(shape):
+        if density == 'dense':
+            return (rng.random(shape, dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+        if act == 'softplus':
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+        return (np.clip(rng.random(shape, dtype=np.float32), 1e-2, 1e8) * np.float32(1e-2)).astype(np.float32)
+
+    def app(shape):
+        return (rng.standard_normal(shape, dtype=np.float32) * np.float32(app_scale)).astype(np.float32)
+
+    nd, na = list(net['n_lamb_sigma']), list(net['n_lamb_sh'])
+    video = net['type'] == 'tensor_vm_split_time'
+    K = int(dataset['num_keyframes'])
+    sd[NET + 'aabb'] = np.asarray(net['aabb'], np.float32)
+    sd[NET + 'gridSize'] = np.asarray(N, np.int64)
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        if video:
+            t0 = MAT_MODE_TIME[i][0]
+            sd[f'{NET}density_plane_space.{i}'] = dens((1, nd[i], N[m1], N[m0]))
+            sd[f'{NET}density_plane_time.{i}'] = dens((1, nd[i], K, N[t0]))
+        else:
+            sd[f'{NET}density_plane.{i}'] = dens((1, nd[i], N[m1], N[m0]))
+            sd[f'{NET}density_line.{i}'] = dens((1, nd[i], N[VEC_MODE[i]], 1))
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        if video:
+            t0 = MAT_MODE_TIME[i][0]
+            sd[f'{NET}app_plane_space.{i}'] = app((1, na[i], N[m1], N[m0]))
+            sd[f'{NET}app_plane_time.{i}'] = app((1, na[i], K, N[t0]))
+        else:
+            sd[f'{NET}app_plane.{i}'] = app((1, na[i], N[m1], N[m0]))
+            sd[f'{NET}app_line.{i}'] = app((1, na[i], N[VEC_MODE[i]], 1))
+    app_dim = int(net.get('data_dim_color', 27))
+    sd[NET + 'basis_mat.weight'] = _uniform(rng, (app_dim, sum(na)), 1.0 / math.sqrt(max(sum(na), 1)))
+    if video:
+        sd[NET + 'basis_mat_density.weight'] = _uniform(rng, (1, sum(nd)), 1.0 / math.sqrt(max(sum(nd), 1)))
+    return sd
+
+
+def state_dict_checksum(sd):
+    """Order-independent fingerprint used by the golden fixtures."""
+    return float(sum(float(np.sum(np.asarray(v, np.float64))) * (1 + (len(k) % 7)) for k, v in sorted(sd.items())))
+
+
+# --------------------------------------------------------------------------- rays
+def _normalize(v):
+    n = np.sqrt(np.sum(v * v, -1, keepdims=True, dtype=np.float32))
+    return (v / np.maximum(n, np.float32(1e-12))).astype(np.float32)
+
+
+def random_rays(n, seed=0, video=False, pos_mean=(0.0, 0.0, 0.0), pos_std=0.1, dir_mean=(0.0, 0.0, 0.0),
+                dir_std=1.0, times=None):
+    """Gaussian rays about a mean (datasets/random.py:111-125)."""
+    rng = np.random.default_rng(seed)
+    o = np.asarray(pos_mean, np.float32)[None] + rng.standard_normal((n, 3), dtype=np.float32) * np.float32(pos_std)
+    d = _normalize(np.asarray(dir_mean, np.float32)[None] + rng.standard_normal((n, 3), dtype=np.float32) * np.float32(dir_std))
+    rays = np.concatenate([o, d], -1).astype(np.float32)
+    if video:
+        t = rng.random((n, 1), dtype=np.float32) if times is None else np.asarray(times, np.float32).reshape(-1, 1)
+        rays = np.concatenate([rays, np.zeros((n, 1), np.float32), np.broadcast_to(t, (n, 1))], -1).astype(np.float32)
+    return rays
+
+
+def look_at_pose(eye, target, up=(0.0, 1.0, 0.0)):
+    """3x4 camera-to-world with -z forward (nerf_pl convention used by get_rays)."""
+    eye = np.asarray(eye, np.float64)
+    f = np.asarray(target, np.float64) - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, np.float64))
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    return np.stack([r, u, -f, eye], 1).astype(np.float32)
+
+
+def pinhole_rays(H, W, fov_deg, c2w, cam_id=None, time=None):
+    """get_ray_directions_K(centered_pixels=True) + get_rays (utils/ray_utils.py:98-135)."""
+    focal = np.float32(0.5 * W / math.tan(0.5 * math.radians(fov_deg)))
+    cx, cy = np.float32(W / 2.0), np.float32(H / 2.0)
+    j, i = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    dirs = np.stack([(i - cx + np.float32(0.5)) / focal, -(j - cy + np.float32(0.5)) / focal,
+                     -np.ones_like(i)], -1).reshape(-1, 3)
+    c2w = np.asarray(c2w, np.float32)
+    d = _normalize(dirs @ c2w[:, :3].T)
+    o = np.broadcast_to(c2w[:, 3][None], d.shape)
+    rays = np.concatenate([o, d], -1).astype(np.float32)
+    if time is not None:
+        n = rays.shape[0]
+        rays = np.concatenate([rays, np.full((n, 1), 0.0 if cam_id is None else cam_id, np.float32),
+                               np.full((n, 1), time, np.float32)], -1)
+    return np.ascontiguousarray(rays, np.float32)
+
+
+def benchmark_rays(model_name, H=800, W=800, frame=0, num_frames=50):
+    """The BASELINE ray sets: an inside-out orbit camera for the
+    sphere/cylinder scenes, a forward-facing camera at z=+1 for the z-plane scenes."""
+    video = not model_name.startswith('donerf')
+    t = None
+    if video:
+        t = frame / float(max(num_frames - 1, 1))
+    if 'z_plane' in model_name:
+        pose = look_at_pose((0.05, 0.03, 1.0), (0.0, 0.0, -1.0))
+    else:
+        pose = look_at_pose((0.3, 0.0, 0.0), (1.0, 0.1, 0.05))
+    return pinhole_rays(H, W, 40.0, pose, cam_id=0 if video else None, time=t)

@@ -1,0 +1,43 @@
+"""Shared test plumbing: golden fixtures -> (cfg, dataset scalars, regenerated weights, rays, expected)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from hyperreel_amd import config as C
+from hyperreel_amd import scenes
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+
+
+class Golden:
+    def __init__(self, case):
+        z = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
+        self.arrays = {k: z[k] for k in z.files if k != 'recipe'}
+        self.recipe = json.loads(bytes(z['recipe']).decode())
+        r = self.recipe
+        self.cfg = C.model_config(r['model'], z_channels=r['z_channels'])
+        self.dataset = r['dataset']
+        self.grid = r['grid']
+        self.rays = self.arrays['rays']
+        self.rgb = self.arrays['rgb']
+        self._sd = None
+
+    @property
+    def state_dict(self):
+        if self._sd is None:
+            r = self.recipe
+            self._sd = scenes.make_state_dict(self.cfg, self.dataset, r['grid'], r['seed'], r['density'], r['app_scale'])
+            got = scenes.state_dict_checksum(self._sd)
+            assert abs(got - r['checksum']) <= 1e-6 * max(1.0, abs(r['checksum'])), \
+                f'regenerated weights differ from the ones the golden was made with ({got} vs {r["checksum"]})'
+        return self._sd
+
+
+def linf(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0

@@ -1,0 +1,35 @@
+"""Pins the numpy oracle against outputs of the reference itself (tests/golden/*.npz,
+made by oracle/refgen/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import Golden, golden_cases, linf
+from hyperreel_oracle import HyperReelOracle
+
+
+@pytest.mark.parametrize('case', golden_cases())
+def test_oracle_matches_reference_golden(case):
+    g = Golden(case)
+    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+    out = orc.render(g.rays, keep='all')
+    # fp32 on both sides; only BLAS summation order / libm ulps differ
+    assert linf(out['rgb'], g.rgb) <= 2e-5
+    if 'distances' in g.arrays:
+        n, Z = g.arrays['distances'].shape
+        d_ref = g.arrays['distances']
+        scale = 1.0 + np.abs(d_ref)
+        assert float(np.max(np.abs(out['distances'].reshape(n, Z) - d_ref) / scale)) <= 2e-5
+        p_ref = g.arrays['points']
+        assert float(np.max(np.abs(out['points'] - p_ref) / (1.0 + np.abs(p_ref)))) <= 2e-5
+        assert linf(out['render_weights'], g.arrays['render_weights']) <= 2e-5
+        cs = g.arrays['color_scale']
+        assert float(np.max(np.abs(out['color_scale'] - cs) / (1.0 + np.abs(cs)))) <= 2e-5
+        if 'base_times' in g.arrays:
+            assert linf(out['base_times'][:, 0, 0], g.arrays['base_times']) == 0.0
+
+
+def test_golden_rgb_is_not_degenerate():
+    for case in golden_cases():
+        g = Golden.__new__(Golden)
+        z = np.load(__import__('os').path.join(__import__('helpers').GOLDEN_DIR, case + '.npz'))
+        assert z['rgb'].std() > 0.02 and np.isfinite(z['rgb']).all()
