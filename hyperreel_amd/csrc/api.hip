@@ -1,0 +1,449 @@
+// C ABI of libhyperreel_hip.so (declared in include/hyperreel_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "hr_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HR_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) return fail(HR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e__));  \
+    } while (0)
+
+const int MAT_MODE[3][2] = {{0, 1}, {0, 2}, {1, 2}};   // tensorf_base.py:231
+const int VEC_MODE[3] = {2, 1, 0};                     // tensorf_base.py:232
+const int MAT_MODE_TIME0[3] = {2, 1, 0};               // tensorf_dynamic.py:48 (first index of each pair)
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct hr_model {
+    hr_config cfg;
+    bool finalized = false;
+    std::map<std::string, DevBuf> raw;     // uploaded tensors, reference layout, device memory
+    std::map<std::string, size_t> expect;  // name -> expected byte size
+    // packed MLP
+    float4* wpack[HR_MAX_LAYERS] = {};
+    float* bias[HR_MAX_LAYERS] = {};
+    int n_tiles[HR_MAX_LAYERS] = {};
+    int k0p = 0;
+    int n_out = 0;
+    // packed grids
+    float* grid_a[3] = {};
+    float* grid_b[3] = {};
+    HrGridPlane planes[3] = {};
+    float* basis = nullptr;
+    int n_basis_cols = 0;
+    int ca_total = 0;
+    // workspace
+    float* head = nullptr;
+    int64_t chunk = 0;
+    int64_t packed_bytes = 0;
+};
+
+namespace {
+
+int layer_in(const hr_config& c, int l)
+{
+    if (l == 0) return c.mlp_in;
+    return c.mlp_hidden + (((c.mlp_skip_mask >> l) & 1) ? c.mlp_in : 0);
+}
+
+int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? c.z_channels * c.preds_per_z : c.mlp_hidden; }
+
+int validate(const hr_config& c)
+{
+    if (c.ray_dim != 6 && c.ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8 (got %d)", c.ray_dim);
+    if (c.n_groups < 1 || c.n_groups > HR_MAX_GROUPS) return fail(HR_E_INVALID, "n_groups out of range");
+    if (c.mlp_hidden != 64 && c.mlp_hidden != 128 && c.mlp_hidden != 256)
+        return fail(HR_E_INVALID, "mlp_hidden must be 64, 128 or 256 (got %d)", c.mlp_hidden);
+    if (c.mlp_layers < 2 || c.mlp_layers > HR_MAX_LAYERS) return fail(HR_E_INVALID, "mlp_layers must be in [2,%d]", HR_MAX_LAYERS);
+    if (c.mlp_in < 1 || c.mlp_in > HR_MAX_MLP_IN) return fail(HR_E_INVALID, "mlp_in must be in [1,%d]", HR_MAX_MLP_IN);
+    if (c.mlp_skip_mask & 1) return fail(HR_E_INVALID, "layer 0 cannot be a skip layer");
+    if (c.z_channels < 1 || c.z_channels > HR_MAX_Z) return fail(HR_E_INVALID, "z_channels must be in [1,%d]", HR_MAX_Z);
+    if (c.preds_per_z < 1 || c.preds_per_z > 64) return fail(HR_E_INVALID, "preds_per_z out of range");
+    const hr_head_field* fs[7] = {&c.f_z_vals, &c.f_isect_sigma, &c.f_offset_sigma, &c.f_point_offset,
+                                  &c.f_color_scale, &c.f_color_shift, &c.f_spatial_flow};
+    for (const hr_head_field* f : fs)
+        if (f->offset >= 0 && f->offset + f->channels > c.preds_per_z) return fail(HR_E_INVALID, "head field exceeds preds_per_z");
+    if (c.f_z_vals.offset < 0) return fail(HR_E_INVALID, "z_vals head is required");
+    if (c.isect_type == HR_ISECT_Z_PLANE ? c.f_z_vals.channels != 1 : c.f_z_vals.channels != 4)
+        return fail(HR_E_INVALID, "z_vals needs 1 channel for z_plane and 4 for sphere/cylinder");
+    if ((c.f_color_scale.offset >= 0) != (c.f_color_shift.offset >= 0)) return fail(HR_E_INVALID, "color_scale and color_shift come together");
+    if (c.point_offset && (c.f_point_offset.offset < 0 || c.f_point_offset.channels != 3)) return fail(HR_E_INVALID, "point_offset head missing");
+    if (c.advect && c.use_spatial_flow && (c.f_spatial_flow.offset < 0 || c.f_spatial_flow.channels != 3))
+        return fail(HR_E_INVALID, "spatial_flow head missing");
+    if (c.video && c.ray_dim != 8) return fail(HR_E_INVALID, "video net needs 8-column rays");
+    if (c.video && (!c.advect || c.num_keyframes < 1)) return fail(HR_E_INVALID, "video net needs the advect stage and num_keyframes >= 1");
+    for (int i = 0; i < 3; ++i)
+        if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
+    if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
+    return HR_OK;
+}
+
+void free_dev(float*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hr_abi_version(void) { return HR_ABI_VERSION; }
+
+const char* hr_last_error(void) { return g_err; }
+
+int hr_model_create(const hr_config* cfg, hr_model** out)
+{
+    if (!cfg || !out) return fail(HR_E_INVALID, "null argument");
+    *out = nullptr;
+    int rc = validate(*cfg);
+    if (rc != HR_OK) return rc;
+    int ndev = 0;
+    HR_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(HR_E_HIP, "no HIP device");
+    hr_model* m = new hr_model();
+    m->cfg = *cfg;
+    const hr_config& c = m->cfg;
+    char name[64];
+    for (int l = 0; l < c.mlp_layers; ++l) {
+        snprintf(name, sizeof(name), "mlp.%d.weight", l);
+        m->expect[name] = sizeof(float) * (size_t)layer_out(c, l) * layer_in(c, l);
+        snprintf(name, sizeof(name), "mlp.%d.bias", l);
+        m->expect[name] = sizeof(float) * (size_t)layer_out(c, l);
+    }
+    int n_app_sum = 0;
+    for (int j = 0; j < 3; ++j) {
+        const size_t hw = (size_t)c.grid[MAT_MODE[j][1]] * c.grid[MAT_MODE[j][0]];
+        const char* kinds[2] = {"density", "app"};
+        const int nch[2] = {c.n_den[j], c.n_app[j]};
+        for (int t = 0; t < 2; ++t) {
+            if (c.video) {
+                snprintf(name, sizeof(name), "%s_plane_space.%d", kinds[t], j);
+                m->expect[name] = sizeof(float) * nch[t] * hw;
+                snprintf(name, sizeof(name), "%s_plane_time.%d", kinds[t], j);
+                m->expect[name] = sizeof(float) * (size_t)nch[t] * c.num_keyframes * c.grid[MAT_MODE_TIME0[j]];
+            } else {
+                snprintf(name, sizeof(name), "%s_plane.%d", kinds[t], j);
+                m->expect[name] = sizeof(float) * nch[t] * hw;
+                snprintf(name, sizeof(name), "%s_line.%d", kinds[t], j);
+                m->expect[name] = sizeof(float) * (size_t)nch[t] * c.grid[VEC_MODE[j]];
+            }
+        }
+        n_app_sum += c.n_app[j];
+    }
+    m->expect["basis_mat.weight"] = sizeof(float) * (size_t)c.app_dim * n_app_sum;
+    *out = m;
+    return HR_OK;
+}
+
+int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes)
+{
+    if (!m || !name) return fail(HR_E_INVALID, "null argument");
+    auto it = m->expect.find(name);
+    if (it == m->expect.end()) return fail(HR_E_INVALID, "unknown tensor name '%s'", name);
+    if (bytes != it->second) return fail(HR_E_INVALID, "tensor '%s': expected %zu bytes, got %zu", name, it->second, bytes);
+    if (bytes > 0 && !ptr) return fail(HR_E_INVALID, "tensor '%s': null data", name);
+    DevBuf& b = m->raw[name];
+    if (b.bytes != bytes || (bytes > 0 && !b.p)) {
+        free_dev(b.p);
+        b.bytes = bytes;
+        if (bytes > 0) HR_HIP(hipMalloc((void**)&b.p, bytes));
+    }
+    if (bytes > 0) HR_HIP(hipMemcpy(b.p, ptr, bytes, hipMemcpyDefault));
+    m->finalized = false;
+    return HR_OK;
+}
+
+int hr_model_finalize(hr_model* m)
+{
+    if (!m) return fail(HR_E_INVALID, "null argument");
+    const hr_config& c = m->cfg;
+    for (auto& kv : m->expect)
+        if (m->raw.find(kv.first) == m->raw.end()) return fail(HR_E_MISSING, "tensor '%s' was never uploaded", kv.first.c_str());
+    m->packed_bytes = 0;
+    char name[64];
+
+    // ---- MLP: MFMA B-operand tiles (layout documented in hr_kernels.h)
+    const int W = c.mlp_hidden;
+    m->k0p = (c.mlp_in + 15) & ~15;
+    m->n_out = c.z_channels * c.preds_per_z;
+    for (int l = 0; l < c.mlp_layers; ++l) {
+        const int N = layer_out(c, l), Kt = layer_in(c, l);
+        const bool first = (l == 0);
+        const bool skip = (c.mlp_skip_mask >> l) & 1;
+        const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
+        const int nt = (N + 15) / 16;
+        std::vector<float> w((size_t)N * Kt), b(N);
+        snprintf(name, sizeof(name), "mlp.%d.weight", l);
+        HR_HIP(hipMemcpy(w.data(), m->raw[name].p, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        snprintf(name, sizeof(name), "mlp.%d.bias", l);
+        HR_HIP(hipMemcpy(b.data(), m->raw[name].p, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float> pk((size_t)(Kp / 16) * nt * 64 * 4, 0.0f);
+        for (int kt = 0; kt < Kp / 16; ++kt)
+            for (int t = 0; t < nt; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int n = 16 * t + (lane & 15);
+                        const int kk = 16 * kt + 4 * (lane >> 4) + s;   // kernel K index
+                        int col = -1;                                     // torch in-feature index
+                        if (first) {
+                            if (kk < c.mlp_in) col = kk;
+                        } else if (skip) {
+                            if (kk < m->k0p) { if (kk < c.mlp_in) col = kk; }
+                            else col = c.mlp_in + (kk - m->k0p);          // cat([input, x]), mlp.py:166-168
+                        } else {
+                            col = kk;
+                        }
+                        float v = 0.0f;
+                        if (n < N && col >= 0 && col < Kt) v = w[(size_t)n * Kt + col];
+                        pk[(((size_t)kt * nt + t) * 64 + lane) * 4 + s] = v;
+                    }
+        free_dev(reinterpret_cast<float*&>(m->wpack[l]));
+        free_dev(m->bias[l]);
+        HR_HIP(hipMalloc((void**)&m->wpack[l], pk.size() * sizeof(float)));
+        HR_HIP(hipMemcpy(m->wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+        const int nb = nt * 16;
+        std::vector<float> bp(nb, 0.0f);
+        for (int i = 0; i < N; ++i) bp[i] = b[i];
+        HR_HIP(hipMalloc((void**)&m->bias[l], nb * sizeof(float)));
+        HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+        m->n_tiles[l] = nt;
+        m->packed_bytes += (int64_t)(pk.size() + nb) * sizeof(float);
+    }
+
+    // ---- grids: channel-last texels, density | appearance interleaved per plane pair
+    int app_off = 0, real_off = 0;
+    for (int j = 0; j < 3; ++j) {
+        HrGridPlane& g = m->planes[j];
+        g = HrGridPlane();
+        free_dev(m->grid_a[j]);
+        free_dev(m->grid_b[j]);
+        int nd = c.n_den[j], na = c.n_app[j];
+        // tensorf_dynamic.py:310-311,355-356: a plane pair whose DENSITY plane has no
+        // components is skipped for density and appearance alike
+        if (c.video && nd == 0) na = 0;
+        g.cd4 = (nd + 3) / 4;
+        g.ca4 = (na + 3) / 4;
+        g.aw = c.grid[MAT_MODE[j][0]];
+        g.ah = c.grid[MAT_MODE[j][1]];
+        g.ax = MAT_MODE[j][0];
+        g.ay = MAT_MODE[j][1];
+        if (c.video) {
+            g.bw = c.grid[MAT_MODE_TIME0[j]];
+            g.bh = c.num_keyframes;
+            g.bx = MAT_MODE_TIME0[j];
+        } else {
+            g.bw = 1;
+            g.bh = c.grid[VEC_MODE[j]];
+            g.bx = VEC_MODE[j];
+        }
+        g.app_off = app_off;
+        g.app_real = na;
+        g.app_real_off = real_off;
+        app_off += 4 * g.ca4;
+        real_off += na;
+        const int tex = 4 * (g.cd4 + g.ca4);
+        if (tex == 0) continue;
+        const size_t a_bytes = sizeof(float) * (size_t)g.aw * g.ah * tex;
+        const size_t b_bytes = sizeof(float) * (size_t)g.bw * g.bh * tex;
+        HR_HIP(hipMalloc((void**)&m->grid_a[j], a_bytes));
+        HR_HIP(hipMalloc((void**)&m->grid_b[j], b_bytes));
+        HR_HIP(hipMemset(m->grid_a[j], 0, a_bytes));
+        HR_HIP(hipMemset(m->grid_b[j], 0, b_bytes));
+        const char* an = c.video ? "plane_space" : "plane";
+        const char* bn = c.video ? "plane_time" : "line";
+        snprintf(name, sizeof(name), "density_%s.%d", an, j);
+        hr_launch_interleave(m->raw[name].p, m->grid_a[j], nd, g.ah, g.aw, tex, 0, nullptr);
+        snprintf(name, sizeof(name), "app_%s.%d", an, j);
+        hr_launch_interleave(m->raw[name].p, m->grid_a[j], na, g.ah, g.aw, tex, 4 * g.cd4, nullptr);
+        snprintf(name, sizeof(name), "density_%s.%d", bn, j);
+        hr_launch_interleave(m->raw[name].p, m->grid_b[j], nd, g.bh, g.bw, tex, 0, nullptr);
+        snprintf(name, sizeof(name), "app_%s.%d", bn, j);
+        hr_launch_interleave(m->raw[name].p, m->grid_b[j], na, g.bh, g.bw, tex, 4 * g.cd4, nullptr);
+        g.a = m->grid_a[j];
+        g.b = m->grid_b[j];
+        m->packed_bytes += (int64_t)(a_bytes + b_bytes);
+    }
+    m->ca_total = app_off;
+    // basis_mat columns follow the reference's torch.cat over the sampled planes.  For the
+    // video net a skipped plane pair contributes no columns; its n_app must then be 0 too
+    // (otherwise the reference itself fails with a shape error in basis_mat).
+    int n_app_sum = 0;
+    for (int j = 0; j < 3; ++j) n_app_sum += c.n_app[j];
+    if (real_off != n_app_sum) return fail(HR_E_INVALID, "video net: n_lamb_sh must be 0 wherever n_lamb_sigma is 0");
+    m->n_basis_cols = n_app_sum;
+    free_dev(m->basis);
+    {
+        const size_t bytes = m->raw["basis_mat.weight"].bytes;
+        HR_HIP(hipMalloc((void**)&m->basis, bytes > 0 ? bytes : 16));
+        if (bytes > 0) HR_HIP(hipMemcpy(m->basis, m->raw["basis_mat.weight"].p, bytes, hipMemcpyDeviceToDevice));
+        m->packed_bytes += (int64_t)bytes;
+    }
+    HR_HIP(hipDeviceSynchronize());
+    HR_HIP(hipGetLastError());
+    m->finalized = true;
+    if (m->chunk == 0) return hr_model_reserve(m, 32768);
+    return HR_OK;
+}
+
+int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
+{
+    if (!m) return fail(HR_E_INVALID, "null argument");
+    if (rays_per_chunk < 64) rays_per_chunk = 64;
+    rays_per_chunk = (rays_per_chunk + 63) & ~(int64_t)63;
+    if (rays_per_chunk == m->chunk && m->head) return HR_OK;
+    free_dev(m->head);
+    m->chunk = 0;
+    const size_t bytes = sizeof(float) * (size_t)rays_per_chunk * m->cfg.z_channels * m->cfg.preds_per_z;
+    HR_HIP(hipMalloc((void**)&m->head, bytes));
+    m->chunk = rays_per_chunk;
+    return HR_OK;
+}
+
+static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n)
+{
+    a.rays = rays;
+    a.n_rays = n;
+    a.head = m->head;
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+        a.wpack[l] = m->wpack[l];
+        a.bias[l] = m->bias[l];
+        a.n_tiles[l] = m->n_tiles[l];
+    }
+    a.n_out = m->n_out;
+    a.k0p = m->k0p;
+}
+
+static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
+{
+    a.rays = rays;
+    a.head = m->head;
+    a.n_rays = n;
+    a.rgb = rgb;
+    a.fields = hr_fields();
+    for (int j = 0; j < 3; ++j) a.planes[j] = m->planes[j];
+    a.basis = m->basis;
+    a.n_basis_cols = m->n_basis_cols;
+    a.ca_total = m->ca_total;
+}
+
+static int check_render(const hr_model* m, const float* rays, int64_t n, const float* rgb)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
+    if (n < 0) return fail(HR_E_INVALID, "negative ray count");
+    if (n > 0 && (!rays || !rgb)) return fail(HR_E_INVALID, "null ray / rgb buffer");
+    return HR_OK;
+}
+
+int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, const hr_fields* fields, void* stream)
+{
+    int rc = check_render(m, rays_dev, n_rays, rgb_dev);
+    if (rc != HR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const hr_config& c = m->cfg;
+    const int Z = c.z_channels;
+    for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
+        const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
+        const float* rays = rays_dev + r0 * c.ray_dim;
+        HrMlpArgs ma;
+        fill_mlp_args(m, ma, rays, n);
+        hr_launch_mlp(c, ma, st);
+        HrSampleArgs sa;
+        fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
+        if (fields) {
+            if (fields->distances_dev) sa.fields.distances_dev = fields->distances_dev + r0 * Z;
+            if (fields->points_dev) sa.fields.points_dev = fields->points_dev + r0 * Z * 3;
+            if (fields->sigma_dev) sa.fields.sigma_dev = fields->sigma_dev + r0 * Z;
+            if (fields->weights_dev) sa.fields.weights_dev = fields->weights_dev + r0 * Z;
+            if (fields->head_dev)
+                HR_HIP(hipMemcpyAsync(fields->head_dev + r0 * m->n_out, m->head, sizeof(float) * (size_t)n * m->n_out,
+                                      hipMemcpyDeviceToDevice, st));
+        }
+        hr_launch_samples(c, sa, st);
+    }
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream)
+{
+    return hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
+}
+
+int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream)
+{
+    int rc = check_render(m, rays_dev, n_rays, rays_dev);
+    if (rc != HR_OK) return rc;
+    if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
+    HrMlpArgs ma;
+    fill_mlp_args(m, ma, rays_dev, n_rays);
+    hr_launch_mlp(m->cfg, ma, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream)
+{
+    int rc = check_render(m, rays_dev, n_rays, rgb_dev);
+    if (rc != HR_OK) return rc;
+    if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
+    HrSampleArgs sa;
+    fill_sample_args(m, sa, rays_dev, n_rays, rgb_dev);
+    hr_launch_samples(m->cfg, sa, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int64_t hr_model_device_bytes(const hr_model* m)
+{
+    if (!m) return 0;
+    int64_t raw = 0;
+    for (auto& kv : m->raw) raw += (int64_t)kv.second.bytes;
+    return raw + m->packed_bytes + (int64_t)sizeof(float) * m->chunk * m->cfg.z_channels * m->cfg.preds_per_z;
+}
+
+void hr_model_destroy(hr_model* m)
+{
+    if (!m) return;
+    for (auto& kv : m->raw) free_dev(kv.second.p);
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+        free_dev(reinterpret_cast<float*&>(m->wpack[l]));
+        free_dev(m->bias[l]);
+    }
+    for (int j = 0; j < 3; ++j) {
+        free_dev(m->grid_a[j]);
+        free_dev(m->grid_b[j]);
+    }
+    free_dev(m->basis);
+    free_dev(m->head);
+    delete m;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Internal interface between the C-ABI layer (api.hip) and the kernels.
+#ifndef HR_KERNELS_H
+#define HR_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hyperreel_hip.h"
+
+// ---------------------------------------------------------------- MLP (mlp_kernel.hip)
+// Weights of layer L are stored as MFMA B-operand tiles for v_mfma_f32_16x16x4_f32:
+//   wpack[L][((kt * n_tiles[L]) + nt) * 64 + lane] = float4{ W[n][k0], W[n][k0+1], W[n][k0+2], W[n][k0+3] }
+//   with n = 16*nt + (lane & 15), k0 = 16*kt + 4*(lane >> 4)
+// (W[n][k] = torch weight (out=n, in=k) in the kernel's K order; zero outside the real matrix).
+// K order: plain layers: hidden index.  Layer 0: input feature index, padded to k0p.
+// Skip layers: [input features padded to k0p | hidden].
+struct HrMlpArgs {
+    const float* rays;
+    int64_t n_rays;
+    float* head;                 // (n_rays, n_out) raw output of the last Linear
+    const float4* wpack[HR_MAX_LAYERS];
+    const float* bias[HR_MAX_LAYERS];
+    int n_tiles[HR_MAX_LAYERS];  // 16-column tiles of layer L (N padded up to 16)
+    int n_out;                   // Z * P
+    int k0p;                     // mlp_in padded to a multiple of 16
+};
+
+// ---------------------------------------------------------------- sample stage (sample_kernel.hip)
+// Packed feature grids.  Texel = [density channels | appearance channels] of one
+// plane-pair index j, channel counts rounded up to a multiple of 4 floats:
+//   static: plane j  [H = N[mat1]][W = N[mat0]][cd4 + ca4], line j [N[vec]][cd4 + ca4]
+//   video:  space j  [H][W][cd4 + ca4],                     time j [K][N[matT0]][cd4 + ca4]
+struct HrGridPlane {
+    const float* a;     // plane (static) / space plane (video)
+    const float* b;     // line (static) / time plane (video)
+    int aw, ah;         // plane width / height in texels
+    int bw, bh;         // line: bw = 1, bh = N[vec];  time plane: bw = N[matT0], bh = K
+    int cd4, ca4;       // density / appearance float4 groups per texel
+    int ax, ay;         // point coordinate index sampled along plane x / y
+    int bx;             // point coordinate index sampled along b's axis (line: y; time plane: x)
+    int app_off;        // first (padded) appearance slot of this plane pair in the per-ray decode matrix
+    int app_real;       // real appearance channels of this plane pair (<= 4*ca4)
+    int app_real_off;   // their first column in basis_mat (position in the reference's torch.cat)
+};
+
+struct HrSampleArgs {
+    const float* rays;
+    const float* head;
+    int64_t n_rays;
+    float* rgb;
+    hr_fields fields;       // optional diagnostics (NULL pointers when unused)
+    HrGridPlane planes[3];
+    const float* basis;     // (app_dim, n_basis_cols) row-major, torch layout
+    int n_basis_cols;       // sum of the real appearance channels of the sampled planes
+    int ca_total;           // padded appearance slots (multiple of 4) = sum 4*ca4
+};
+
+void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
+void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
+
+// layout kernels (pack_kernels.hip)
+// dst[y][x][c_off + c] = src[c][y][x] for c < C  (dst texel stride = tex floats)
+void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
+
+#endif

@@ -1,0 +1,327 @@
+// Per-ray / per-sample arithmetic of the HyperReel forward path, written once and
+// used by the HIP kernels.  Every function is straight-line fp32 with the reference's
+// operation order (file:line cited), so that decisions the reference takes on
+// exact comparisons (masks, branch selection) come out the same way.  The file is also
+// compilable by a plain host C++ compiler (HR_FN expands to `static inline`), which the
+// CPU test-suite uses to check these formulas against the oracle without a GPU
+// (tests/host_math).  The product only ever runs them on the device.
+#ifndef HR_MATH_H
+#define HR_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/hyperreel_hip.h"
+
+#if defined(__HIPCC__)
+#define HR_FN __device__ __forceinline__
+#else
+#define HR_FN static inline
+#endif
+
+// ---------------------------------------------------------------- activations
+// y = act(x*inner + shift)*outer   (nlf/activations.py:53-69,121-137,163-178)
+HR_FN float hr_apply_act(const hr_act& a, float x)
+{
+    float y = x * a.inner + a.shift;
+    if (a.type == HR_ACT_SIGMOID) {
+        y = 1.0f / (1.0f + expf(-y));
+    } else if (a.type == HR_ACT_TANH) {
+        y = tanhf(y);
+    }
+    return y * a.outer;
+}
+
+// ---------------------------------------------------------------- ray features (MLP input)
+// utils/intersect_utils.py:127-150  (|d| < 1e-5 -> 1e12)
+HR_FN float hr_axis_plane_t(float val, float o, float d)
+{
+    float dd = (fabsf(d) < 1e-5f) ? 1e12f : d;
+    return (val - o) / dd;
+}
+
+// nlf/param.py:244-253 (pluecker), :87-115 (two_plane), :20-24 (identity) followed by
+// nlf/pe.py:210-221 (windowed) / :53-66 (basic).  Writes mlp_in floats to `out`
+// (stride 1).  Returns the number written.
+HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
+{
+    int n_out = 0;
+    for (int g = 0; g < c.n_groups; ++g) {
+        const hr_param_group& pg = c.groups[g];
+        // up to 8 parameterised values, kept in registers (all loops over them are unrolled)
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f, x4 = 0.f, x5 = 0.f, x6 = 0.f, x7 = 0.f;
+        int nx = 0;
+        if (pg.fn == HR_PARAM_PLUECKER) {
+            float ox = ray[pg.start + 0] - pg.origin[0];
+            float oy = ray[pg.start + 1] - pg.origin[1];
+            float oz = ray[pg.start + 2] - pg.origin[2];
+            float dx = ray[pg.start + 3], dy = ray[pg.start + 4], dz = ray[pg.start + 5];
+            float nrm = sqrtf(dx * dx + dy * dy + dz * dz);      // F.normalize(p=2, eps=1e-12)
+            nrm = fmaxf(nrm, 1e-12f);
+            dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
+            float mx = oy * dz - oz * dy;                          // torch.cross(o, d)
+            float my = oz * dx - ox * dz;
+            float mz = ox * dy - oy * dx;
+            x0 = dx * pg.a; x1 = dy * pg.a; x2 = dz * pg.a;
+            x3 = mx * pg.b; x4 = my * pg.b; x5 = mz * pg.b;
+            nx = 6;
+        } else if (pg.fn == HR_PARAM_TWO_PLANE) {
+            float ox = ray[pg.start + 0] - pg.origin[0];
+            float oy = ray[pg.start + 1] - pg.origin[1];
+            float oz = ray[pg.start + 2] - pg.origin[2];
+            float dx = ray[pg.start + 3], dy = ray[pg.start + 4], dz = ray[pg.start + 5];
+            float t1 = hr_axis_plane_t(pg.a, oz, dz);
+            float t2 = hr_axis_plane_t(pg.b, oz, dz);
+            x0 = ox + dx * t1; x1 = oy + dy * t1;
+            x2 = ox + dx * t2; x3 = oy + dy * t2;
+            nx = 4;
+        } else {
+            nx = pg.end - pg.start;
+            if (nx > 0) x0 = ray[pg.start + 0];
+            if (nx > 1) x1 = ray[pg.start + 1];
+            if (nx > 2) x2 = ray[pg.start + 2];
+            if (nx > 3) x3 = ray[pg.start + 3];
+            if (nx > 4) x4 = ray[pg.start + 4];
+            if (nx > 5) x5 = ray[pg.start + 5];
+            if (nx > 6) x6 = ray[pg.start + 6];
+            if (nx > 7) x7 = ray[pg.start + 7];
+        }
+#define HR_X(i) ((i) == 0 ? x0 : (i) == 1 ? x1 : (i) == 2 ? x2 : (i) == 3 ? x3 : (i) == 4 ? x4 : (i) == 5 ? x5 : (i) == 6 ? x6 : x7)
+        const bool ident = (pg.pe_type == HR_PE_NONE) || (pg.pe_type == HR_PE_BASIC) || !pg.pe_exclude_identity;
+        if (ident)
+            for (int i = 0; i < nx; ++i) out[n_out++] = HR_X(i);
+        if (pg.pe_type == HR_PE_WINDOWED) {
+            float f = 1.0f;
+            for (int j = 0; j < pg.pe_n_freqs; ++j) {
+                f = f * pg.pe_freq_mult;                           // freq_multiplier ** (j+1)
+                float bf = pg.pe_base_mult * f;
+                for (int i = 0; i < nx; ++i) out[n_out++] = sinf(bf * HR_X(i));
+                for (int i = 0; i < nx; ++i) out[n_out++] = cosf(bf * HR_X(i));
+            }
+        } else if (pg.pe_type == HR_PE_BASIC) {  // [x, sin(f_j x_i) (i-major, j-minor), cos(...)]
+            for (int i = 0; i < nx; ++i) {
+                float f = 1.0f;
+                for (int j = 0; j < pg.pe_n_freqs; ++j) { f = f * pg.pe_freq_mult; out[n_out++] = sinf(f * HR_X(i)); }
+            }
+            for (int i = 0; i < nx; ++i) {
+                float f = 1.0f;
+                for (int j = 0; j < pg.pe_n_freqs; ++j) { f = f * pg.pe_freq_mult; out[n_out++] = cosf(f * HR_X(i)); }
+            }
+        }
+#undef HR_X
+    }
+    return n_out;
+}
+
+// ---------------------------------------------------------------- contraction (nlf/contract.py)
+// inverse_contract_distance, contract.py:143-158 (identity distance_activation)
+HR_FN float hr_inverse_contract_distance(const hr_config& c, float distance)
+{
+    distance = (distance / 2.0f) * 2.0f;
+    distance = fminf(fmaxf(distance, -2.0f), 2.0f);
+    float t = 2.0f - fabsf(distance);
+    float inv = t / c.c_d_scale + c.c_d_inv_end;
+    float sgn = (distance > 0.0f) ? 1.0f : ((distance < 0.0f) ? -1.0f : 0.0f);
+    float r = (fabsf(distance) < 1.0f) ? distance : sgn * (1.0f / inv);
+    return r * c.c_d0;
+}
+
+// contract_points, contract.py:178-192
+HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, float* q)
+{
+    px = px / c.c_r0; py = py / c.c_r0; pz = pz / c.c_r0;
+    float dist = sqrtf(px * px + py * py + pz * pz);
+    if (dist < 1.0f) {
+        q[0] = px; q[1] = py; q[2] = pz;
+    } else {
+        float inv = 1.0f / fabsf(dist);
+        float t = (inv - c.c_r_inv_end) * c.c_r_scale;
+        float s = 2.0f - t;
+        q[0] = (px / dist) * s; q[1] = (py / dist) * s; q[2] = (pz / dist) * s;
+    }
+}
+
+// ---------------------------------------------------------------- ray / primitive intersection
+// utils/intersect_utils.py:45-84 (sphere) and :86-125 (cylinder: the xz components)
+HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius)
+{
+    float a = dd;
+    float b = 2.0f * od;
+    float cc = oo - radius * radius;
+    float disc = b * b - 4.0f * a * cc;
+    disc = (disc < 0.0f) ? 0.0f : disc;
+    float sq = sqrtf(disc + 1e-8f);
+    float t1 = (-b + sq) / (2.0f * a);
+    float t2 = (-b - sq) / (2.0f * a);
+    t1 = (disc <= 0.0f) ? 0.0f : t1;
+    t2 = (disc <= 0.0f) ? 0.0f : t2;
+    return ((t2 < 0.0f) || (radius < 0.0f)) ? t1 : t2;
+}
+
+// Pre-sort distance of sample k (Intersect.forward, intersect/base.py:142-203):
+// head activation -> z activation * (1 - sigma) -> anchors/scale -> inverse contraction
+// -> closed-form intersection -> near/far mask.  `hk` points at the P raw head values of
+// sample k; `ro`/`rd` are the ray origin (minus intersect origin) and direction.
+HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const float* ro, const float* rd)
+{
+    float sigma = 0.0f;
+    if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
+    float one_m = 1.0f - sigma;
+    float dist;
+    if (c.isect_type == HR_ISECT_Z_PLANE) {
+        float z = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset])) * one_m;
+        z = z * c.z_scale + c.samples[k];                            // base.py:129
+        if (c.contract_samples) z = hr_inverse_contract_distance(c, z);
+        dist = hr_axis_plane_t(z, ro[2], rd[2]);                     // z.py:88-95
+    } else {
+        float zz[4];
+        for (int i = 0; i < 4; ++i)
+            zz[i] = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + i])) * one_m;
+        float sx = zz[0] * c.origin_scale + c.origin_initial[0];     // primitive.py:410-412
+        float sy = zz[1] * c.origin_scale + c.origin_initial[1];
+        float sz = zz[2] * c.origin_scale + c.origin_initial[2];
+        float radius = zz[3] * c.z_scale + c.samples[k];
+        if (c.contract_samples) radius = hr_inverse_contract_distance(c, radius);
+        float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
+        float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
+        if (c.isect_type == HR_ISECT_SPHERE) {
+            float oo = ox * ox + oy * oy + oz * oz;
+            float dd = dx * dx + dy * dy + dz * dz;
+            float od = ox * dx + oy * dy + oz * dz;
+            dist = hr_quadratic_t(oo, dd, od, radius);
+        } else {
+            float oo = ox * ox + oz * oz;
+            float dd = dx * dx + dz * dz;
+            float od = ox * dx + oz * dz;
+            dist = hr_quadratic_t(oo, dd, od, radius);
+        }
+    }
+    bool mask = (dist <= c.near) || (dist >= c.far);                 // base.py:194
+    return mask ? 0.0f : dist;
+}
+
+// get_base_time, utils/flow_utils.py:10-35 (jitter off).  rintf == torch.round (half to even).
+HR_FN float hr_base_time(const hr_config& c, float t)
+{
+    if (c.num_keyframes <= 0) return 0.0f;
+    float tt = t * c.flow_fac;
+    tt = fminf(fmaxf(tt, 0.0f), c.flow_kmax);
+    return rintf(tt - 1e-5f) * c.flow_inv_fac;
+}
+
+// Everything between the sort and the colour net for the sample of sorted rank k
+// (base.py:212-257 points + contraction + re-mask; point.py:780-831 advect;
+// point.py:371-396 offset).  `oc` is the contracted ray origin (hr_contract_point of ro).
+// Outputs the final point and the final distance.
+HR_FN void hr_sample_point(const hr_config& c, const float* hk, float dist_sorted, const float* ro, const float* rd,
+                           const float* oc, float time_offset, float* p, float* dist_out)
+{
+    bool zero = (dist_sorted == 0.0f);
+    float px = ro[0] + rd[0] * dist_sorted;
+    float py = ro[1] + rd[1] * dist_sorted;
+    float pz = ro[2] + rd[2] * dist_sorted;
+    float dist = dist_sorted;
+    if (c.contract_type == HR_CONTRACT_MIPNERF) {
+        float q[3];
+        hr_contract_point(c, px, py, pz, q);
+        float ex = q[0] - oc[0], ey = q[1] - oc[1], ez = q[2] - oc[2];
+        dist = sqrtf(ex * ex + ey * ey + ez * ez);                   // contract.py:43-50
+        px = q[0]; py = q[1]; pz = q[2];
+    }
+    dist = zero ? 0.0f : dist;                                       // base.py:246
+    if (c.advect && c.use_spatial_flow) {
+        const hr_head_field& f = c.f_spatial_flow;
+        for (int i = 0; i < 3; ++i) {
+            float fl = hr_apply_act(c.flow_act, hr_apply_act(f.act, hk[f.offset + i]));
+            float add = fl * time_offset;
+            if (i == 0) px = px + add; else if (i == 1) py = py + add; else pz = pz + add;
+        }
+    }
+    if (c.point_offset) {
+        float sig = 0.0f;
+        if (c.f_offset_sigma.offset >= 0) sig = hr_apply_act(c.f_offset_sigma.act, hk[c.f_offset_sigma.offset]);
+        float om = 1.0f - sig;
+        const hr_head_field& f = c.f_point_offset;
+        float o0 = hr_apply_act(c.offset_act, hr_apply_act(f.act, hk[f.offset + 0])) * om;
+        float o1 = hr_apply_act(c.offset_act, hr_apply_act(f.act, hk[f.offset + 1])) * om;
+        float o2 = hr_apply_act(c.offset_act, hr_apply_act(f.act, hk[f.offset + 2])) * om;
+        px = px + o0; py = py + o1; pz = pz + o2;
+    }
+    p[0] = px; p[1] = py; p[2] = pz;
+    *dist_out = dist;
+}
+
+// valid_mask (tensorf_base.py:349-353) & (distances > 0) (tensorf_no_sample.py:156)
+HR_FN bool hr_sample_valid(const hr_config& c, const float* p, float dist)
+{
+    bool out = (c.aabb[0] > p[0]) || (p[0] > c.aabb[3]) || (c.aabb[1] > p[1]) || (p[1] > c.aabb[4]) ||
+               (c.aabb[2] > p[2]) || (p[2] > c.aabb[5]);
+    return (!out) && (dist > 0.0f);
+}
+
+// normalize_coord (tensorf_base.py:308-309)
+HR_FN float hr_normalize_coord(const hr_config& c, float v, int axis)
+{
+    return (v - c.aabb[axis]) * c.inv_size[axis] - 1.0f;
+}
+
+// normalize_time_coord (tensorf_dynamic.py:615-616)
+HR_FN float hr_normalize_time(const hr_config& c, float base_t)
+{
+    return (base_t * c.time_scale + c.time_offset) * 2.0f - 1.0f;
+}
+
+// feature2density (tensorf_no_sample.py:82-88 / tensorf_dynamic.py:386-391)
+HR_FN float hr_density(const hr_config& c, float f)
+{
+    if (c.density_act == HR_DENSITY_RELU) return fmaxf(f, 0.0f);
+    if (c.density_act == HR_DENSITY_RELU_ABS) return fabsf(f);
+    float z = f + c.density_shift;                                   // F.softplus, threshold 20
+    return (z > 20.0f) ? z : log1pf(expf(z));
+}
+
+// eval_sh_bases(2, d) (utils/sh_utils.py:94-119)
+HR_FN void hr_sh_deg2(float x, float y, float z, float* sh)
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f;
+    const float C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    sh[0] = C0;
+    sh[1] = -C1 * y;
+    sh[2] = C1 * z;
+    sh[3] = -C1 * x;
+    sh[4] = C20 * xy;
+    sh[5] = C21 * yz;
+    sh[6] = C22 * (2.0f * zz - xx - yy);
+    sh[7] = C23 * xz;
+    sh[8] = C24 * (xx - yy);
+}
+
+// One axis of F.grid_sample(align_corners=True, padding_mode='zeros'): unnormalise,
+// floor, the two weights in ATen's form ((x1 - ix), (ix - x0)), and validity of the two taps.
+struct hr_axis_tap {
+    int i0;            // clamped index of the low tap
+    int i1;            // clamped index of the high tap
+    float w0, w1;      // weights, already zeroed for out-of-range taps
+};
+HR_FN hr_axis_tap hr_make_tap(float g, int n)
+{
+    hr_axis_tap t;
+    float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+    float f0 = floorf(ix);
+    float f1 = f0 + 1.0f;
+    float w0 = f1 - ix;
+    float w1 = ix - f0;
+    int i0 = (int)f0;
+    int i1 = i0 + 1;
+    bool ok0 = (i0 >= 0) && (i0 < n);
+    bool ok1 = (i1 >= 0) && (i1 < n);
+    t.w0 = ok0 ? w0 : 0.0f;
+    t.w1 = ok1 ? w1 : 0.0f;
+    t.i0 = ok0 ? i0 : 0;
+    t.i1 = ok1 ? i1 : 0;
+    return t;
+}
+
+#endif  // HR_MATH_H

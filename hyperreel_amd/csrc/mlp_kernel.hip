@@ -1,0 +1,187 @@
+// K1 -- the ray-conditioned sample-prediction MLP (reference: RayPredictionEmbedding.forward,
+// nlf/embedding/ray.py:316-347 -> BaseMLP.forward, nlf/nets/mlp.py:159-172), one launch for
+// all layers.
+//
+// CDNA4 mapping
+//   * a workgroup (4 waves) owns a tile of 64 rays and walks all Linear layers with the
+//     tile's activations resident in LDS (64 x (W+4) fp32 = 66.5 KB for W = 256): no
+//     activation ever goes to HBM between layers;
+//   * every GEMM runs on the matrix cores with v_mfma_f32_16x16x4_f32 (exact fp32, the
+//     numerics of an fmaf chain -> the 1e-4 RGB bar holds with margin).  Wave w owns output
+//     columns [w*W/4, (w+1)*W/4): 4 (rows) x NT (cols) accumulator tiles = 64 VGPRs;
+//   * A fragments come from LDS with one ds_read_b128 per 16x16 tile and 4 k-steps (the
+//     k index inside a 16-wide K block is permuted so that a lane's 4 values are
+//     contiguous); rows are padded by 4 floats so the 16 rows of a fragment land on
+//     distinct 16-byte bank slots;
+//   * B fragments (weights) are pre-tiled on the host side of the ABI into exactly the
+//     lane order of the MFMA operand, so one global_load_dwordx4 per tile per 4 k-steps,
+//     fully coalesced (1 KiB per wave-instruction), served from L2 (1.6 MB of weights);
+//   * 2 workgroups per CU (75 KB LDS each, <=128 VGPR): one wave's loads and epilogue hide
+//     behind the other's MFMA stream.
+#include "hr_kernels.h"
+#include "hr_math.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define HR_TILE_M 64
+
+template <int NT>
+__device__ __forceinline__ void hr_mlp_accumulate(floatx4 (&acc)[4][NT], const float* __restrict__ src, int stride,
+                                                  int nkt, const float4* __restrict__ wp, int kt0, int tiles_total,
+                                                  const int (&tile)[NT], int lane)
+{
+    const float* arow = src + (lane & 15) * stride + 4 * (lane >> 4);
+#pragma unroll 2
+    for (int kt = 0; kt < nkt; ++kt) {
+        float4 av[4];
+        float4 bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) av[mt] = *reinterpret_cast<const float4*>(arow + mt * 16 * stride + kt * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[((size_t)(kt0 + kt) * tiles_total + tile[nt]) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void hr_mlp_kernel(const hr_config cfg, const HrMlpArgs a)
+{
+    constexpr int W = 64 * NT;       // hidden width
+    constexpr int XS = W + 4;        // LDS row stride of the hidden activations
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int k0p = a.k0p;
+    const int XSI = k0p + 4;
+    float* Xin = lds;                // [64][k0p + 4]  PE'd MLP input (kept for skip layers)
+    float* X = lds + HR_TILE_M * XSI;  // [64][W + 4]  hidden activations
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t ray0 = (int64_t)blockIdx.x * HR_TILE_M;
+
+    // ---- prologue: ray parameterisation + positional encoding -> Xin
+    if (tid < HR_TILE_M) {
+        const int64_t r = ray0 + tid;
+        float* row = Xin + tid * XSI;
+        int n = 0;
+        if (r < a.n_rays) n = hr_ray_features(cfg, a.rays + r * cfg.ray_dim, row);
+        for (int i = n; i < k0p; ++i) row[i] = 0.0f;
+    }
+    __syncthreads();
+
+    const int L = cfg.mlp_layers;
+    // ---- hidden layers
+    for (int l = 0; l + 1 < L; ++l) {
+        floatx4 acc[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int tile[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tile[nt] = wave * NT + nt;
+        const bool skip = (cfg.mlp_skip_mask >> l) & 1;
+        int kt0 = 0;
+        if (l == 0 || skip) {
+            hr_mlp_accumulate<NT>(acc, Xin, XSI, k0p / 16, a.wpack[l], 0, a.n_tiles[l], tile, lane);
+            kt0 = k0p / 16;
+        }
+        if (l > 0) hr_mlp_accumulate<NT>(acc, X, XS, W / 16, a.wpack[l], kt0, a.n_tiles[l], tile, lane);
+        __syncthreads();  // every wave has finished reading X
+        const float* bias = a.bias[l];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = tile[nt] * 16 + (lane & 15);
+            const float b = bias[col];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mt][nt][r] + b;
+                    v = (v > 0.0f) ? v : v * cfg.leaky_slope;   // nn.LeakyReLU(0.01), mlp.py:149-154
+                    X[(mt * 16 + 4 * (lane >> 4) + r) * XS + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- last Linear (no activation): N = Z*P columns in passes of 4 waves x NT tiles
+    {
+        const int l = L - 1;
+        const int tiles_total = a.n_tiles[l];
+        const bool skip = (cfg.mlp_skip_mask >> l) & 1;
+        const float* bias = a.bias[l];
+        for (int t0 = 0; t0 < tiles_total; t0 += 4 * NT) {
+            floatx4 acc[4][NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+            int tile[NT], tile_ld[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                tile[nt] = t0 + wave * NT + nt;
+                tile_ld[nt] = min(tile[nt], tiles_total - 1);   // out-of-range tiles compute garbage, never stored
+            }
+            if (tile[0] >= tiles_total) continue;               // wave-uniform
+            int kt0 = 0;
+            if (skip) {
+                hr_mlp_accumulate<NT>(acc, Xin, XSI, k0p / 16, a.wpack[l], 0, tiles_total, tile_ld, lane);
+                kt0 = k0p / 16;
+            }
+            hr_mlp_accumulate<NT>(acc, X, XS, W / 16, a.wpack[l], kt0, tiles_total, tile_ld, lane);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = tile[nt] * 16 + (lane & 15);
+                if (tile[nt] < tiles_total && col < a.n_out) {
+                    const float b = bias[col];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t row = ray0 + mt * 16 + 4 * (lane >> 4) + r;
+                            if (row < a.n_rays) a.head[row * a.n_out + col] = acc[mt][nt][r] + b;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static void hr_launch_mlp_nt(const hr_config& cfg, const HrMlpArgs& args, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    // more than 64 KiB of dynamic LDS has to be opted into once per kernel
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allowed = lds;
+    }
+    hipLaunchKernelGGL(hr_mlp_kernel<NT>, dim3(blocks), dim3(256), lds, stream, cfg, args);
+}
+
+void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
+{
+    if (args.n_rays <= 0) return;
+    const int W = cfg.mlp_hidden;
+    const size_t lds = (size_t)HR_TILE_M * ((args.k0p + 4) + (W + 4)) * sizeof(float);
+    const unsigned blocks = (unsigned)((args.n_rays + HR_TILE_M - 1) / HR_TILE_M);
+    switch (W / 64) {
+        case 4: hr_launch_mlp_nt<4>(cfg, args, blocks, lds, stream); break;
+        case 2: hr_launch_mlp_nt<2>(cfg, args, blocks, lds, stream); break;
+        case 1: hr_launch_mlp_nt<1>(cfg, args, blocks, lds, stream); break;
+        default: break;  // rejected by hr_model_create
+    }
+}

@@ -1,0 +1,27 @@
+// One-time layout transforms run by hr_model_finalize (not on the render path).
+#include "hr_kernels.h"
+
+// Reference planes are channel-first (1, C, H, W) (nlf/nets/tensorf_base.py:911-948,
+// nlf/nets/tensorf_dynamic.py:126-173).  The sample kernel wants channel-last texels with
+// the density and appearance channels of one plane side by side:
+//   dst[(y*W + x)*tex + c_off + c] = src[(c*H + y)*W + x]
+__global__ void hr_interleave_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
+                                     int tex, int c_off)
+{
+    const int64_t n = (int64_t)C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the destination order (y, x, c) so that writes are contiguous per texel
+        const int c = (int)(i % C);
+        const int64_t yx = i / C;
+        dst[yx * tex + c_off + c] = src[(int64_t)c * H * W + yx];
+    }
+}
+
+void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream)
+{
+    const int64_t n = (int64_t)C * H * W;
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(hr_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, C, H, W, tex, c_off);
+}

@@ -1,0 +1,347 @@
+// K2+K3 -- everything after the MLP, one lane per (ray, sample):
+//   head activations -> ray/primitive intersection -> near/far mask -> per-ray sort ->
+//   points -> contraction -> advect -> offset   (reference: Intersect.forward,
+//   nlf/intersect/base.py:142-259; nlf/embedding/point.py:371-396,780-831)
+//   -> VM feature gather -> density -> alpha/transmittance -> colour decode -> composite
+//   (TensorVMNoSample.forward, nlf/nets/tensorf_no_sample.py:128-280;
+//    TensorVMKeyframeTime.forward, nlf/nets/tensorf_dynamic.py:645-839;
+//    raw2alpha, utils/tensorf_utils.py:242-253).
+//
+// CDNA4 mapping
+//   * the Z samples of a ray sit in adjacent lanes of ONE wavefront (ZP = 16/32/64 lanes),
+//     so the per-ray sort is an in-register bitonic network over DPP/bpermute shuffles,
+//     the transmittance is a wave-level segmented prefix product and the final colour a
+//     segmented butterfly sum -- no LDS round trips, no atomics, no global intermediates;
+//   * the block's slice of the MLP head is staged once through LDS with coalesced
+//     dwordx4 loads; each lane then reads its P values at an odd dword stride (conflict free);
+//   * feature grids are stored channel-last with density and appearance channels of a
+//     plane interleaved in one texel, so the 4 bilinear taps of a sample are 2 contiguous
+//     runs of 2 texels and every fetch is a 16-byte vector load; density and appearance
+//     features come from the same fetch (one pass over the grid instead of the
+//     reference's two);
+//   * the SH / RGB decode matrix is folded with the ray's SH basis once per ray into LDS
+//     (3 x C_app), so the per-sample decode is 3*C_app FMAs regardless of SH degree.
+#include "hr_kernels.h"
+#include "hr_math.h"
+
+#define HR_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+template <int ZP>
+__device__ __forceinline__ float hr_bitonic_sort(float v, int k)
+{
+#pragma unroll
+    for (int size = 2; size <= ZP; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j, 64);
+            const bool up = ((k & size) == 0);
+            const bool lower = ((k & j) == 0);
+            const float mn = fminf(v, o), mx = fmaxf(v, o);
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    return v;
+}
+
+// weighted sum of the 4 bilinear taps for one float4 channel group, in ATen's order
+// (nw, ne, sw, se; grid_sampler_2d)
+__device__ __forceinline__ float4 hr_bilerp4(const float4 v00, const float4 v01, const float4 v10, const float4 v11,
+                                              float w00, float w01, float w10, float w11)
+{
+    float4 r;
+    r.x = HR_FMA(v11.x, w11, HR_FMA(v10.x, w10, HR_FMA(v01.x, w01, v00.x * w00)));
+    r.y = HR_FMA(v11.y, w11, HR_FMA(v10.y, w10, HR_FMA(v01.y, w01, v00.y * w00)));
+    r.z = HR_FMA(v11.z, w11, HR_FMA(v10.z, w10, HR_FMA(v01.z, w01, v00.z * w00)));
+    r.w = HR_FMA(v11.w, w11, HR_FMA(v10.w, w10, HR_FMA(v01.w, w01, v00.w * w00)));
+    return r;
+}
+
+__device__ __forceinline__ float4 hr_lerp4(const float4 v0, const float4 v1, float w0, float w1)
+{
+    float4 r;
+    r.x = HR_FMA(v1.x, w1, v0.x * w0);
+    r.y = HR_FMA(v1.y, w1, v0.y * w0);
+    r.z = HR_FMA(v1.z, w1, v0.z * w0);
+    r.w = HR_FMA(v1.w, w1, v0.w * w0);
+    return r;
+}
+
+template <int ZP>
+__global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
+{
+    constexpr int RPB = 256 / ZP;   // rays per block
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Z = cfg.z_channels;
+    const int P = cfg.preds_per_z;
+    const int ZPn = Z * P;
+    const int CA = a.ca_total;                   // padded appearance slots (multiple of 4)
+    float* s_head = lds;                           // [RPB][Z*P]
+    float* s_M = lds + ((RPB * ZPn + 3) & ~3);     // [RPB][3][CA]
+
+    const int tid = threadIdx.x;
+    const int rib = tid / ZP;
+    const int k = tid % ZP;
+    const int64_t ray_base = (int64_t)blockIdx.x * RPB;
+    const int64_t ray = ray_base + rib;
+    const bool ray_ok = ray < a.n_rays;
+    const bool lane_ok = ray_ok && (k < Z);
+
+    // ---- stage this block's head rows (contiguous in memory) into LDS
+    {
+        const int64_t n_here = min((int64_t)RPB, a.n_rays - ray_base);
+        const int total = (int)(n_here * ZPn);
+        const float* src = a.head + ray_base * ZPn;
+        if ((((uintptr_t)src) & 15) == 0) {
+            const int n4 = total >> 2;
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            float4* dst4 = reinterpret_cast<float4*>(s_head);
+            for (int i = tid; i < n4; i += 256) dst4[i] = src4[i];
+            for (int i = (n4 << 2) + tid; i < total; i += 256) s_head[i] = src[i];
+        } else {
+            for (int i = tid; i < total; i += 256) s_head[i] = src[i];
+        }
+    }
+
+    // ---- per-ray quantities (computed redundantly by the ray's lanes)
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 1.f}, vd[3] = {0.f, 0.f, 1.f};
+    float t_ray = 0.0f;
+    if (ray_ok) {
+        const float* r = a.rays + ray * cfg.ray_dim;
+        ro[0] = r[0] - cfg.isect_origin[0];        // base.py:143-149
+        ro[1] = r[1] - cfg.isect_origin[1];
+        ro[2] = r[2] - cfg.isect_origin[2];
+        rd[0] = r[3]; rd[1] = r[4]; rd[2] = r[5];
+        vd[0] = r[3]; vd[1] = r[4]; vd[2] = r[5];  // viewdirs, point.py:868-869
+        t_ray = r[cfg.ray_dim - 1];                // rays[..., -1], point.py:783
+    }
+
+    // ---- decode matrix of this ray: M[c][ch] (RGB: basis_mat rows; SH: sum_j sh_j(d) * basis row c*9+j)
+    {
+        float sh[9];
+        hr_sh_deg2(vd[0], vd[1], vd[2], sh);
+        float* M = s_M + rib * 3 * CA;
+        const int nat = a.n_basis_cols;
+        for (int e = k; e < 3 * CA; e += ZP) {
+            const int c = e / CA, pos = e - c * CA;
+            // padded slot -> column of basis_mat (the reference concatenates only real channels)
+            int col = -1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int rel = pos - a.planes[j].app_off;
+                if (rel >= 0 && rel < a.planes[j].app_real && a.planes[j].ca4 > 0) col = a.planes[j].app_real_off + rel;
+            }
+            float v = 0.0f;
+            if (col >= 0) {
+                if (cfg.shading == HR_SHADING_SH) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) v = HR_FMA(sh[j], a.basis[(c * 9 + j) * nat + col], v);
+                } else {
+                    v = a.basis[c * nat + col];
+                }
+            }
+            M[e] = v;
+        }
+    }
+    __syncthreads();
+
+    const float* hk = s_head + rib * ZPn + (lane_ok ? k : 0) * P;
+
+    // ---- distances: intersect + mask, then sort along the ray (base.py:152-210)
+    float dist = __builtin_inff();
+    if (lane_ok) dist = hr_sample_distance(cfg, hk, k, ro, rd);
+    if (cfg.sort) dist = hr_bitonic_sort<ZP>(dist, k);
+
+    // ---- points, contraction, advect, offset
+    float oc[3] = {0.f, 0.f, 0.f};
+    if (cfg.contract_type == HR_CONTRACT_MIPNERF) hr_contract_point(cfg, ro[0], ro[1], ro[2], oc);
+    float base_t = 0.0f, time_off = 0.0f;
+    if (cfg.advect) {
+        base_t = hr_base_time(cfg, t_ray);
+        time_off = t_ray - base_t;
+    }
+    float p[3] = {0.f, 0.f, 0.f};
+    float dist_c = 0.0f;
+    if (lane_ok) hr_sample_point(cfg, hk, dist, ro, rd, oc, time_off, p, &dist_c);
+
+    // deltas (tensorf_no_sample.py:137-144)
+    const float dist_next = __shfl_down(dist_c, 1, 64);
+    const float delta = (k == Z - 1) ? 1e10f : (dist_next - dist_c);
+
+    // ---- feature gather
+    const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c);
+    float sig_feat = 0.0f;
+    float pre0 = 0.0f, pre1 = 0.0f, pre2 = 0.0f;
+    if (valid) {
+        float pn[4];
+        pn[0] = hr_normalize_coord(cfg, p[0], 0);
+        pn[1] = hr_normalize_coord(cfg, p[1], 1);
+        pn[2] = hr_normalize_coord(cfg, p[2], 2);
+        pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
+        const float* M = s_M + rib * 3 * CA;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& g = a.planes[j];
+            const int ng = g.cd4 + g.ca4;
+            if (ng == 0) continue;
+            const int tex = ng * 4;
+            const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
+            const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
+            const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
+            const hr_axis_tap tx = hr_make_tap(gx, g.aw);
+            const hr_axis_tap ty = hr_make_tap(gy, g.ah);
+            // ATen: nw = (x1-ix)(y1-iy), ne = (ix-x0)(y1-iy), sw = (x1-ix)(iy-y0), se = (ix-x0)(iy-y0)
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const float* a00 = g.a + (ty.i0 * g.aw + tx.i0) * tex;
+            const float* a01 = g.a + (ty.i0 * g.aw + tx.i1) * tex;
+            const float* a10 = g.a + (ty.i1 * g.aw + tx.i0) * tex;
+            const float* a11 = g.a + (ty.i1 * g.aw + tx.i1) * tex;
+            if (g.bw == 1) {
+                // vector (line) factor: grid x == 0 on a width-1 image -> weight exactly 1 on column 0
+                const hr_axis_tap tl = hr_make_tap(gb, g.bh);
+                const float* b0 = g.b + tl.i0 * tex;
+                const float* b1 = g.b + tl.i1 * tex;
+                for (int q = 0; q < ng; ++q) {
+                    const float4 pa = hr_bilerp4(*reinterpret_cast<const float4*>(a00 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a01 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a10 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a11 + 4 * q), w00, w01, w10, w11);
+                    const float4 pb = hr_lerp4(*reinterpret_cast<const float4*>(b0 + 4 * q),
+                                               *reinterpret_cast<const float4*>(b1 + 4 * q), tl.w0, tl.w1);
+                    const float fx = pa.x * pb.x, fy = pa.y * pb.y, fz = pa.z * pb.z, fw = pa.w * pb.w;
+                    if (q < g.cd4) {
+                        sig_feat = sig_feat + fx; sig_feat = sig_feat + fy; sig_feat = sig_feat + fz; sig_feat = sig_feat + fw;
+                    } else {
+                        const int ch = g.app_off + 4 * (q - g.cd4);
+                        const float4 m0 = *reinterpret_cast<const float4*>(M + ch);
+                        const float4 m1 = *reinterpret_cast<const float4*>(M + CA + ch);
+                        const float4 m2 = *reinterpret_cast<const float4*>(M + 2 * CA + ch);
+                        pre0 = HR_FMA(m0.w, fw, HR_FMA(m0.z, fz, HR_FMA(m0.y, fy, HR_FMA(m0.x, fx, pre0))));
+                        pre1 = HR_FMA(m1.w, fw, HR_FMA(m1.z, fz, HR_FMA(m1.y, fy, HR_FMA(m1.x, fx, pre1))));
+                        pre2 = HR_FMA(m2.w, fw, HR_FMA(m2.z, fz, HR_FMA(m2.y, fy, HR_FMA(m2.x, fx, pre2))));
+                    }
+                }
+            } else {
+                // (axis, time) plane of the keyframe volume: x = spatial coordinate, y = keyframe time
+                const hr_axis_tap bxp = hr_make_tap(gb, g.bw);
+                const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
+                const float v00 = bxp.w0 * byp.w0, v01 = bxp.w1 * byp.w0, v10 = bxp.w0 * byp.w1, v11 = bxp.w1 * byp.w1;
+                const float* b00 = g.b + (byp.i0 * g.bw + bxp.i0) * tex;
+                const float* b01 = g.b + (byp.i0 * g.bw + bxp.i1) * tex;
+                const float* b10 = g.b + (byp.i1 * g.bw + bxp.i0) * tex;
+                const float* b11 = g.b + (byp.i1 * g.bw + bxp.i1) * tex;
+                for (int q = 0; q < ng; ++q) {
+                    const float4 pa = hr_bilerp4(*reinterpret_cast<const float4*>(a00 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a01 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a10 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(a11 + 4 * q), w00, w01, w10, w11);
+                    const float4 pb = hr_bilerp4(*reinterpret_cast<const float4*>(b00 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(b01 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(b10 + 4 * q),
+                                                 *reinterpret_cast<const float4*>(b11 + 4 * q), v00, v01, v10, v11);
+                    const float fx = pa.x * pb.x, fy = pa.y * pb.y, fz = pa.z * pb.z, fw = pa.w * pb.w;
+                    if (q < g.cd4) {
+                        sig_feat = sig_feat + fx; sig_feat = sig_feat + fy; sig_feat = sig_feat + fz; sig_feat = sig_feat + fw;
+                    } else {
+                        const int ch = g.app_off + 4 * (q - g.cd4);
+                        const float4 m0 = *reinterpret_cast<const float4*>(M + ch);
+                        const float4 m1 = *reinterpret_cast<const float4*>(M + CA + ch);
+                        const float4 m2 = *reinterpret_cast<const float4*>(M + 2 * CA + ch);
+                        pre0 = HR_FMA(m0.w, fw, HR_FMA(m0.z, fz, HR_FMA(m0.y, fy, HR_FMA(m0.x, fx, pre0))));
+                        pre1 = HR_FMA(m1.w, fw, HR_FMA(m1.z, fz, HR_FMA(m1.y, fy, HR_FMA(m1.x, fx, pre1))));
+                        pre2 = HR_FMA(m2.w, fw, HR_FMA(m2.z, fz, HR_FMA(m2.y, fy, HR_FMA(m2.x, fx, pre2))));
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- density -> alpha -> transmittance -> weight (raw2alpha, tensorf_utils.py:242-253)
+    const float sigma = valid ? hr_density(cfg, sig_feat) : 0.0f;
+    const float alpha = lane_ok ? (1.0f - expf(-sigma * (delta * cfg.distance_scale))) : 0.0f;
+    float inc = lane_ok ? ((1.0f - alpha) + 1e-10f) : 1.0f;
+#pragma unroll
+    for (int d = 1; d < ZP; d <<= 1) {
+        const float o = __shfl_up(inc, d, 64);
+        if (k >= d) inc = inc * o;
+    }
+    float T = __shfl_up(inc, 1, 64);
+    if (k == 0) T = 1.0f;
+    const float weight = alpha * T;
+
+    // ---- colour decode (+ per-sample scale/shift) and front-to-back sum
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    if (lane_ok) {
+        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        if (weight > cfg.weight_thresh) {          // app_mask, tensorf_no_sample.py:201
+            if (cfg.shading == HR_SHADING_SH) {    // SHRender, tensorf_utils.py:334-338
+                r0 = fmaxf(pre0 + 0.5f, 0.0f); r1 = fmaxf(pre1 + 0.5f, 0.0f); r2 = fmaxf(pre2 + 0.5f, 0.0f);
+            } else {                               // RGBRender, tensorf_utils.py:341-343
+                r0 = 1.0f / (1.0f + expf(-pre0)); r1 = 1.0f / (1.0f + expf(-pre1)); r2 = 1.0f / (1.0f + expf(-pre2));
+            }
+        }
+        if (cfg.f_color_scale.offset >= 0) {       // scale_shift_color_all, tensorf_utils.py:267-273
+            const hr_head_field& fs = cfg.f_color_scale;
+            const hr_head_field& fh = cfg.f_color_shift;
+            r0 = r0 * (hr_apply_act(fs.act, hk[fs.offset + 0]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 0]);
+            r1 = r1 * (hr_apply_act(fs.act, hk[fs.offset + 1]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 1]);
+            r2 = r2 * (hr_apply_act(fs.act, hk[fs.offset + 2]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 2]);
+        }
+        c0 = weight * r0; c1 = weight * r1; c2 = weight * r2;
+    }
+    float acc_w = lane_ok ? weight : 0.0f;
+#pragma unroll
+    for (int d = ZP >> 1; d > 0; d >>= 1) {
+        c0 += __shfl_xor(c0, d, 64);
+        c1 += __shfl_xor(c1, d, 64);
+        c2 += __shfl_xor(c2, d, 64);
+        acc_w += __shfl_xor(acc_w, d, 64);
+    }
+    if (ray_ok && k == 0) {
+        if (cfg.white_bg) {                        // tensorf_no_sample.py:236-237
+            const float bg = 1.0f - acc_w;
+            c0 += bg; c1 += bg; c2 += bg;
+        }
+        a.rgb[ray * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);   // eval-mode clamp, :246-247
+        a.rgb[ray * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
+        a.rgb[ray * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
+    }
+
+    // ---- optional diagnostics
+    if (lane_ok) {
+        const int64_t s = ray * Z + k;
+        if (a.fields.distances_dev) a.fields.distances_dev[s] = dist_c;
+        if (a.fields.points_dev) {
+            a.fields.points_dev[s * 3 + 0] = p[0];
+            a.fields.points_dev[s * 3 + 1] = p[1];
+            a.fields.points_dev[s * 3 + 2] = p[2];
+        }
+        if (a.fields.sigma_dev) a.fields.sigma_dev[s] = sigma;
+        if (a.fields.weights_dev) a.fields.weights_dev[s] = weight;
+    }
+}
+
+static size_t hr_sample_lds_bytes(const hr_config& cfg, int ca_total, int ZP)
+{
+    const int RPB = 256 / ZP;
+    const int CA = ca_total;
+    const size_t head = ((size_t)RPB * cfg.z_channels * cfg.preds_per_z + 3) & ~(size_t)3;
+    return (head + (size_t)RPB * 3 * CA) * sizeof(float);
+}
+
+void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream)
+{
+    if (args.n_rays <= 0) return;
+    const int Z = cfg.z_channels;
+    int ZP = 8;
+    while (ZP < Z) ZP <<= 1;
+    const int RPB = 256 / ZP;
+    const unsigned blocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
+    const size_t lds = hr_sample_lds_bytes(cfg, args.ca_total, ZP);
+    switch (ZP) {
+        case 8: hipLaunchKernelGGL(hr_sample_kernel<8>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
+        case 16: hipLaunchKernelGGL(hr_sample_kernel<16>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
+        case 32: hipLaunchKernelGGL(hr_sample_kernel<32>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
+        case 64: hipLaunchKernelGGL(hr_sample_kernel<64>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
+        default: break;  // Z > 64 is rejected by hr_model_create
+    }
+}

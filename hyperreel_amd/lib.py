@@ -1,0 +1,70 @@
+"""ctypes binding of libhyperreel_hip.so (include/hyperreel_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails this module
+raises.  The product never routes through PyTorch ops or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+from .plan import hr_config, hr_fields
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libhyperreel_hip.so')
+
+ABI_VERSION = 1
+
+# every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('hr_abi_version', C.c_int, []),
+    ('hr_last_error', C.c_char_p, []),
+    ('hr_model_create', C.c_int, [C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
+    ('hr_model_upload', C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    ('hr_model_finalize', C.c_int, [C.c_void_p]),
+    ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
+    ('hr_render', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ('hr_render_fields', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(hr_fields), C.c_void_p]),
+    ('hr_stage_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ('hr_stage_samples', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ('hr_model_device_bytes', C.c_int64, [C.c_void_p]),
+    ('hr_model_destroy', None, [C.c_void_p]),
+]
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads (once) and returns the ctypes handle.  Raises HipLibraryError when the
+    in-tree library has not been built (`python -m hyperreel_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} is missing: build it with `python -m hyperreel_amd.build` '
+            '(hipcc --offload-arch=gfx950).  hyperreel_amd has no CPU or PyTorch fallback.')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.hr_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f'ABI version mismatch: library {v}, binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hr_last_error()
+        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')

@@ -1,0 +1,354 @@
+"""Host-side mirror of the reference's model objects for the forward-render path.
+
+`HipLightfieldModel` stands where `LightfieldModel` (nlf/models/models.py:104-138) stands
+in the reference: it is built from the same `experiment.model` YAML group and the same
+`system` object, exposes the attributes `INRSystem` touches (`set_iter`,
+`embedding_model`, `color_model.net`, nlf/__init__.py:449-479,608-614) and owns
+nn.Parameters under exactly the reference's state_dict keys, so
+reference checkpoints load by name.  The modules hold weights only -- all arithmetic
+happens in libhyperreel_hip.so, which receives the tensors through hr_model_upload.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import lib as _lib
+from .config import n_to_reso, to_plain
+from .plan import compile_config, hr_fields, upload_names
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+MAT_MODE_TIME = [[2, 3], [1, 3], [0, 3]]
+
+
+def dataset_scalars_from_system(system):
+    """The five `system.dm.train_dataset` reads of the hot path."""
+    td = system.dm.train_dataset
+    get = (lambda k, d=None: td[k] if isinstance(td, dict) and k in td else getattr(td, k, d))
+    return {'near': get('near', 0.0), 'far': get('far', 1.0), 'depth_range': list(get('depth_range', [0.0, 1.0])),
+            'num_keyframes': get('num_keyframes', 1), 'num_frames': get('num_frames', 1)}
+
+
+class _Dummy(nn.Module):
+    """RayParam / PE modules of the reference carry an unused nn.Linear(1,1) `dummy_layer`
+    (nlf/param.py:479, nlf/pe.py:165); kept so strict state_dict loading works."""
+
+    def __init__(self):
+        super().__init__()
+        self.dummy_layer = nn.Linear(1, 1)
+
+
+class _Empty(nn.Module):
+    pass
+
+
+class HostMLP(nn.Module):
+    """Parameter container shaped like BaseMLP (nlf/nets/mlp.py:127-154)."""
+
+    def __init__(self, shapes):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        for i, (o, n_in) in enumerate(shapes):
+            lin = nn.Linear(n_in, o)
+            self.layers.append(nn.Sequential(lin, nn.Identity()) if i < len(shapes) - 1 else lin)
+
+
+class HostRayPrediction(nn.Module):
+    def __init__(self, pred_cfg, shapes):
+        super().__init__()
+        self.params = nn.ModuleList([_Dummy() for _ in pred_cfg['params']])
+        self.pes = nn.ModuleList([_Dummy() if 'pe' in p else _Empty() for p in pred_cfg['params'].values()])
+        self.net = HostMLP(shapes)
+
+
+class HostEmbedding(nn.Module):
+    def __init__(self, cfg, shapes):
+        super().__init__()
+        mods = []
+        for e in cfg['embedding']['embeddings'].values():
+            mods.append(HostRayPrediction(e, shapes) if e['type'] == 'ray_prediction' else _Empty())
+        self.embeddings = nn.ModuleList(mods)
+
+
+class HostTensorVM(nn.Module):
+    """Parameter container shaped like TensorVMSplit (nlf/nets/tensorf_base.py:895-991) or
+    TensorVMKeyframeTime (nlf/nets/tensorf_dynamic.py:108-244)."""
+
+    def __init__(self, net_cfg, grid_size, num_keyframes):
+        super().__init__()
+        self.video = net_cfg['type'] == 'tensor_vm_split_time'
+        self.n_den = list(net_cfg.get('n_lamb_sigma', [8, 8, 8]))
+        self.n_app = list(net_cfg.get('n_lamb_sh', [24, 24, 24]))
+        self.app_dim = int(net_cfg.get('data_dim_color', 27))
+        self.num_keyframes = int(num_keyframes)
+        self.act = net_cfg.get('fea2denseAct', 'softplus')
+        self.register_buffer('aabb', torch.tensor(to_plain(net_cfg['aabb']), dtype=torch.float32))
+        self.register_buffer('gridSize', torch.tensor([int(v) for v in grid_size], dtype=torch.long))
+        self.basis_mat = nn.Linear(sum(self.n_app), self.app_dim, bias=False)
+        if self.video:
+            self.basis_mat_density = nn.Linear(sum(self.n_den), 1, bias=False)
+        self.init_svd_volume(grid_size)
+
+    def _dens(self, shape):
+        if self.act == 'softplus':
+            return 0.1 * torch.randn(shape)
+        return 1e-2 * torch.rand(shape).clamp(1e-2, 1e8)
+
+    def init_svd_volume(self, grid_size, device=None):
+        """(Re)allocates the planes for `grid_size` with the reference's initialisers."""
+        N = [int(v) for v in grid_size]
+        device = device if device is not None else self.aabb.device
+        self.gridSize = torch.tensor(N, dtype=torch.long, device=device)
+        mk = lambda fn, shapes: nn.ParameterList([nn.Parameter(fn(s).to(device)) for s in shapes])
+        app = lambda s: 0.1 * torch.randn(s)
+        plane = lambda n: [(1, n[i], N[MAT_MODE[i][1]], N[MAT_MODE[i][0]]) for i in range(3)]
+        if self.video:
+            time = lambda n: [(1, n[i], self.num_keyframes, N[MAT_MODE_TIME[i][0]]) for i in range(3)]
+            self.density_plane_space = mk(self._dens, plane(self.n_den))
+            self.density_plane_time = mk(self._dens, time(self.n_den))
+            self.app_plane_space = mk(app, plane(self.n_app))
+            self.app_plane_time = mk(app, time(self.n_app))
+        else:
+            line = lambda n: [(1, n[i], N[VEC_MODE[i]], 1) for i in range(3)]
+            self.density_plane = mk(self._dens, plane(self.n_den))
+            self.density_line = mk(self._dens, line(self.n_den))
+            self.app_plane = mk(app, plane(self.n_app))
+            self.app_line = mk(app, line(self.n_app))
+
+    def set_iter(self, i):
+        self.cur_iter = i
+
+
+class HostColorModel(nn.Module):
+    def __init__(self, net_cfg, grid_size, num_keyframes):
+        super().__init__()
+        self.net = HostTensorVM(net_cfg, grid_size, num_keyframes)
+
+    def set_iter(self, i):
+        self.net.set_iter(i)
+
+
+class HipLightfieldModel(nn.Module):
+    """Drop-in for model_dict['lightfield'] (nlf/models/models.py:141-143)."""
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        from .scenes import mlp_layer_shapes
+        self.cfg = cfg
+        system = kwargs.get('system')
+        self.dataset = kwargs['dataset'] if 'dataset' in kwargs else dataset_scalars_from_system(system)
+        net = cfg['color']['net']
+        if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
+            grid = list(kwargs['grid_size'])
+        elif 'grid_size' in net:                                   # tensorf_base.py:150-154
+            grid = list(net['grid_size']['start'])
+        else:
+            grid = n_to_reso(net['N_voxel_init'], to_plain(net['aabb']))
+        self.param = _Dummy()
+        self.embedding_model = HostEmbedding(cfg, mlp_layer_shapes(cfg))
+        self.color_model = HostColorModel(net, grid, self.dataset['num_keyframes'])
+        self.cur_iter = 0
+        self._native = None
+        self._native_key = None
+        # fail on configurations outside the supported path now, not at the first render
+        compile_config(cfg, self.dataset, grid)
+
+    # -- reference surface ---------------------------------------------------------
+    def set_iter(self, i):
+        """Inference-time no-op: every EaseValue/WindowedPE weight is 1 once training has
+        passed its windows, which is the only regime this renderer serves
+        (nlf/__init__.py:582-583 sets iter=1e7 for render/test)."""
+        self.cur_iter = i
+        self.color_model.set_iter(i)
+
+    @property
+    def grid_size(self):
+        return [int(v) for v in self.color_model.net.gridSize.tolist()]
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts reference checkpoints: strips a leading `render_fn.model.` / `model.`,
+        re-allocates the planes when the checkpoint's gridSize differs and reshapes plane
+        tensors (nlf/__init__.py:433-479)."""
+        sd = {}
+        for k, v in state_dict.items():
+            for pre in ('render_fn.model.', 'model.'):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+                    break
+            sd[k] = v
+        gs = sd.get('color_model.net.gridSize')
+        if gs is not None and [int(x) for x in gs.tolist()] != self.grid_size:
+            self.color_model.net.init_svd_volume([int(x) for x in gs.tolist()])
+        own = self.state_dict()
+        for k in list(sd.keys()):
+            if k in own and torch.is_tensor(sd[k]) and sd[k].shape != own[k].shape and sd[k].numel() == own[k].numel():
+                sd[k] = sd[k].view(own[k].shape)
+        self._native_key = None
+        return super().load_state_dict(sd, strict=strict)
+
+    # -- native side -------------------------------------------------------------------
+    def _tensors(self):
+        own = dict(self.named_parameters())
+        hc = compile_config(self.cfg, self.dataset, self.grid_size)
+        pred_idx = [i for i, e in enumerate(self.cfg['embedding']['embeddings'].values())
+                    if e['type'] == 'ray_prediction'][0]
+        return hc, [(abi, own[key.format(idx=pred_idx)]) for abi, key in upload_names(hc)]
+
+    def native(self):
+        """Returns the hr_model handle, (re)uploading weights if any parameter changed."""
+        hc, tensors = self._tensors()
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for _, t in tensors)
+        if self._native is not None and key == self._native_key:
+            return self._native
+        L = _lib.load()
+        dev = tensors[0][1].device
+        if dev.type != 'cuda':
+            raise RuntimeError('HipLightfieldModel must live on a HIP device (model.cuda()); there is no CPU path')
+        import ctypes as C
+        with torch.cuda.device(dev):
+            if self._native is None:
+                h = C.c_void_p()
+                _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
+                self._native = h
+                self._native_grid = self.grid_size
+            elif self._native_grid != self.grid_size:
+                L.hr_model_destroy(self._native)
+                h = C.c_void_p()
+                _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
+                self._native = h
+                self._native_grid = self.grid_size
+            torch.cuda.current_stream().synchronize()
+            for abi, t in tensors:
+                t = t.detach().contiguous().float()
+                _lib.check(L.hr_model_upload(self._native, abi.encode(), C.c_void_p(t.data_ptr()),
+                                             t.numel() * 4), f'hr_model_upload({abi})')
+            _lib.check(L.hr_model_finalize(self._native), 'hr_model_finalize')
+        self._native_key = key
+        self._hc = hc
+        return self._native
+
+    def reserve(self, rays_per_chunk):
+        L = _lib.load()
+        _lib.check(L.hr_model_reserve(self.native(), int(rays_per_chunk)), 'hr_model_reserve')
+
+    def device_bytes(self):
+        return int(_lib.load().hr_model_device_bytes(self.native()))
+
+    def __del__(self):
+        try:
+            if self._native is not None:
+                _lib.load().hr_model_destroy(self._native)
+                self._native = None
+        except Exception:
+            pass
+
+    # -- rendering ---------------------------------------------------------------------
+    def _check_rays(self, rays):
+        hc = self._hc
+        if rays.device.type != 'cuda':
+            raise RuntimeError('rays must be on the HIP device; there is no CPU path')
+        if rays.dim() != 2 or rays.shape[1] < hc.ray_dim:
+            raise ValueError(f'rays must be (B,{hc.ray_dim}), got {tuple(rays.shape)}')
+        if rays.shape[1] != hc.ray_dim:
+            rays = rays[:, :hc.ray_dim] if hc.ray_dim == 6 else rays
+        return rays.contiguous().float()
+
+    def render(self, rays, want=()):
+        """rays (B, 6|8) on the HIP device -> dict with 'rgb' (B,3) and any of
+        'distances' (B,Z), 'points' (B,Z,3), 'sigma' (B,Z), 'render_weights' (B,Z),
+        'head' (B,Z*P) listed in `want`."""
+        import ctypes as C
+        h = self.native()
+        L = _lib.load()
+        rays = self._check_rays(rays)
+        B = rays.shape[0]
+        hc = self._hc
+        Z = hc.z_channels
+        out = {'rgb': torch.empty((B, 3), dtype=torch.float32, device=rays.device)}
+        stream = C.c_void_p(torch.cuda.current_stream(rays.device).cuda_stream)
+        with torch.cuda.device(rays.device):
+            if not want:
+                _lib.check(L.hr_render(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()), stream),
+                           'hr_render')
+                return out
+            f = hr_fields()
+            shapes = {'distances': (B, Z), 'points': (B, Z, 3), 'sigma': (B, Z), 'render_weights': (B, Z),
+                      'head': (B, Z * hc.preds_per_z)}
+            slots = {'distances': 'distances_dev', 'points': 'points_dev', 'sigma': 'sigma_dev',
+                     'render_weights': 'weights_dev', 'head': 'head_dev'}
+            for k in want:
+                out[k] = torch.zeros(shapes[k], dtype=torch.float32, device=rays.device)
+                setattr(f, slots[k], out[k].data_ptr())
+            _lib.check(L.hr_render_fields(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()),
+                                          C.byref(f), stream), 'hr_render_fields')
+        return out
+
+    def forward(self, rays, render_kwargs=None):
+        """LightfieldModel.forward (models.py:135-138)."""
+        render_kwargs = render_kwargs or {}
+        fields = list(render_kwargs.get('fields', []))
+        if not fields:
+            return {'rgb': self.render(rays)['rgb']}
+        return self._forward_fields(rays, render_kwargs)
+
+    # -- diagnostics surface (visualizers only) ------------------------------------------
+    def _head_fields(self, rays, head):
+        hc = self._hc
+        B, Z, P = rays.shape[0], hc.z_channels, hc.preds_per_z
+        h = head.view(B, Z, P)
+        out = {}
+
+        def act(f, x):
+            y = x * f.act.inner + f.act.shift
+            if f.act.type == 1:
+                y = torch.sigmoid(y)
+            elif f.act.type == 2:
+                y = torch.tanh(y)
+            return y * f.act.outer
+
+        for name, f in (('color_scale', hc.f_color_scale), ('color_shift', hc.f_color_shift)):
+            if f.offset >= 0:
+                out[name] = act(f, h[..., f.offset:f.offset + f.channels]).reshape(B, -1)
+        return out
+
+    def embed(self, rays, render_kwargs=None):
+        """LightfieldModel.embed (models.py:131-133): the flattened fields handed to the
+        colour net (extract_fields lists of the YAMLs).  Diagnostics path."""
+        r = self.render(rays, want=('distances', 'points', 'head'))
+        rays = self._check_rays(rays)
+        B, Z = rays.shape[0], self._hc.z_channels
+        x = {'points': r['points'].reshape(B, -1), 'distances': r['distances'],
+             'viewdirs': rays[:, None, 3:6].expand(B, Z, 3).reshape(B, -1),
+             'weights': torch.ones_like(r['distances'])}
+        x.update(self._head_fields(rays, r['head']))
+        if self._hc.advect:
+            t = rays[:, -1:]
+            fac, inv = self._hc.flow_fac, self._hc.flow_inv_fac
+            base = torch.round((t * fac).clamp(0.0, self._hc.flow_kmax) - 1e-5) * inv
+            x['base_times'] = base.expand(B, Z).contiguous()
+            x['time_offset'] = (t - base).expand(B, Z).contiguous()
+            x['times'] = t.expand(B, Z).contiguous()
+        return x
+
+    def _forward_fields(self, rays, render_kwargs):
+        """render_kwargs `fields` / `no_over_fields` (tensorf_no_sample.py:254-278)."""
+        fields = list(render_kwargs.get('fields', []))
+        no_over = list(render_kwargs.get('no_over_fields', []))
+        if render_kwargs.get('pred_weights_fields'):
+            raise NotImplementedError('pred_weights_fields')
+        r = self.render(rays, want=('distances', 'points', 'render_weights', 'head'))
+        x = self.embed(rays)
+        B, Z = r['render_weights'].shape
+        out = {'rgb': r['rgb']}
+        w = r['render_weights']
+        for key in fields:
+            if key == 'render_weights':
+                out[key] = w
+            elif key in x:
+                v = x[key]
+                out[key] = v.view(B, -1) if key in no_over else torch.sum(w[..., None] * v.view(B, Z, -1), -2)
+        return out
+
+
+model_dict = {'lightfield': HipLightfieldModel}

@@ -1,0 +1,446 @@
+"""Compiles the reference's model YAML (+ five dataset scalars) into the flat `hr_config`
+that libhyperreel_hip.so consumes (include/hyperreel_hip.h).
+
+This is the host-side half of the drop-in boundary: everything the reference's module
+constructors derive at build time is derived here, in the reference's own precision and
+order, so the kernels only see numbers:
+
+  RayPredictionEmbedding.__init__   nlf/embedding/ray.py:213-315   (param groups, PE, head layout, depth-2)
+  Intersect.__init__                nlf/intersect/base.py:52-126   (near/far, sort, contract, activation)
+  IntersectZPlane.__init__          nlf/intersect/z.py:16-75       (anchor samples, z_scale)
+  IntersectSphereOld/CylinderOld    nlf/intersect/primitive.py:181-233, 366-418
+  MIPNeRFContract.__init__          nlf/contract.py:113-141
+  AdvectPointsEmbedding.__init__    nlf/embedding/point.py:741-778
+  PointOffsetEmbedding.__init__     nlf/embedding/point.py:338-369
+  TensorBase.__init__               nlf/nets/tensorf_base.py:137-248
+  TensorVMKeyframeTime.__init__     nlf/nets/tensorf_dynamic.py:45-77
+
+Anything outside the hot-path scope raises NotImplementedError with
+the offending key -- never a silent fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+F32 = np.float32
+
+HR_MAX_Z = 64
+HR_MAX_GROUPS = 4
+HR_MAX_LAYERS = 8
+HR_MAX_MLP_IN = 64
+
+ACT = {'identity': 0, 'sigmoid': 1, 'tanh': 2}
+PARAM = {'identity': 0, 'pluecker': 1, 'two_plane': 2}
+PE = {None: 0, 'windowed': 1, 'basic': 2}
+ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2}
+CONTRACT = {'identity': 0, 'mipnerf': 1}
+DENSITY = {'relu': 0, 'softplus': 1, 'relu_abs': 2}
+SHADING = {'RGB': 0, 'SH': 1}
+
+
+class hr_act(C.Structure):
+    _fields_ = [('type', C.c_int32), ('inner', C.c_float), ('shift', C.c_float), ('outer', C.c_float)]
+
+
+class hr_param_group(C.Structure):
+    _fields_ = [('start', C.c_int32), ('end', C.c_int32), ('fn', C.c_int32), ('origin', C.c_float * 3),
+                ('a', C.c_float), ('b', C.c_float), ('pe_type', C.c_int32), ('pe_n_freqs', C.c_int32),
+                ('pe_exclude_identity', C.c_int32), ('pe_freq_mult', C.c_float), ('pe_base_mult', C.c_float)]
+
+
+class hr_head_field(C.Structure):
+    _fields_ = [('offset', C.c_int32), ('channels', C.c_int32), ('act', hr_act)]
+
+
+class hr_config(C.Structure):
+    _fields_ = [
+        ('ray_dim', C.c_int32), ('n_groups', C.c_int32), ('groups', hr_param_group * HR_MAX_GROUPS),
+        ('mlp_in', C.c_int32), ('mlp_layers', C.c_int32), ('mlp_hidden', C.c_int32), ('mlp_skip_mask', C.c_int32),
+        ('leaky_slope', C.c_float), ('z_channels', C.c_int32), ('preds_per_z', C.c_int32),
+        ('f_z_vals', hr_head_field), ('f_isect_sigma', hr_head_field), ('f_offset_sigma', hr_head_field),
+        ('f_point_offset', hr_head_field), ('f_color_scale', hr_head_field), ('f_color_shift', hr_head_field),
+        ('f_spatial_flow', hr_head_field),
+        ('isect_type', C.c_int32), ('isect_origin', C.c_float * 3), ('near', C.c_float), ('far', C.c_float),
+        ('z_act', hr_act), ('sort', C.c_int32), ('samples', C.c_float * HR_MAX_Z), ('z_scale', C.c_float),
+        ('origin_scale', C.c_float), ('origin_initial', C.c_float * 3),
+        ('contract_type', C.c_int32), ('contract_samples', C.c_int32),
+        ('c_r0', C.c_float), ('c_r_inv_end', C.c_float), ('c_r_scale', C.c_float),
+        ('c_d0', C.c_float), ('c_d_inv_end', C.c_float), ('c_d_scale', C.c_float),
+        ('advect', C.c_int32), ('use_spatial_flow', C.c_int32), ('flow_fac', C.c_float), ('flow_inv_fac', C.c_float),
+        ('flow_kmax', C.c_float), ('flow_act', hr_act),
+        ('point_offset', C.c_int32), ('offset_act', hr_act),
+        ('video', C.c_int32), ('aabb', C.c_float * 6), ('inv_size', C.c_float * 3), ('grid', C.c_int32 * 3),
+        ('num_keyframes', C.c_int32), ('n_den', C.c_int32 * 3), ('n_app', C.c_int32 * 3), ('app_dim', C.c_int32),
+        ('shading', C.c_int32), ('distance_scale', C.c_float), ('weight_thresh', C.c_float),
+        ('density_act', C.c_int32), ('density_shift', C.c_float), ('time_scale', C.c_float), ('time_offset', C.c_float),
+        ('white_bg', C.c_int32),
+    ]
+
+
+class hr_fields(C.Structure):
+    _fields_ = [('distances_dev', C.c_void_p), ('points_dev', C.c_void_p), ('sigma_dev', C.c_void_p),
+                ('weights_dev', C.c_void_p), ('head_dev', C.c_void_p)]
+
+
+# --------------------------------------------------------------------------- small helpers
+def _act(cfg):
+    """get_activation (nlf/activations.py:566-570) at inference: EaseValue -> inner."""
+    if cfg is None:
+        cfg = 'identity'
+    if isinstance(cfg, str):
+        cfg = {'type': cfg}
+    while cfg['type'] == 'ease_value':
+        cfg = cfg['activation']
+        if isinstance(cfg, str):
+            cfg = {'type': cfg}
+    t = cfg['type']
+    if t not in ACT:
+        raise NotImplementedError(f"activation '{t}' is outside the hot-path scope (identity/sigmoid/tanh/ease_value)")
+    a = hr_act()
+    a.type = ACT[t]
+    a.inner = float(cfg.get('inner_fac', 1.0))
+    a.shift = float(cfg.get('shift', 0.0))
+    a.outer = float(cfg['fac']) if 'fac' in cfg else float(cfg.get('outer_fac', 1.0))
+    return a
+
+
+def _absent_field():
+    f = hr_head_field()
+    f.offset, f.channels, f.act = -1, 0, _act(None)
+    return f
+
+
+def torch_linspace_f32(start, end, steps):
+    """torch.linspace for float32 on CPU: two-sided evaluation around the midpoint."""
+    start, end = F32(start), F32(end)
+    if steps == 1:
+        return np.asarray([start], F32)
+    step = F32((end - start) / F32(steps - 1))
+    out = np.empty((steps,), F32)
+    half = steps // 2
+    for i in range(steps):
+        out[i] = start + step * F32(i) if i < half else end - step * F32(steps - 1 - i)
+    return out
+
+
+class _MipNerf:
+    """Setup-time arithmetic of MIPNeRFContract (nlf/contract.py:113-176), float32 like torch."""
+
+    def __init__(self, c, ds):
+        if c.get('use_dataset_bounds', False):
+            self.r0 = c.get('contract_start_radius', max(ds['depth_range'][0] * 1.5, 1.0))
+            self.r1 = c.get('contract_end_radius', ds['depth_range'][1] * 1.5)
+        else:
+            self.r0 = c.get('contract_start_radius', 1.0)
+            self.r1 = c.get('contract_end_radius', float('inf'))
+        self.d0 = c.get('contract_start_distance', self.r0)
+        self.d1 = c.get('contract_end_distance', self.r1)
+        if 'distance_activation' in c:
+            raise NotImplementedError('contract.distance_activation is outside the hot-path scope')
+
+    def contract_distance(self, distance):             # contract.py:160-176, on a 0-dim float32 tensor
+        d = F32(distance) / F32(self.d0)
+        with np.errstate(divide='ignore'):
+            inv = F32(1.0) / np.abs(d)
+        inv_end = self.d0 / self.d1
+        scale = 1.0 / (1.0 - inv_end)
+        t = (inv - F32(inv_end)) * F32(scale)
+        out = d / F32(1.0) if np.abs(d) < 1.0 else np.sign(d) * (F32(2.0) - t)
+        return F32((F32(out) / F32(2.0)) * F32(2.0))
+
+
+# --------------------------------------------------------------------------- the compiler
+def compile_config(cfg, dataset, grid_size):
+    """cfg: `experiment.model` group (dict/Cfg); dataset: {near, far, depth_range,
+    num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes."""
+    if cfg.get('param', {}).get('fn', 'identity') != 'identity':
+        raise NotImplementedError("model.param.fn other than 'identity'")
+    if cfg['embedding']['type'] != 'ray_point':
+        raise NotImplementedError(f"embedding type {cfg['embedding']['type']}")
+    hc = hr_config()
+    for name in ('f_z_vals', 'f_isect_sigma', 'f_offset_sigma', 'f_point_offset', 'f_color_scale',
+                 'f_color_shift', 'f_spatial_flow'):
+        setattr(hc, name, _absent_field())
+    stages = list(cfg['embedding']['embeddings'].values())
+    types = [s['type'] for s in stages]
+    allowed = {'ray_prediction', 'ray_intersect', 'advect_points', 'point_offset', 'add_point_outputs', 'extract_fields'}
+    for t in types:
+        if t not in allowed:
+            raise NotImplementedError(f"embedding '{t}' is outside the hot-path scope")
+    order = [t for t in types if t in ('ray_prediction', 'ray_intersect', 'advect_points', 'point_offset')]
+    if order[:2] != ['ray_prediction', 'ray_intersect'] or order[2:] not in ([], ['point_offset'], ['advect_points'],
+                                                                             ['advect_points', 'point_offset']):
+        raise NotImplementedError(f'embedding order {order} (expected prediction, intersect[, advect][, offset])')
+
+    # ---- ray_prediction ------------------------------------------------------------
+    pred = stages[types.index('ray_prediction')]
+    if pred.get('ray_outputs'):
+        raise NotImplementedError('ray_outputs')
+    if pred.get('rays_name', 'rays') != 'rays':
+        raise NotImplementedError('rays_name')
+    groups = list(pred['params'].values())
+    if len(groups) > HR_MAX_GROUPS:
+        raise NotImplementedError(f'more than {HR_MAX_GROUPS} parameter groups')
+    hc.n_groups = len(groups)
+    mlp_in = 0
+    max_col = 0
+    for i, g in enumerate(groups):
+        pg = hc.groups[i]
+        pg.start, pg.end = int(g['start']), int(g['end'])
+        max_col = max(max_col, pg.end)
+        p = g['param']
+        fn = p['fn']
+        if fn not in PARAM:
+            raise NotImplementedError(f"ray param '{fn}' is outside the hot-path scope")
+        if p.get('use_local_param', False):
+            raise NotImplementedError('use_local_param')
+        pg.fn = PARAM[fn]
+        org = p.get('origin', [0.0, 0.0, 0.0])
+        for k in range(3):
+            pg.origin[k] = float(org[k])
+        if fn == 'pluecker':
+            if pg.end - pg.start < 6:
+                raise ValueError('pluecker needs 6 ray columns')
+            pg.a, pg.b = float(p.get('direction_multiplier', 1.0)), float(p.get('moment_multiplier', 1.0))
+            n = 6
+        elif fn == 'two_plane':
+            if pg.end - pg.start < 6:
+                raise ValueError('two_plane needs 6 ray columns')
+            pg.a, pg.b = float(p.get('near', -1.0)), float(p.get('far', 0.0))
+            n = 4
+        else:
+            n = pg.end - pg.start
+            if n > 8:
+                raise NotImplementedError('identity param with more than 8 columns')
+        pe = g.get('pe')
+        if pe is None:
+            pg.pe_type = 0
+        else:
+            if pe['type'] not in ('windowed', 'basic'):
+                raise NotImplementedError(f"pe '{pe['type']}' is outside the hot-path scope")
+            if 'window_iters' in pe or pe.get('ceil', False):
+                raise NotImplementedError('windowed PE schedules are training-time only')
+            pg.pe_type = PE[pe['type']]
+            pg.pe_n_freqs = int(pe['n_freqs'])
+            pg.pe_exclude_identity = int(bool(pe.get('exclude_identity', False))) if pe['type'] == 'windowed' else 0
+            pg.pe_freq_mult = float(pe.get('freq_multiplier', 2.0))
+            pg.pe_base_mult = float(pe.get('base_multiplier', 1.0)) if pe['type'] == 'windowed' else 1.0
+            k = 2 * pg.pe_n_freqs
+            n = n * (k if pg.pe_exclude_identity else k + 1)
+        mlp_in += n
+    hc.mlp_in = mlp_in
+    if mlp_in > HR_MAX_MLP_IN:
+        raise NotImplementedError(f'MLP input of {mlp_in} features (max {HR_MAX_MLP_IN})')
+    net = pred['net']
+    if net['type'] != 'base':
+        raise NotImplementedError(f"net '{net['type']}' is outside the hot-path scope (BaseMLP only)")
+    for k in ('pe', 'pad_to', 'is_constant', 'zero_before_channel', 'latent_dim'):
+        if k in net:
+            raise NotImplementedError(f'net.{k}')
+    if net.get('layer_activation', 'leaky_relu') != 'leaky_relu' or net.get('activation', 'identity') != 'identity':
+        raise NotImplementedError('MLP activations other than leaky_relu / identity')
+    if not net.get('bias', True):
+        raise NotImplementedError('bias-free MLP')
+    D = int(net['depth']) - 2                       # ray.py:283-285
+    hc.mlp_layers = D + 2
+    hc.mlp_hidden = int(net['hidden_channels'])
+    mask = 0
+    for s in net.get('skips', []):
+        if 0 < s < D + 2:
+            mask |= 1 << int(s)
+        elif s == 0:
+            raise NotImplementedError('skip connection into layer 0')
+    hc.mlp_skip_mask = mask
+    hc.leaky_slope = 0.01
+    Z = int(pred['z_channels'])
+    if Z > HR_MAX_Z:
+        raise NotImplementedError(f'z_channels {Z} > {HR_MAX_Z}')
+    hc.z_channels = Z
+    heads = {}
+    off = 0
+    for name, o in pred['outputs'].items():
+        f = hr_head_field()
+        f.offset, f.channels, f.act = off, int(o['channels']), _act(o.get('activation'))
+        heads[name] = f
+        off += f.channels
+    hc.preds_per_z = off
+    if 'z_vals' not in heads:
+        raise NotImplementedError('model without a z_vals head')
+    hc.f_z_vals = heads['z_vals']
+    if 'color_scale' in heads and 'color_shift' in heads:
+        hc.f_color_scale, hc.f_color_shift = heads['color_scale'], heads['color_shift']
+    for k in ('color_transform', 'color_scale_global', 'color_shift_global', 'color_transform_global', 'weights_shift'):
+        if k in heads:
+            raise NotImplementedError(f"head '{k}' is outside the hot-path scope")
+
+    # ---- ray_intersect --------------------------------------------------------------
+    st = stages[types.index('ray_intersect')]
+    if int(st['z_channels']) != Z:
+        raise ValueError('ray_prediction and ray_intersect disagree on z_channels')
+    ic = st['intersect']
+    t = ic['type']
+    if t not in ISECT:
+        raise NotImplementedError(f"intersect '{t}' is outside the hot-path scope (SURVEY 8f-1)")
+    hc.isect_type = ISECT[t]
+    for k in ('weight_fn', 'sort_outputs', 'mask', 'dropout', 'normalize', 'residual_z', 'residual_distance', 'clamp',
+              'use_local_prediction', 'flip_axes', 'use_disparity', 'z_scale', 'num_samples_for_scale'):
+        if ic.get(k):
+            raise NotImplementedError(f'intersect.{k}')
+    if ic.get('num_repeat', 1) != 1:
+        raise NotImplementedError('intersect.num_repeat')
+    udb = ic.get('use_dataset_bounds', False)
+    org = ic.get('origin', [0.0, 0.0, 0.0])
+    for k in range(3):
+        hc.isect_origin[k] = float(org[k])
+    hc.near = float(ic['near']) if 'near' in ic else (float(dataset['near']) if udb else 0.0)   # base.py:88-94
+    hc.far = float(ic.get('far', float('inf')))
+    hc.z_act = _act(ic.get('activation'))
+    hc.sort = int(bool(ic.get('sort', False)))
+    if ic.get('use_sigma', False):
+        fld = ic.get('in_density_field', 'sigma')
+        if fld in heads:
+            if heads[fld].channels != 1:
+                raise NotImplementedError('intersect density field with more than one channel')
+            hc.f_isect_sigma = heads[fld]
+    contract = None
+    if 'contract' in ic:
+        ct = ic['contract']['type']
+        if ct not in CONTRACT:
+            raise NotImplementedError(f"contract '{ct}' is outside the hot-path scope")
+        if 'stop_iters' in ic['contract']:
+            raise NotImplementedError('contract.stop_iters')
+        hc.contract_type = CONTRACT[ct]
+        hc.contract_samples = int(bool(ic['contract'].get('contract_samples', False)))
+        if ct == 'mipnerf':
+            contract = _MipNerf(ic['contract'], dataset)
+            hc.c_r0 = float(contract.r0)
+            inv_end = contract.r0 / contract.r1
+            hc.c_r_inv_end = float(inv_end)
+            hc.c_r_scale = float(1.0 / (1.0 - inv_end))
+            hc.c_d0 = float(contract.d0)
+            inv_end = contract.d0 / contract.d1
+            hc.c_d_inv_end = float(inv_end)
+            hc.c_d_scale = float(1.0 / (1.0 - inv_end))
+        elif hc.contract_samples:
+            hc.contract_samples = 0          # IdentityContract.inverse_contract_distance is the identity
+    if t == 'z_plane':                        # z.py:25-39
+        if udb:
+            initial, end = F32(-dataset['near']), F32(-dataset['far'])
+        else:
+            initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
+    else:                                     # primitive.py:185-215 / 370-400
+        if udb:
+            initial = F32(ic['initial']) if 'initial' in ic else F32(dataset['near'] * 1.5)
+            end = F32(ic['end']) if 'end' in ic else F32(dataset['far'] * 1.5)
+        else:
+            initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
+        hc.origin_scale = float(ic.get('origin_scale_factor', 0.0))
+        oi = ic.get('origin_initial', [1.0, 1.0, 1.0])
+        for k in range(3):
+            hc.origin_initial[k] = float(oi[k])
+    if hc.contract_samples and contract is not None:
+        initial, end = contract.contract_distance(initial), contract.contract_distance(end)
+    samples = torch_linspace_f32(initial, end, Z)
+    for k in range(Z):
+        hc.samples[k] = float(samples[k])
+    hc.z_scale = float(np.abs(samples[1] - samples[0])) if Z > 1 else 1.0
+
+    # ---- advect / offset --------------------------------------------------------------
+    if 'advect_points' in types:
+        ad = stages[types.index('advect_points')]
+        if ad.get('use_angular_flow', False):
+            raise NotImplementedError('angular flow')
+        hc.advect = 1
+        hc.use_spatial_flow = int(bool(ad.get('use_spatial_flow', False)))
+        K, Fr = int(dataset['num_keyframes']), int(dataset['num_frames'])
+        if K > 0:
+            fac = K * (Fr - 1) / Fr           # flow_utils.py:18-19
+            hc.flow_fac = float(fac)
+            hc.flow_inv_fac = float(1.0 / fac)
+            hc.flow_kmax = float(K - 1.0)
+        hc.flow_act = _act(ad.get('spatial_flow_activation'))
+        if hc.use_spatial_flow:
+            if 'spatial_flow' not in heads:
+                raise ValueError('advect_points needs a spatial_flow head')
+            hc.f_spatial_flow = heads['spatial_flow']
+    else:
+        hc.flow_act = _act(None)
+    if 'point_offset' in types:
+        po = stages[types.index('point_offset')]
+        for k in ('dropout', 'in_points_field', 'out_points_field', 'in_offset_field'):
+            if k in po and po[k] not in (None, 'points', 'point_offset'):
+                raise NotImplementedError(f'point_offset.{k}')
+        hc.point_offset = 1
+        hc.offset_act = _act(po.get('activation'))
+        if 'point_offset' not in heads:
+            raise ValueError('point_offset needs a point_offset head')
+        hc.f_point_offset = heads['point_offset']
+        fld = po.get('in_density_field', 'sigma')
+        if po.get('use_sigma', True) and fld in heads:
+            if heads[fld].channels != 1:
+                raise NotImplementedError('offset density field with more than one channel')
+            hc.f_offset_sigma = heads[fld]
+    else:
+        hc.offset_act = _act(None)
+
+    # ---- colour net ---------------------------------------------------------------------
+    if cfg['color']['type'] != 'base':
+        raise NotImplementedError(f"color model {cfg['color']['type']}")
+    n = cfg['color']['net']
+    if n['type'] not in ('tensor_vm_split_no_sample', 'tensor_vm_split_time'):
+        raise NotImplementedError(f"colour net '{n['type']}' is outside the hot-path scope")
+    hc.video = int(n['type'] == 'tensor_vm_split_time')
+    if 'filter' in n:
+        raise NotImplementedError('net.filter (apply_filter_weights)')
+    aabb = np.asarray(n['aabb'], F32)
+    for k in range(3):
+        hc.aabb[k], hc.aabb[3 + k] = float(aabb[0][k]), float(aabb[1][k])
+    inv = F32(2.0) / (aabb[1] - aabb[0])      # tensorf_base.py:296-297
+    for k in range(3):
+        hc.inv_size[k] = float(inv[k])
+        hc.grid[k] = int(grid_size[k])
+    nd, na = list(n.get('n_lamb_sigma', [8, 8, 8])), list(n.get('n_lamb_sh', [24, 24, 24]))
+    for k in range(3):
+        hc.n_den[k], hc.n_app[k] = int(nd[k]), int(na[k])
+    shading = n.get('shadingMode', 'MLP_PE')
+    if shading not in SHADING:
+        raise NotImplementedError(f"shadingMode '{shading}' is outside the hot-path scope (RGB, SH)")
+    hc.shading = SHADING[shading]
+    hc.app_dim = int(n.get('data_dim_color', 27))
+    hc.distance_scale = float(n.get('distance_scale', 25))
+    hc.weight_thresh = float(n.get('rm_weight_mask_thre', 0.0001))
+    act = n.get('fea2denseAct', 'softplus')
+    if act not in DENSITY:
+        raise NotImplementedError(f'fea2denseAct {act}')
+    hc.density_act = DENSITY[act]
+    hc.density_shift = float(n.get('density_shift', -10.0))
+    hc.white_bg = int(bool(n.get('white_bg', 0)) and not bool(n.get('black_bg', 0)))
+    hc.ray_dim = 8 if (hc.video or max_col > 6 or hc.advect) else 6
+    if hc.video:
+        if n.get('densityMode', 'Density') != 'Density':
+            raise NotImplementedError(f"densityMode {n.get('densityMode')}")
+        K, Fr = int(dataset['num_keyframes']), int(dataset['num_frames'])
+        hc.num_keyframes = K
+        hc.time_scale = float((Fr - 1) / Fr)  # tensorf_dynamic.py:58-59
+        hc.time_offset = float(0.5 / K)
+        if not hc.advect:
+            raise NotImplementedError('video net without an advect_points stage (base_times)')
+    return hc
+
+
+def upload_names(hc):
+    """[(ABI tensor name, reference state_dict key suffix)] for hr_model_upload."""
+    names = []
+    emb = 'embedding_model.embeddings.{idx}.net.layers.'
+    L = hc.mlp_layers
+    for i in range(L):
+        mid = '.0' if i < L - 1 else ''        # Sequential(Linear, act) vs bare Linear (mlp.py:149-154)
+        names.append((f'mlp.{i}.weight', f'{emb}{i}{mid}.weight'))
+        names.append((f'mlp.{i}.bias', f'{emb}{i}{mid}.bias'))
+    kinds = ('plane_space', 'plane_time') if hc.video else ('plane', 'line')
+    for what in ('density', 'app'):
+        for kind in kinds:
+            for j in range(3):
+                names.append((f'{what}_{kind}.{j}', f'color_model.net.{what}_{kind}.{j}'))
+    names.append(('basis_mat.weight', 'color_model.net.basis_mat.weight'))
+    return names

@@ -1,0 +1,206 @@
+/*
+ * hyperreel_hip.h -- C ABI of libhyperreel_hip.so, the MI355X (gfx950) forward renderer
+ * for HyperReel scenes.
+ *
+ * This is the drop-in boundary for ONE path of the reference: what
+ * `render_fn(rays)` computes, i.e. RenderLightfield.forward
+ * (nlf/rendering.py:72-77) -> LightfieldModel.forward (nlf/models/models.py:135-138)
+ * -> RayPointEmbedding (nlf/embedding/embedding.py:100-117) -> TensorVMNoSample /
+ * TensorVMKeyframeTime .forward (nlf/nets/tensorf_no_sample.py:128-280,
+ * nlf/nets/tensorf_dynamic.py:645-839).  The reference has no FFI of its own (it is
+ * pure PyTorch); the binding a maintainer adds is the ctypes stub shown in
+ * INTEGRATION.md, selected with `experiment.model.render.type: lightfield_hip`
+ * through the reference's own registry (nlf/rendering.py:95-97).
+ *
+ * Conventions: plain C types only; every pointer named *_dev is a device pointer
+ * owned by the caller (e.g. torch tensor .data_ptr()); the library never frees
+ * caller memory; `stream` is a hipStream_t passed as void*; all calls return 0 on
+ * success and a negative HR_E_* code otherwise (hr_last_error() has the text; the
+ * Python wrapper raises RuntimeError, the reference's only error channel).  Render
+ * calls only enqueue work on `stream`: no allocation, no synchronisation, so they
+ * can be captured in a hipGraph.
+ */
+#ifndef HYPERREEL_HIP_H
+#define HYPERREEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HR_ABI_VERSION 1
+
+#define HR_MAX_Z 64          /* samples per ray (z_channels) supported by the sample kernel */
+#define HR_MAX_GROUPS 4      /* ray-parameterisation groups feeding the MLP (`params:` in the YAML) */
+#define HR_MAX_LAYERS 8      /* Linear layers of the sample-prediction MLP */
+#define HR_MAX_MLP_IN 64     /* MLP input features after positional encoding */
+
+/* error codes */
+#define HR_OK 0
+#define HR_E_INVALID (-1)    /* bad argument / unsupported configuration */
+#define HR_E_STATE (-2)      /* call order: upload after finalize, render before finalize ... */
+#define HR_E_HIP (-3)        /* a HIP runtime call failed */
+#define HR_E_MISSING (-4)    /* finalize: a required tensor was never uploaded */
+
+/* nlf/activations.py: Identity (:163-178), Sigmoid (:53-69), Tanh (:121-137); EaseValue
+ * (:462-496) is resolved to its inner activation by the host (inference). y = act(x*inner+shift)*outer */
+enum { HR_ACT_IDENTITY = 0, HR_ACT_SIGMOID = 1, HR_ACT_TANH = 2 };
+typedef struct hr_act {
+    int32_t type;
+    float inner, shift, outer;
+} hr_act;
+
+/* nlf/param.py: identity (:20-24), PlueckerParam (:223-256), TwoPlaneParam (:63-118) */
+enum { HR_PARAM_IDENTITY = 0, HR_PARAM_PLUECKER = 1, HR_PARAM_TWO_PLANE = 2 };
+/* nlf/pe.py: IdentityPE, WindowedPE (:130-224, weights == 1 at inference), BasicPE (:32-71) */
+enum { HR_PE_NONE = 0, HR_PE_WINDOWED = 1, HR_PE_BASIC = 2 };
+typedef struct hr_param_group {
+    int32_t start, end;          /* ray columns [start, end) (nlf/embedding/ray.py:319-321) */
+    int32_t fn;                  /* HR_PARAM_* */
+    float origin[3];
+    float a, b;                  /* pluecker: direction/moment multiplier; two_plane: near/far plane z */
+    int32_t pe_type;             /* HR_PE_* */
+    int32_t pe_n_freqs;
+    int32_t pe_exclude_identity;
+    float pe_freq_mult, pe_base_mult;
+} hr_param_group;
+
+/* One per-sample output of the MLP head (nlf/embedding/ray.py:333-337): `channels`
+ * consecutive columns starting at `offset` inside the P = preds_per_z columns of a
+ * sample; offset < 0: the field does not exist in this model. */
+typedef struct hr_head_field {
+    int32_t offset, channels;
+    hr_act act;
+} hr_head_field;
+
+enum { HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2 };
+enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1 };
+enum { HR_DENSITY_RELU = 0, HR_DENSITY_SOFTPLUS = 1, HR_DENSITY_RELU_ABS = 2 };
+enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
+
+/* Everything the kernels need that the reference derives from the model YAML and the
+ * five dataset scalars (near, far, depth_range, num_keyframes, num_frames).  Derived
+ * floats are computed by the host in the reference's own precision and order
+ * (hyperreel_amd/plan.py cites the lines). */
+typedef struct hr_config {
+    /* ---- rays + MLP (nlf/embedding/ray.py:213-347, nlf/nets/mlp.py:60-172) */
+    int32_t ray_dim;                     /* 6 static [o,d]; 8 video [o,d,cam_id,t] */
+    int32_t n_groups;
+    hr_param_group groups[HR_MAX_GROUPS];
+    int32_t mlp_in;                      /* input features (sum over groups after PE) */
+    int32_t mlp_layers;                  /* number of Linear layers (D+2) */
+    int32_t mlp_hidden;                  /* W */
+    int32_t mlp_skip_mask;               /* bit i set: layer i takes cat([input, x]) */
+    float leaky_slope;                   /* 0.01 */
+    int32_t z_channels;                  /* Z */
+    int32_t preds_per_z;                 /* P */
+    hr_head_field f_z_vals;
+    hr_head_field f_isect_sigma;         /* x[intersect.in_density_field], intersect/base.py:152-158 */
+    hr_head_field f_offset_sigma;        /* x[point_offset.in_density_field], embedding/point.py:378-381 */
+    hr_head_field f_point_offset;
+    hr_head_field f_color_scale;
+    hr_head_field f_color_shift;
+    hr_head_field f_spatial_flow;
+    /* ---- intersect (nlf/intersect/base.py:142-259, z.py, primitive.py) */
+    int32_t isect_type;                  /* HR_ISECT_* */
+    float isect_origin[3];
+    float near, far;                     /* mask: dist <= near | dist >= far */
+    hr_act z_act;
+    int32_t sort;
+    float samples[HR_MAX_Z];             /* anchor samples (contracted space when contract_samples) */
+    float z_scale;
+    float origin_scale;                  /* sphere/cylinder: origins = z[:3]*origin_scale + origin_initial */
+    float origin_initial[3];
+    /* ---- contraction (nlf/contract.py:113-192) */
+    int32_t contract_type;               /* HR_CONTRACT_* */
+    int32_t contract_samples;
+    float c_r0, c_r_inv_end, c_r_scale;  /* points:   start radius,   r0/r1, 1/(1-r0/r1) */
+    float c_d0, c_d_inv_end, c_d_scale;  /* distance: start distance, d0/d1, 1/(1-d0/d1) */
+    /* ---- advect (nlf/embedding/point.py:780-831, utils/flow_utils.py:10-35) */
+    int32_t advect;
+    int32_t use_spatial_flow;
+    float flow_fac, flow_inv_fac;        /* K*(F-1)/F and its reciprocal */
+    float flow_kmax;                     /* K-1 */
+    hr_act flow_act;
+    /* ---- point offset (nlf/embedding/point.py:371-396) */
+    int32_t point_offset;
+    hr_act offset_act;
+    /* ---- colour net (nlf/nets/tensorf_no_sample.py, tensorf_dynamic.py, tensorf_base.py) */
+    int32_t video;                       /* 0: tensor_vm_split_no_sample, 1: tensor_vm_split_time */
+    float aabb[6];                       /* [min xyz, max xyz] */
+    float inv_size[3];                   /* 2/(max-min) */
+    int32_t grid[3];                     /* gridSize [Nx,Ny,Nz] */
+    int32_t num_keyframes;               /* K (video) */
+    int32_t n_den[3], n_app[3];          /* n_lamb_sigma, n_lamb_sh */
+    int32_t app_dim;                     /* 3 (RGB) or 27 (SH degree 2) */
+    int32_t shading;                     /* HR_SHADING_* */
+    float distance_scale;
+    float weight_thresh;                 /* rm_weight_mask_thre */
+    int32_t density_act;                 /* HR_DENSITY_* */
+    float density_shift;
+    float time_scale, time_offset;       /* (F-1)/F and 0.5/K, tensorf_dynamic.py:58-59 */
+    int32_t white_bg;
+} hr_config;
+
+/* Optional per-sample diagnostics of hr_render_fields (all device pointers, any may be
+ * NULL).  They mirror what the reference exposes through render_kwargs `fields`
+ * (tensorf_no_sample.py:254-278) and LightfieldModel.embed. */
+typedef struct hr_fields {
+    float* distances_dev;       /* (n, Z)    x['distances'] after sort + contraction */
+    float* points_dev;          /* (n, Z, 3) x['points'] fed to the colour net */
+    float* sigma_dev;           /* (n, Z)    density after feature2density */
+    float* weights_dev;         /* (n, Z)    'render_weights' */
+    float* head_dev;            /* (n, Z*P)  raw MLP output */
+} hr_fields;
+
+typedef struct hr_model hr_model;
+
+int hr_abi_version(void);
+const char* hr_last_error(void);
+
+/* Builds a model for `cfg` on the current HIP device.  Replaces the constructors
+ * LightfieldModel.__init__ (nlf/models/models.py:104-129) + RenderLightfield.__init__
+ * (nlf/rendering.py:59-70). */
+int hr_model_create(const hr_config* cfg, hr_model** out);
+
+/* Hands over one tensor of the reference state_dict, float32, in the reference's own
+ * layout (nlf/__init__.py:433-479 are the reference's loader).  `name` is the key with
+ * the module prefix removed:
+ *   mlp.<i>.weight (out,in)  mlp.<i>.bias (out)                      i < mlp_layers
+ *   density_plane.<j> (1,C,H,W)  density_line.<j> (1,C,N,1)
+ *   app_plane.<j>  app_line.<j>                                      static net, j < 3
+ *   density_plane_space.<j> density_plane_time.<j> (1,C,K,N)
+ *   app_plane_space.<j> app_plane_time.<j>                           video net
+ *   basis_mat.weight (app_dim, sum n_app)
+ * `ptr` may be host or device memory; the data is copied before the call returns. */
+int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes);
+
+/* Re-lays the uploaded tensors out for the kernels (channel-last interleaved planes,
+ * MFMA-tiled MLP weights).  May be called again after further uploads. */
+int hr_model_finalize(hr_model* m);
+
+/* Sizes the per-launch workspace (rays processed per internal chunk).  Optional. */
+int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
+
+/* rgb_dev[n,3] = render_fn(rays_dev[n,ray_dim])['rgb']  (eval mode: clamped to [0,1]). */
+int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
+int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,
+                     const hr_fields* fields, void* stream);
+
+/* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
+ * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
+ * must not exceed the reserved chunk size. */
+int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream);
+int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
+
+/* bytes of device memory held by the model (packed grids + weights + workspace) */
+int64_t hr_model_device_bytes(const hr_model* m);
+
+void hr_model_destroy(hr_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERREEL_HIP_H */

@@ -1,0 +1,96 @@
+"""CPU check of the formulas the HIP kernels call (hyperreel_amd/csrc/hr_math.h, compiled
+for the host by g++ into a test-only library) against the oracle, on the golden scenes.
+This exercises the kernels' arithmetic and the YAML -> hr_config compiler without a GPU;
+the cross-lane parts, indexing and MFMA layouts are covered by the `-m gpu` tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import Golden, golden_cases, linf
+from hyperreel_amd import plan
+from hyperreel_oracle import HyperReelOracle, eval_sh_bases_deg2, grid_sample_2d
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'host_math', 'hr_math_host.cpp')
+OUT = os.path.join(HERE, 'host_math', '_build', 'libhr_math_host.so')
+
+FP = C.POINTER(C.c_float)
+IP = C.POINTER(C.c_int)
+
+
+def fp(a):
+    return a.ctypes.data_as(FP)
+
+
+@pytest.fixture(scope='module')
+def hm():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    deps = [SRC, os.path.join(HERE, '..', 'hyperreel_amd', 'csrc', 'hr_math.h'),
+            os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', OUT, SRC], check=True)
+    lib = C.CDLL(OUT)
+    lib.hm_normalize_time.restype = C.c_float
+    lib.hm_normalize_time.argtypes = [C.c_void_p, C.c_float]
+    return lib
+
+
+def test_config_struct_layout_matches_c(hm):
+    assert hm.hm_sizeof_config() == C.sizeof(plan.hr_config)
+
+
+SMALL = [c for c in golden_cases() if c.endswith('_small') or c.startswith('config1')]
+
+
+@pytest.mark.parametrize('case', SMALL)
+def test_features_and_embedding_match_oracle(hm, case):
+    g = Golden(case)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+    rays = np.ascontiguousarray(g.rays[:300], np.float32)
+    n = rays.shape[0]
+    assert rays.shape[1] == hc.ray_dim
+    # MLP input features
+    feat = np.zeros((n, hc.mlp_in), np.float32)
+    hm.hm_features(C.byref(hc), fp(rays), n, fp(feat))
+    ref = orc._param_pe(rays)
+    assert ref.shape == feat.shape
+    assert float(np.max(np.abs(feat - ref) / (1 + np.abs(ref)))) <= 2e-6
+    # embedding from the oracle's own raw head: isolates everything after the MLP
+    x = orc.embed(rays)
+    head = np.ascontiguousarray(x['_head_raw'], np.float32)
+    Z = hc.z_channels
+    assert head.shape == (n, Z * hc.preds_per_z)
+    dist = np.zeros((n, Z), np.float32)
+    pts = np.zeros((n, Z, 3), np.float32)
+    valid = np.zeros((n, Z), np.int32)
+    bt = np.zeros((n,), np.float32)
+    hm.hm_embed(C.byref(hc), fp(rays), fp(head), n, fp(dist), fp(pts), valid.ctypes.data_as(IP), fp(bt))
+    d_ref = x['distances'].reshape(n, Z)
+    assert float(np.max(np.abs(dist - d_ref) / (1 + np.abs(d_ref)))) <= 1e-6
+    assert float(np.max(np.abs(pts - x['points']) / (1 + np.abs(x['points'])))) <= 1e-6
+    if 'base_times' in x:
+        assert linf(bt, x['base_times'][:, 0, 0]) == 0.0
+    col = orc.color(x)
+    assert (valid.astype(bool) == col['valid']).mean() > 0.999
+
+
+def test_taps_sh_density_normalize(hm):
+    rng = np.random.default_rng(0)
+    g = np.concatenate([rng.uniform(-1.2, 1.2, 500), [-1.0, 1.0, 0.0, 0.99999994, -0.99999994]]).astype(np.float32)
+    for size in (1, 2, 7, 600):
+        i0 = np.zeros(g.shape, np.int32); i1 = np.zeros(g.shape, np.int32)
+        w0 = np.zeros(g.shape, np.float32); w1 = np.zeros(g.shape, np.float32)
+        hm.hm_taps(fp(g), g.size, size, i0.ctypes.data_as(IP), i1.ctypes.data_as(IP), fp(w0), fp(w1))
+        # a 1-channel "image" whose texel value is its index: the line sample must equal grid_sample
+        line = np.arange(size, dtype=np.float32).reshape(1, size, 1) + 1.0
+        ref = grid_sample_2d(line, np.zeros_like(g), g)[0]
+        got = w0 * (i0 + 1.0) + w1 * (i1 + 1.0)
+        assert np.max(np.abs(got - ref)) <= 1e-4 * size
+    d = rng.standard_normal((64, 3)).astype(np.float32)
+    sh = np.zeros((64, 9), np.float32)
+    hm.hm_sh(fp(np.ascontiguousarray(d)), 64, fp(sh))
+    assert np.max(np.abs(sh - eval_sh_bases_deg2(d))) <= 1e-6
