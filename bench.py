@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Benchmark of the HyperReel forward-render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): DoNeRF static scene, `donerf_sphere` model group,
+800x800 pinhole frame = 640 000 rays, 32 samples/ray, shipped final grid 600^3,
+synthetic random-weight scene ('dense' density variant so alpha spans (0,1)), fp32.
+One step = one full forward render of the frame with rays and rgb resident in HBM.
+
+Multi-GPU (weak scaling): every rank renders its own 800x800 tile of an (800*N)x800
+panorama (640 000 rays per GPU, weights replicated) and the rendered tiles are
+all-gathered over RCCL/xGMI inside the timed step; value = rays rendered by all ranks / s.
+
+The JSON line also carries
+  roofline      the dominant kernel of the step, timed live with HIP events on the launch
+                stream, against the MI355X peak of the unit that bounds it;
+  roofline_other  the other kernel, same treatment;
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hyperreel_amd import config as C  # noqa: E402
+from hyperreel_amd import scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
+
+
+def algorithmic_bytes_per_ray(cfg, video):
+    """4*R_in + 12 + Z*(G_d + G_a), G = sum_i C_i * T * 4 bytes,
+    T = 6 texels/channel (static VM: 4 plane + 2 line) or 8 (video: 4 space + 4 time)."""
+    pred = cfg['embedding']['embeddings']['ray_prediction_0']
+    Z = pred['z_channels']
+    n = cfg['color']['net']
+    T = 8 if video else 6
+    nd, na = list(n['n_lamb_sigma']), list(n['n_lamb_sh'])
+    if video:  # plane pairs without density components are skipped altogether
+        na = [a if d > 0 else 0 for a, d in zip(na, nd)]
+    G = (sum(nd) + sum(na)) * T * 4
+    return 4 * (8 if video else 6) + 12 + Z * G
+
+
+def mlp_flops_per_ray(cfg):
+    return 2 * sum(o * i for o, i in scenes.mlp_layer_shapes(cfg))
+
+
+def time_stage(fn, reps):
+    """Average ms of `fn()` (which enqueues on the current stream), HIP events around each call."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return float(np.mean(ts)), float(ts[0]), float(ts[len(ts) // 2])
+
+
+def cpu_baseline(cfg, ds, sd, rays, n_sample):
+    """The numpy oracle on a bounded random sample of the same frame (checker code used
+    here only as the reported CPU baseline, never on the measured path)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    from hyperreel_oracle import HyperReelOracle
+    idx = np.random.default_rng(0).choice(rays.shape[0], n_sample, replace=False)
+    orc = HyperReelOracle(cfg, ds, sd)
+    orc.render(rays[idx[:256]])
+    t0 = time.perf_counter()
+    out = orc.render(rays[idx], chunk=16384)
+    dt = time.perf_counter() - t0
+    return n_sample / dt, dt, idx, out['rgb']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default='donerf_sphere')
+    ap.add_argument('--height', type=int, default=800)
+    ap.add_argument('--width', type=int, default=800)
+    ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
+    ap.add_argument('--cpu-sample', type=int, default=65536, help='rays of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-stage-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch N>1 with torch.distributed.run (one process per GPU)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from hyperreel_amd.render import build_render_fn
+    cfg = C.model_config(args.model)
+    ds = C.dataset_scalars(args.model)
+    video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    grid = [int(v) for v in sd['model.color_model.net.gridSize']]
+    fn = build_render_fn(cfg, dataset=ds, grid_size=grid)
+    fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    # tile of this rank: the same camera, panned by the tile index (weak scaling)
+    rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
+    if world > 1:
+        pose_shift = np.zeros_like(rays_np)
+        pose_shift[:, 1] = 0.01 * rank
+        rays_np = rays_np + pose_shift
+    rays = torch.from_numpy(rays_np).cuda()
+    B = rays.shape[0]
+    model = fn.model
+    if args.chunk:
+        model.reserve(args.chunk)
+    model.native()
+    gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if world > 1 else None
+
+    def step():
+        rgb = model.render(rays)['rgb']
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), rgb.view(-1))
+        return rgb
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgb = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    total_rays = B * world
+    value = total_rays / (dt / args.steps) / 1e6
+
+    result = {
+        'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
+        'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
+        'config': {'workload': f'BASELINE configs[1]: DoNeRF static ({args.model}), {args.height}x{args.width} frame '
+                               f'= {B} rays per GPU, {cfg["embedding"]["embeddings"]["ray_prediction_0"]["z_channels"]} '
+                               f'samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
+                   'rays_per_gpu': B, 'parallelism': f'image tiles x{world}, RCCL all_gather of rgb' if world > 1 else 'single GPU',
+                   'frame_ms_per_gpu': round(ms_per_step, 4)},
+    }
+
+    # ---- per-kernel timing + roofline (rank 0)
+    if rank == 0 and not args.no_stage_timing:
+        import ctypes
+        from hyperreel_amd import lib as hlib
+        L = hlib.load()
+        h = model.native()
+        chunk = 32768 if not args.chunk else args.chunk
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rgb_tmp = torch.empty((B, 3), dtype=torch.float32, device='cuda')
+        offs = list(range(0, B, chunk))
+
+        def run_mlp():
+            for o in offs:
+                n = min(chunk, B - o)
+                hlib.check(L.hr_stage_mlp(h, ctypes.c_void_p(rays.data_ptr() + o * rays.shape[1] * 4), n, stream), 'hr_stage_mlp')
+
+        def run_samples():
+            for o in offs:
+                n = min(chunk, B - o)
+                hlib.check(L.hr_stage_samples(h, ctypes.c_void_p(rays.data_ptr() + o * rays.shape[1] * 4), n,
+                                              ctypes.c_void_p(rgb_tmp.data_ptr() + o * 12), stream), 'hr_stage_samples')
+
+        # the sample stage reads the head of the LAST chunk the MLP stage wrote: both stages
+        # see representative data because every chunk of the frame is statistically alike
+        run_mlp(); run_samples()
+        reps = max(5, min(args.steps, 20))
+        mlp_ms = time_stage(run_mlp, reps)
+        smp_ms = time_stage(run_samples, reps)
+        nl = len(offs)
+        flops = mlp_flops_per_ray(cfg) * B
+        byts = algorithmic_bytes_per_ray(cfg, video) * B
+        r_mlp = {'kernel': 'hr_mlp_kernel', 'bound': 'mfma', 'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
+                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(mlp_ms[0] / nl, 4),
+                 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {min(chunk, B)} rays'}
+        r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
+                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
+                 'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video)} B/ray x {min(chunk, B)} rays'}
+        dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
+        result['roofline'] = dom
+        result['roofline_other'] = oth
+        result['stage_ms'] = {'mlp': round(mlp_ms[0], 4), 'samples': round(smp_ms[0], 4)}
+
+    # ---- CPU baseline (rank 0, N = 1)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd, rays_np, min(args.cpu_sample, B))
+        got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
+        result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': 1, 'kind': 'port',
+                                  'sample': f'{len(idx)} random rays of the same frame through oracle/hyperreel_oracle.py '
+                                            f'(numpy fp32, single process) in {secs:.1f} s'}
+        result['parity_vs_oracle_linf'] = float(np.abs(got - ref_rgb).max())
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

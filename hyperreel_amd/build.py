@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB_DIR = os.path.join(HERE, 'lib')
+LIB_DIR = os.path.join(HERE, '_build')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
 SOURCES = ['api.hip', 'mlp_kernel.hip', 'sample_kernel.hip', 'pack_kernels.hip']
 HEADERS = ['hr_kernels.h', 'hr_math.h', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]

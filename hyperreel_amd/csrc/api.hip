@@ -116,6 +116,8 @@ extern "C" {
 
 int hr_abi_version(void) { return HR_ABI_VERSION; }
 
+int hr_sizeof_config(void) { return (int)sizeof(hr_config); }
+
 const char* hr_last_error(void) { return g_err; }
 
 int hr_model_create(const hr_config* cfg, hr_model** out)

@@ -31,7 +31,6 @@ __device__ __forceinline__ void hr_mlp_accumulate(floatx4 (&acc)[4][NT], const f
                                                   const int (&tile)[NT], int lane)
 {
     const float* arow = src + (lane & 15) * stride + 4 * (lane >> 4);
-#pragma unroll 2
     for (int kt = 0; kt < nkt; ++kt) {
         float4 av[4];
         float4 bv[NT];

@@ -9,13 +9,14 @@ import os
 from .plan import hr_config, hr_fields
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libhyperreel_hip.so')
+LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
 ABI_VERSION = 1
 
 # every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ('hr_abi_version', C.c_int, []),
+    ('hr_sizeof_config', C.c_int, []),
     ('hr_last_error', C.c_char_p, []),
     ('hr_model_create', C.c_int, [C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
     ('hr_model_upload', C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
@@ -60,6 +61,8 @@ def load():
     v = lib.hr_abi_version()
     if v != ABI_VERSION:
         raise HipLibraryError(f'ABI version mismatch: library {v}, binding {ABI_VERSION}')
+    if lib.hr_sizeof_config() != C.sizeof(hr_config):
+        raise HipLibraryError('hr_config layout differs between the library and plan.py')
     _lib = lib
     return lib
 

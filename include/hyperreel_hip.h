@@ -158,6 +158,7 @@ typedef struct hr_fields {
 typedef struct hr_model hr_model;
 
 int hr_abi_version(void);
+int hr_sizeof_config(void);      /* sizeof(hr_config) as compiled, for binding self-checks */
 const char* hr_last_error(void);
 
 /* Builds a model for `cfg` on the current HIP device.  Replaces the constructors

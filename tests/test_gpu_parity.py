@@ -1,0 +1,216 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures made from the
+reference itself, and against the CPU oracle on the same seeded inputs.  `-m gpu` only.
+
+Tolerance: BASELINE.json north_star -- 1e-4 L-inf on RGB.  Intermediates use relative
+tolerances that localise a failure (distances, points, compositing weights)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, golden_cases, linf
+from hyperreel_amd import config as C
+from hyperreel_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+
+
+def _oracle(g):
+    from hyperreel_oracle import HyperReelOracle
+    return HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+
+
+@pytest.fixture(scope='module')
+def fns():
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            from gpu_common import make_render_fn
+            g = Golden(case)
+            cache[case] = (g, make_render_fn(g.cfg, g.dataset, g.state_dict))
+        return cache[case]
+
+    yield get
+    cache.clear()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('case', golden_cases())
+def test_rgb_matches_reference_golden(fns, case):
+    from gpu_common import render_np
+    g, fn = fns(case)
+    out = render_np(fn, g.rays)
+    assert out['rgb'].shape == g.rgb.shape
+    assert np.isfinite(out['rgb']).all()
+    err = np.abs(out['rgb'] - g.rgb).max(-1)
+    assert err.max() <= RGB_TOL, f'{case}: L-inf {err.max():.3e} at ray {int(err.argmax())} ({(err > RGB_TOL).sum()} rays over)'
+
+
+@pytest.mark.parametrize('case', [c for c in golden_cases() if c.endswith('_small')])
+def test_intermediates_match_reference_golden(fns, case):
+    from gpu_common import render_np
+    g, fn = fns(case)
+    out = render_np(fn, g.rays, want=('distances', 'points', 'render_weights'))
+    d_ref, p_ref, w_ref = g.arrays['distances'], g.arrays['points'], g.arrays['render_weights']
+    rel = lambda a, b: float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+    assert rel(out['distances'], d_ref) <= 2e-5, f'distances {rel(out["distances"], d_ref):.3e}'
+    assert rel(out['points'], p_ref) <= 2e-5, f'points {rel(out["points"], p_ref):.3e}'
+    assert linf(out['render_weights'], w_ref) <= 5e-5, f'weights {linf(out["render_weights"], w_ref):.3e}'
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'neural_3d_z_plane_small'])
+def test_mlp_head_matches_oracle(fns, case):
+    """K1 alone: raw head of the MFMA MLP against the oracle's numpy matmul chain."""
+    from gpu_common import render_np
+    g, fn = fns(case)
+    orc = _oracle(g)
+    out = render_np(fn, g.rays, want=('head',))
+    ref = orc.embed(g.rays)['_head_raw']
+    scale = np.abs(ref).max()
+    assert np.max(np.abs(out['head'] - ref)) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('model', C.MODEL_NAMES)
+def test_seeded_scene_matches_oracle(model):
+    """Fresh seeded scene per model family, odd ray counts, oracle as the checker."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    cfg, ds = C.model_config(model), C.dataset_scalars(model)
+    grid = [37, 41, 29]
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=123, density='dense', app_scale=1.0)
+    video = not model.startswith('donerf')
+    if 'z_plane' in model:
+        rays = scenes.random_rays(777, 5, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
+    else:
+        rays = scenes.random_rays(777, 5, video)
+    fn = make_render_fn(cfg, ds, sd)
+    out = render_np(fn, rays, want=('distances', 'render_weights', 'sigma'))
+    ref = HyperReelOracle(cfg, ds, sd).render(rays, keep='all')
+    assert linf(out['rgb'], ref['rgb']) <= RGB_TOL
+    Z = ref['distances'].shape[1]
+    assert float(np.max(np.abs(out['distances'] - ref['distances'].reshape(-1, Z)) / (1 + np.abs(ref['distances'].reshape(-1, Z))))) <= 2e-5
+    assert linf(out['render_weights'], ref['render_weights']) <= 5e-5
+
+
+def test_default_initialiser_and_z16(fns):
+    """BASELINE config 1: Z=16, 4096 random rays, 64^3 grid, the reference's own (tiny) density init."""
+    from gpu_common import render_np
+    g, fn = fns('config1_random_z16')
+    out = render_np(fn, g.rays)
+    assert linf(out['rgb'], g.rgb) <= RGB_TOL
+
+
+@pytest.mark.parametrize('n', [0, 1, 7, 63, 64, 65, 257])
+def test_ragged_ray_counts(fns, n):
+    from gpu_common import render_np
+    g, fn = fns('donerf_sphere_small')
+    full = render_np(fn, g.rays)['rgb']
+    part = render_np(fn, g.rays[:n])['rgb'] if n <= g.rays.shape[0] else None
+    if part is not None:
+        assert part.shape == (n, 3)
+        assert np.array_equal(part, full[:n])
+
+
+def test_internal_chunking_is_invisible(fns):
+    """The library's workspace chunking must not change a single bit."""
+    from gpu_common import render_np
+    g, fn = fns('immersive_sphere_small')
+    rays = np.concatenate([g.rays] * 3, 0)
+    fn.model.reserve(64)
+    a = render_np(fn, rays)['rgb']
+    fn.model.reserve(32768)
+    b = render_np(fn, rays)['rgb']
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:g.rays.shape[0]], a[g.rays.shape[0]:2 * g.rays.shape[0]])
+
+
+def test_ray_order_independence_and_determinism(fns):
+    from gpu_common import render_np
+    g, fn = fns('technicolor_z_plane_small')
+    perm = np.random.default_rng(0).permutation(g.rays.shape[0])
+    a = render_np(fn, g.rays)['rgb']
+    b = render_np(fn, g.rays[perm])['rgb']
+    assert np.array_equal(a[perm], b)
+    assert np.array_equal(a, render_np(fn, g.rays)['rgb'])
+
+
+def test_render_fn_surface(fns):
+    """forward / forward_multiple / embed keep the reference's dict-of-(B,k) contract."""
+    g, fn = fns('donerf_sphere_small')
+    rays = torch.from_numpy(g.rays).cuda()
+    out = fn(rays)
+    assert set(out.keys()) == {'rgb'} and out['rgb'].shape == (rays.shape[0], 3)
+    assert torch.equal(fn.forward_multiple(rays)['rgb'], out['rgb'])
+    emb = fn.embed(rays)
+    Z = 32
+    assert emb['points'].shape == (rays.shape[0], 3 * Z) and emb['distances'].shape == (rays.shape[0], Z)
+    assert linf(emb['distances'].cpu().numpy(), g.arrays['distances']) <= 1e-4
+    assert linf(emb['color_shift'].cpu().numpy(), g.arrays['color_shift'].reshape(rays.shape[0], -1)) <= 1e-5
+    fields = fn(rays, fields=['render_weights', 'distances'])
+    assert linf(fields['render_weights'].cpu().numpy(), g.arrays['render_weights']) <= 5e-5
+    from hyperreel_amd.render import render_chunked
+    chunked = render_chunked(rays, fn, {}, 100)
+    assert torch.equal(chunked['rgb'], out['rgb'])
+
+
+def test_errors_are_loud(fns):
+    g, fn = fns('donerf_sphere_small')
+    with pytest.raises(RuntimeError):
+        fn(torch.from_numpy(g.rays))          # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        fn(torch.zeros(4, 3, device='cuda'))
+    import ctypes
+    from hyperreel_amd import lib, plan
+    L = lib.load()
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    h = ctypes.c_void_p()
+    assert L.hr_model_create(ctypes.byref(hc), ctypes.byref(h)) == 0
+    assert L.hr_model_finalize(h) == -4 and b'never uploaded' in L.hr_last_error()
+    buf = torch.zeros(16, device='cuda')
+    assert L.hr_model_upload(h, b'mlp.0.bias', ctypes.c_void_p(buf.data_ptr()), 64) == -1
+    assert L.hr_model_upload(h, b'nope', ctypes.c_void_p(buf.data_ptr()), 64) == -1
+    assert L.hr_render(h, ctypes.c_void_p(buf.data_ptr()), 1, ctypes.c_void_p(buf.data_ptr()), None) == -2
+    L.hr_model_destroy(h)
+    hc.mlp_hidden = 100
+    assert L.hr_model_create(ctypes.byref(hc), ctypes.byref(h)) == -1
+
+
+def test_state_dict_roundtrip_keys(fns):
+    """Parameter names are the reference's checkpoint keys."""
+    g, fn = fns('technicolor_z_plane_small')
+    keys = set(fn.state_dict().keys())
+    for k in g.state_dict:
+        assert k in keys, k
+    assert 'model.embedding_model.embeddings.0.net.layers.5.weight' in keys
+    assert 'model.color_model.net.basis_mat_density.weight' in keys
+
+
+def test_full_frame_800x800_properties():
+    """BASELINE config 2 at full size (640 000 rays, 600^3 grid): oracle on a random
+    subset, plus size-independent properties on the whole frame."""
+    from gpu_common import make_render_fn
+    from hyperreel_oracle import HyperReelOracle
+    cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    rays = scenes.benchmark_rays('donerf_sphere', 800, 800)
+    fn = make_render_fn(cfg, ds, sd)
+    r = torch.from_numpy(rays).cuda()
+    rgb = fn(r)['rgb']
+    torch.cuda.synchronize()
+    assert rgb.shape == (640000, 3) and torch.isfinite(rgb).all()
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+    assert float(rgb.std()) > 0.02
+    # determinism and order independence on the whole frame
+    assert torch.equal(fn(r)['rgb'], rgb)
+    perm = torch.randperm(r.shape[0], device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    assert torch.equal(fn(r[perm].contiguous())['rgb'], rgb[perm])
+    # oracle on 4096 random pixels
+    idx = np.random.default_rng(3).choice(rays.shape[0], 4096, replace=False)
+    ref = HyperReelOracle(cfg, ds, sd).render(rays[idx])['rgb']
+    got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
+    err = np.abs(got - ref).max(-1)
+    assert err.max() <= RGB_TOL, f'L-inf {err.max():.3e}, {(err > RGB_TOL).sum()} of 4096 over'
+    psnr = -10.0 * np.log10(np.mean((got - ref) ** 2) + 1e-20)
+    assert psnr > 90.0
