@@ -37,6 +37,7 @@ from hyperreel_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak
 
 
 def algorithmic_bytes_per_ray(cfg, video):
@@ -94,6 +95,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
     ap.add_argument('--cpu-sample', type=int, default=65536, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'fp32'],
+                    help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -115,7 +118,7 @@ def main():
     video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
-    fn = build_render_fn(cfg, dataset=ds, grid_size=grid)
+    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision)
     fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     # tile of this rank: the same camera, panned by the tile index (weak scaling)
     rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
@@ -163,7 +166,7 @@ def main():
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
+        'dtype': 'f32', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
         'config': {'workload': f'BASELINE configs[1]: DoNeRF static ({args.model}), {args.height}x{args.width} frame '
                                f'= {B} rays per GPU, {cfg["embedding"]["embeddings"]["ray_prediction_0"]["z_channels"]} '
                                f'samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
@@ -202,10 +205,16 @@ def main():
         nl = len(offs)
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video) * B
-        r_mlp = {'kernel': 'hr_mlp_kernel', 'bound': 'mfma', 'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
-                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+        split = model._hc.mlp_precision == 1
+        peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        r_mlp = {'kernel': 'hr_mlp_bf16x3_kernel' if split else 'hr_mlp_kernel', 'bound': 'mfma',
+                 'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
+                 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / peak, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(mlp_ms[0] / nl, 4),
-                 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {min(chunk, B)} rays'}
+                 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {min(chunk, B)} rays',
+                 'note': ('fp32 GEMMs evaluated as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): the matrix '
+                          'cores issue 3x the algorithmic FLOPs, so frac <= 1/3 by construction') if split else
+                         'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
         r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
@@ -224,6 +233,8 @@ def main():
                                             f'(numpy fp32, single process) in {secs:.1f} s'}
         result['parity_vs_oracle_linf'] = float(np.abs(got - ref_rgb).max())
 
+    result['mlp_gemm'] = ('bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)'
+                          if model._hc.mlp_precision == 1 else 'fp32 MFMA')
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -47,6 +47,7 @@ struct hr_model {
     std::map<std::string, size_t> expect;  // name -> expected byte size
     // packed MLP
     float4* wpack[HR_MAX_LAYERS] = {};
+    void* wsplit[HR_MAX_LAYERS] = {};
     float* bias[HR_MAX_LAYERS] = {};
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
@@ -101,6 +102,8 @@ int validate(const hr_config& c)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
+    if (c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_BF16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256) return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
     return HR_OK;
 }
 
@@ -108,6 +111,23 @@ void free_dev(float*& p)
 {
     if (p) (void)hipFree(p);
     p = nullptr;
+}
+
+// float -> bf16 bits, round to nearest even (finite inputs)
+uint16_t bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+float bf16_to_float(uint16_t h)
+{
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
 }
 
 }  // namespace
@@ -200,43 +220,65 @@ int hr_model_finalize(hr_model* m)
         const bool first = (l == 0);
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
-        const int nt = (N + 15) / 16;
+        const bool split = (c.mlp_precision == HR_MLP_BF16X3);
+        const int tile_n = split ? 32 : 16;
+        const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N * Kt), b(N);
         snprintf(name, sizeof(name), "mlp.%d.weight", l);
         HR_HIP(hipMemcpy(w.data(), m->raw[name].p, w.size() * sizeof(float), hipMemcpyDeviceToHost));
         snprintf(name, sizeof(name), "mlp.%d.bias", l);
         HR_HIP(hipMemcpy(b.data(), m->raw[name].p, b.size() * sizeof(float), hipMemcpyDeviceToHost));
-        std::vector<float> pk((size_t)(Kp / 16) * nt * 64 * 4, 0.0f);
-        for (int kt = 0; kt < Kp / 16; ++kt)
-            for (int t = 0; t < nt; ++t)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int s = 0; s < 4; ++s) {
-                        const int n = 16 * t + (lane & 15);
-                        const int kk = 16 * kt + 4 * (lane >> 4) + s;   // kernel K index
-                        int col = -1;                                     // torch in-feature index
-                        if (first) {
-                            if (kk < c.mlp_in) col = kk;
-                        } else if (skip) {
-                            if (kk < m->k0p) { if (kk < c.mlp_in) col = kk; }
-                            else col = c.mlp_in + (kk - m->k0p);          // cat([input, x]), mlp.py:166-168
-                        } else {
-                            col = kk;
-                        }
-                        float v = 0.0f;
-                        if (n < N && col >= 0 && col < Kt) v = w[(size_t)n * Kt + col];
-                        pk[(((size_t)kt * nt + t) * 64 + lane) * 4 + s] = v;
-                    }
+        // torch weight element for (output feature n, kernel K index kk); 0 outside the matrix
+        auto wk = [&](int n, int kk) -> float {
+            int col = -1;                                                 // torch in-feature index
+            if (first) {
+                if (kk < c.mlp_in) col = kk;
+            } else if (skip) {
+                if (kk < m->k0p) { if (kk < c.mlp_in) col = kk; }
+                else col = c.mlp_in + (kk - m->k0p);                      // cat([input, x]), mlp.py:166-168
+            } else {
+                col = kk;
+            }
+            return (n < N && col >= 0 && col < Kt) ? w[(size_t)n * Kt + col] : 0.0f;
+        };
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
+        free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
         free_dev(m->bias[l]);
-        HR_HIP(hipMalloc((void**)&m->wpack[l], pk.size() * sizeof(float)));
-        HR_HIP(hipMemcpy(m->wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-        const int nb = nt * 16;
+        if (!split) {
+            std::vector<float> pk((size_t)(Kp / 16) * nt * 64 * 4, 0.0f);
+            for (int kt = 0; kt < Kp / 16; ++kt)
+                for (int t = 0; t < nt; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s)
+                            pk[(((size_t)kt * nt + t) * 64 + lane) * 4 + s] = wk(16 * t + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
+            HR_HIP(hipMalloc((void**)&m->wpack[l], pk.size() * sizeof(float)));
+            HR_HIP(hipMemcpy(m->wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+            m->packed_bytes += (int64_t)pk.size() * sizeof(float);
+        } else {
+            // hi = bf16(w), lo = bf16(w - hi), both round-to-nearest-even (layout: hr_kernels.h)
+            std::vector<uint16_t> pk((size_t)(Kp / 16) * nt * 2 * 64 * 8, 0);
+            for (int kt = 0; kt < Kp / 16; ++kt)
+                for (int t = 0; t < nt; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = wk(32 * t + (lane & 31), 16 * kt + 8 * (lane >> 5) + j);
+                            const uint16_t hi = bf16_rne(v);
+                            const uint16_t lo = bf16_rne(v - bf16_to_float(hi));
+                            const size_t base = ((((size_t)kt * nt + t) * 2) * 64 + lane) * 8 + j;
+                            pk[base] = hi;
+                            pk[base + 64 * 8] = lo;
+                        }
+            HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
+            HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            m->packed_bytes += (int64_t)pk.size() * sizeof(uint16_t);
+        }
+        const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
         for (int i = 0; i < N; ++i) bp[i] = b[i];
         HR_HIP(hipMalloc((void**)&m->bias[l], nb * sizeof(float)));
         HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         m->n_tiles[l] = nt;
-        m->packed_bytes += (int64_t)(pk.size() + nb) * sizeof(float);
+        m->packed_bytes += (int64_t)nb * sizeof(float);
     }
 
     // ---- grids: channel-last texels, density | appearance interleaved per plane pair
@@ -328,6 +370,12 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     return HR_OK;
 }
 
+static void launch_mlp(const hr_config& c, const HrMlpArgs& a, hipStream_t st)
+{
+    if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
+    else hr_launch_mlp(c, a, st);
+}
+
 static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n)
 {
     a.rays = rays;
@@ -335,6 +383,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.head = m->head;
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         a.wpack[l] = m->wpack[l];
+        a.wsplit[l] = m->wsplit[l];
         a.bias[l] = m->bias[l];
         a.n_tiles[l] = m->n_tiles[l];
     }
@@ -376,7 +425,7 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
         const float* rays = rays_dev + r0 * c.ray_dim;
         HrMlpArgs ma;
         fill_mlp_args(m, ma, rays, n);
-        hr_launch_mlp(c, ma, st);
+        launch_mlp(c, ma, st);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
         if (fields) {
@@ -406,7 +455,7 @@ int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* strea
     if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays_dev, n_rays);
-    hr_launch_mlp(m->cfg, ma, (hipStream_t)stream);
+    launch_mlp(m->cfg, ma, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -437,6 +486,7 @@ void hr_model_destroy(hr_model* m)
     for (auto& kv : m->raw) free_dev(kv.second.p);
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
+        free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
         free_dev(m->bias[l]);
     }
     for (int j = 0; j < 3; ++j) {

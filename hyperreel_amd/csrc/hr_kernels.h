@@ -18,9 +18,10 @@ struct HrMlpArgs {
     const float* rays;
     int64_t n_rays;
     float* head;                 // (n_rays, n_out) raw output of the last Linear
-    const float4* wpack[HR_MAX_LAYERS];
+    const float4* wpack[HR_MAX_LAYERS];   // HR_MLP_FP32: fp32 tiles (16-column tiles)
+    const void* wsplit[HR_MAX_LAYERS];    // HR_MLP_BF16X3: bf16 hi/lo tiles (32-feature tiles), see mlp_bf16x3_kernel.hip
     const float* bias[HR_MAX_LAYERS];
-    int n_tiles[HR_MAX_LAYERS];  // 16-column tiles of layer L (N padded up to 16)
+    int n_tiles[HR_MAX_LAYERS];  // output tiles of layer L: 16 columns (fp32) or 32 features (bf16x3)
     int n_out;                   // Z * P
     int k0p;                     // mlp_in padded to a multiple of 16
 };
@@ -56,6 +57,9 @@ struct HrSampleArgs {
 };
 
 void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
+// split-precision form: wsplit[L][(((kt * n_tiles[L] + nt) * 2 + part) * 64 + lane)] = 8 bf16 of
+//   W[n = 32*nt + (lane & 31)][k = 16*kt + 8*(lane >> 5) + 0..7], part 0 = hi (bf16(w)), 1 = lo (bf16(w - hi))
+void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 
 // layout kernels (pack_kernels.hip)

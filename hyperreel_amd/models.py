@@ -138,6 +138,8 @@ class HipLightfieldModel(nn.Module):
         self.cfg = cfg
         system = kwargs.get('system')
         self.dataset = kwargs['dataset'] if 'dataset' in kwargs else dataset_scalars_from_system(system)
+        # arithmetic of the MLP GEMMs: 'auto' | 'bf16x3' | 'fp32' (see plan.compile_config)
+        self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
             grid = list(kwargs['grid_size'])
@@ -152,7 +154,7 @@ class HipLightfieldModel(nn.Module):
         self._native = None
         self._native_key = None
         # fail on configurations outside the supported path now, not at the first render
-        compile_config(cfg, self.dataset, grid)
+        compile_config(cfg, self.dataset, grid, self.mlp_precision)
 
     # -- reference surface ---------------------------------------------------------
     def set_iter(self, i):
@@ -190,17 +192,22 @@ class HipLightfieldModel(nn.Module):
     # -- native side -------------------------------------------------------------------
     def _tensors(self):
         own = dict(self.named_parameters())
-        hc = compile_config(self.cfg, self.dataset, self.grid_size)
+        hc = compile_config(self.cfg, self.dataset, self.grid_size, self.mlp_precision)
         pred_idx = [i for i, e in enumerate(self.cfg['embedding']['embeddings'].values())
                     if e['type'] == 'ray_prediction'][0]
         return hc, [(abi, own[key.format(idx=pred_idx)]) for abi, key in upload_names(hc)]
 
+    def _param_key(self):
+        # cheap fingerprint of everything the native model was built from: in-place
+        # updates bump ._version, re-allocations change data_ptr/shape
+        return (self.mlp_precision,) + tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
+
     def native(self):
         """Returns the hr_model handle, (re)uploading weights if any parameter changed."""
-        hc, tensors = self._tensors()
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for _, t in tensors)
+        key = self._param_key()
         if self._native is not None and key == self._native_key:
             return self._native
+        hc, tensors = self._tensors()
         L = _lib.load()
         dev = tensors[0][1].device
         if dev.type != 'cuda':
@@ -212,7 +219,7 @@ class HipLightfieldModel(nn.Module):
                 _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
                 self._native = h
                 self._native_grid = self.grid_size
-            elif self._native_grid != self.grid_size:
+            elif self._native_grid != self.grid_size or self._hc.mlp_precision != hc.mlp_precision:
                 L.hr_model_destroy(self._native)
                 h = C.c_void_p()
                 _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')

@@ -73,7 +73,7 @@ class hr_config(C.Structure):
         ('num_keyframes', C.c_int32), ('n_den', C.c_int32 * 3), ('n_app', C.c_int32 * 3), ('app_dim', C.c_int32),
         ('shading', C.c_int32), ('distance_scale', C.c_float), ('weight_thresh', C.c_float),
         ('density_act', C.c_int32), ('density_shift', C.c_float), ('time_scale', C.c_float), ('time_offset', C.c_float),
-        ('white_bg', C.c_int32),
+        ('white_bg', C.c_int32), ('mlp_precision', C.c_int32),
     ]
 
 
@@ -150,7 +150,10 @@ class _MipNerf:
 
 
 # --------------------------------------------------------------------------- the compiler
-def compile_config(cfg, dataset, grid_size):
+MLP_PRECISION = {'fp32': 0, 'bf16x3': 1}
+
+
+def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     """cfg: `experiment.model` group (dict/Cfg); dataset: {near, far, depth_range,
     num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes."""
     if cfg.get('param', {}).get('fn', 'identity') != 'identity':
@@ -425,6 +428,14 @@ def compile_config(cfg, dataset, grid_size):
         hc.time_offset = float(0.5 / K)
         if not hc.advect:
             raise NotImplementedError('video net without an advect_points stage (base_times)')
+    # GEMM arithmetic of the MLP: 'bf16x3' (three bf16 MFMA products of hi/lo split operands,
+    # fp32 accumulate; >= 10x inside the 1e-4 RGB bar) when the kernel supports the width,
+    # 'fp32' (exact fp32 MFMA) otherwise or on request.
+    if mlp_precision == 'auto':
+        mlp_precision = 'bf16x3' if hc.mlp_hidden == 256 else 'fp32'
+    if mlp_precision == 'bf16x3' and hc.mlp_hidden != 256:
+        raise NotImplementedError('bf16x3 MLP needs hidden_channels == 256')
+    hc.mlp_precision = MLP_PRECISION[mlp_precision]
     return hc
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 1
+#define HR_ABI_VERSION 2
 
 #define HR_MAX_Z 64          /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_GROUPS 4      /* ray-parameterisation groups feeding the MLP (`params:` in the YAML) */
@@ -79,6 +79,9 @@ enum { HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2 };
 enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1 };
 enum { HR_DENSITY_RELU = 0, HR_DENSITY_SOFTPLUS = 1, HR_DENSITY_RELU_ABS = 2 };
 enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
+/* arithmetic of the MLP GEMMs: exact fp32 MFMA, or three bf16 MFMA products of the hi/lo
+ * split operands with fp32 accumulation (~2^-17 relative per product; needs mlp_hidden 256) */
+enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1 };
 
 /* Everything the kernels need that the reference derives from the model YAML and the
  * five dataset scalars (near, far, depth_range, num_keyframes, num_frames).  Derived
@@ -142,6 +145,7 @@ typedef struct hr_config {
     float density_shift;
     float time_scale, time_offset;       /* (F-1)/F and 0.5/K, tensorf_dynamic.py:58-59 */
     int32_t white_bg;
+    int32_t mlp_precision;               /* HR_MLP_* */
 } hr_config;
 
 /* Optional per-sample diagnostics of hr_render_fields (all device pointers, any may be
