@@ -180,7 +180,7 @@ def main():
         from hyperreel_amd import lib as hlib
         L = hlib.load()
         h = model.native()
-        chunk = 32768 if not args.chunk else args.chunk
+        chunk = 131072 if not args.chunk else args.chunk
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         rgb_tmp = torch.empty((B, 3), dtype=torch.float32, device='cuda')
         offs = list(range(0, B, chunk))

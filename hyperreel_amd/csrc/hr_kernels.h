@@ -14,16 +14,28 @@
 // (W[n][k] = torch weight (out=n, in=k) in the kernel's K order; zero outside the real matrix).
 // K order: plain layers: hidden index.  Layer 0: input feature index, padded to k0p.
 // Skip layers: [input features padded to k0p | hidden].
+// Layout of the raw MLP head in the workspace ("HQ"): rays in blocks of 64, features in quads,
+//   float index(ray, n) = (((ray / 64) * nq + n / 4) * 64 + ray % 64) * 4 + n % 4,  nq = ceil(n_out / 4)
+// The MLP's 32x32 accumulator tile holds 4 consecutive features of one ray per lane, so a
+// store instruction covers 32 rays x 16 B = 512 contiguous bytes; the sample kernel reads a
+// block's rays as RPB x 16 B contiguous runs per quad.
+__host__ __device__ inline size_t hr_head_index(int64_t ray, int n, int nq)
+{
+    return ((((size_t)(ray >> 6) * nq + (size_t)(n >> 2)) << 6) + (size_t)(ray & 63)) * 4 + (size_t)(n & 3);
+}
+
 struct HrMlpArgs {
     const float* rays;
     int64_t n_rays;
-    float* head;                 // (n_rays, n_out) raw output of the last Linear
+    float* head;                 // raw output of the last Linear, HQ layout (hr_head_index)
     const float4* wpack[HR_MAX_LAYERS];   // HR_MLP_FP32: fp32 tiles (16-column tiles)
     const void* wsplit[HR_MAX_LAYERS];    // HR_MLP_BF16X3: bf16 hi/lo tiles (32-feature tiles), see mlp_bf16x3_kernel.hip
     const float* bias[HR_MAX_LAYERS];
     int n_tiles[HR_MAX_LAYERS];  // output tiles of layer L: 16 columns (fp32) or 32 features (bf16x3)
     int n_out;                   // Z * P
+    int nq;                      // ceil(n_out / 4)
     int k0p;                     // mlp_in padded to a multiple of 16
+    unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -46,7 +58,8 @@ struct HrGridPlane {
 
 struct HrSampleArgs {
     const float* rays;
-    const float* head;
+    const float* head;      // HQ layout (hr_head_index)
+    int nq;                 // ceil(Z*P / 4)
     int64_t n_rays;
     float* rgb;
     hr_fields fields;       // optional diagnostics (NULL pointers when unused)
@@ -64,6 +77,8 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
 
 // layout kernels (pack_kernels.hip)
 // dst[y][x][c_off + c] = src[c][y][x] for c < C  (dst texel stride = tex floats)
+// out[r * n_out + n] = head[hr_head_index(r, n, nq)]  (diagnostics export of the raw head)
+void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int n_out, int nq, hipStream_t stream);
 void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 
 #endif

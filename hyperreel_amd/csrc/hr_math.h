@@ -95,8 +95,13 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
             for (int j = 0; j < pg.pe_n_freqs; ++j) {
                 f = f * pg.pe_freq_mult;                           // freq_multiplier ** (j+1)
                 float bf = pg.pe_base_mult * f;
-                for (int i = 0; i < nx; ++i) out[n_out++] = sinf(bf * HR_X(i));
-                for (int i = 0; i < nx; ++i) out[n_out++] = cosf(bf * HR_X(i));
+                for (int i = 0; i < nx; ++i) {                     // [sin(all i), cos(all i)] per frequency
+                    float sv, cv;
+                    sincosf(bf * HR_X(i), &sv, &cv);
+                    out[n_out + i] = sv;
+                    out[n_out + nx + i] = cv;
+                }
+                n_out += 2 * nx;
             }
         } else if (pg.pe_type == HR_PE_BASIC) {  // [x, sin(f_j x_i) (i-major, j-minor), cos(...)]
             for (int i = 0; i < nx; ++i) {

@@ -11,18 +11,22 @@
 // reference on every model family (tests/test_gpu_parity.py), i.e. >= 10x inside the 1e-4 bar
 // -- at 3/16 of the fp32-MFMA issue time.
 //
-// Structure (per workgroup: 64 rays, 4 waves, 2 workgroups per CU):
+// Structure (per workgroup: 32*MT rays, 4 waves):
 //   * "swapped" GEMM: D[n][m] = sum_k W[n][k] X[m][k], weights as the A operand and rays as
 //     the B operand.  In the 32x32 accumulator layout a lane then holds 4 consecutive output
 //     features of ONE ray per register quad, so the epilogue packs them into one 8-byte LDS
 //     store (hi) + one (lo), and the last layer stores 16-byte float4s;
-//   * activations live in LDS only, already split: Xh/Xl[64][W+8] bf16 (16-byte row pad ->
+//   * activations live in LDS only, already split: Xh/Xl[32*MT][W+8] bf16 (16-byte row pad ->
 //     the 16 rows of a ds_read_b128 lane group fall on distinct bank slots);
 //   * weights are split and tiled once by hr_model_finalize into the exact lane order of the
-//     MFMA A operand: one coalesced 16-byte load per lane per tile, from L2;
-//   * per 16-wide k-step a wave issues 4 global loads + 4 ds_read_b128 for 12 MFMAs
-//     (2 n-tiles x 2 m-tiles x 3 products); the next k-step's operands are prefetched into a
-//     second register set before the current MFMAs issue.
+//     MFMA A operand: one coalesced 16-byte load per lane per tile, from L2.  A wave owns
+//     64 output features (2 n-tiles) and ALL rays of the workgroup (MT m-tiles), so per 16-wide
+//     k-step it issues 4 global loads + 2*MT ds_read_b128 for 6*MT MFMAs.  MT = 4 (128 rays,
+//     one workgroup per CU, 128 accumulator VGPRs) halves the weight bytes that cross the
+//     CU's vector L1 per MFMA relative to MT = 2 (64 rays, two workgroups per CU);
+//   * weights run 3 k-steps ahead of their use in a 4-slot register ring, activations one.
+#include <cstdlib>
+
 #include "hr_kernels.h"
 #include "hr_math.h"
 
@@ -30,55 +34,111 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-#define HR_TILE_M 64
-
-struct HrOperands {
-    bf16x8 wh[2], wl[2];   // weights (A operand), 2 n-tiles
-    bf16x8 xh[2], xl[2];   // activations (B operand), 2 m-tiles
+struct HrWOps {
+    bf16x8 h[2], l[2];   // weights (A operand), hi/lo halves of 2 n-tiles
+};
+template <int MT>
+struct HrXOps {
+    bf16x8 h[MT], l[MT];   // activations (B operand), hi/lo halves of MT m-tiles
 };
 
-__device__ __forceinline__ void hr_load_operands(HrOperands& o, const __bf16* __restrict__ xh, const __bf16* __restrict__ xl,
-                                                 int stride, int kt, const bf16x8* __restrict__ wp, int wkt,
-                                                 int tiles_total, const int (&tile)[2], int lane)
+__device__ __forceinline__ void hr_load_w(HrWOps& o, const bf16x8* __restrict__ wp, int wkt, int tiles_total,
+                                          const int (&tile)[2], int lane)
 {
-    const int xoff = (lane & 31) * stride + kt * 16 + 8 * (lane >> 5);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        o.xh[mt] = *reinterpret_cast<const bf16x8*>(xh + xoff + mt * 32 * stride);
-        o.xl[mt] = *reinterpret_cast<const bf16x8*>(xl + xoff + mt * 32 * stride);
-    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const size_t base = (((size_t)wkt * tiles_total + tile[nt]) * 2) * 64 + lane;
-        o.wh[nt] = wp[base];
-        o.wl[nt] = wp[base + 64];
+        o.h[nt] = wp[base];
+        o.l[nt] = wp[base + 64];
     }
 }
 
-__device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][2], const HrOperands& o)
+template <int MT>
+__device__ __forceinline__ void hr_load_x(HrXOps<MT>& o, const __bf16* __restrict__ xh, const __bf16* __restrict__ xl,
+                                          int stride, int kt, int lane)
+{
+    const int xoff = (lane & 31) * stride + kt * 16 + 8 * (lane >> 5);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        o.h[mt] = *reinterpret_cast<const bf16x8*>(xh + xoff + mt * 32 * stride);
+        o.l[mt] = *reinterpret_cast<const bf16x8*>(xl + xoff + mt * 32 * stride);
+    }
+}
+
+// 6*MT MFMAs of one k-step; products are the outer loop so that consecutive MFMAs write
+// different accumulators (no back-to-back dependent issue)
+template <int MT>
+__device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][MT], const HrWOps& w, const HrXOps<MT>& x)
 {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.wl[nt], o.xh[mt], acc[nt][mt], 0, 0, 0);
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.wh[nt], o.xl[mt], acc[nt][mt], 0, 0, 0);
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.wh[nt], o.xh[mt], acc[nt][mt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l[nt], x.h[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[nt], x.l[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[nt], x.h[mt], acc[nt][mt], 0, 0, 0);
 }
 
-// acc += W[:, segment] * X[segment]^T over nkt 16-wide k-steps, software-pipelined one step deep
-__device__ __forceinline__ void hr_accumulate3(floatx16 (&acc)[2][2], const __bf16* xh, const __bf16* xl, int stride, int nkt,
+// acc += W[:, segment] * X[segment]^T over NKT (multiple of 4, compile-time) 16-wide k-steps.
+// Weights come from L2 (several hundred cycles): a 4-slot register ring keeps them 3 k-steps
+// ahead of their use; activations come from LDS and run one step ahead.
+template <int NKT, int MT>
+__device__ __forceinline__ void hr_accumulate3_pipe(floatx16 (&acc)[2][MT], const __bf16* xh, const __bf16* xl, int stride,
+                                                    const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[2], int lane)
+{
+    static_assert(NKT % 4 == 0 && NKT >= 4, "k-steps must come in fours");
+    HrWOps w0, w1, w2, w3;
+    HrXOps<MT> x0, x1;
+    hr_load_w(w0, wp, kt0, tiles_total, tile, lane);
+    hr_load_w(w1, wp, kt0 + 1, tiles_total, tile, lane);
+    hr_load_w(w2, wp, kt0 + 2, tiles_total, tile, lane);
+    hr_load_x<MT>(x0, xh, xl, stride, 0, lane);
+#pragma unroll 1
+    for (int kt = 0; kt < NKT - 4; kt += 4) {
+        hr_load_w(w3, wp, kt0 + kt + 3, tiles_total, tile, lane);
+        hr_load_x<MT>(x1, xh, xl, stride, kt + 1, lane);
+        hr_mfma3<MT>(acc, w0, x0);
+        hr_load_w(w0, wp, kt0 + kt + 4, tiles_total, tile, lane);
+        hr_load_x<MT>(x0, xh, xl, stride, kt + 2, lane);
+        hr_mfma3<MT>(acc, w1, x1);
+        hr_load_w(w1, wp, kt0 + kt + 5, tiles_total, tile, lane);
+        hr_load_x<MT>(x1, xh, xl, stride, kt + 3, lane);
+        hr_mfma3<MT>(acc, w2, x0);
+        hr_load_w(w2, wp, kt0 + kt + 6, tiles_total, tile, lane);
+        hr_load_x<MT>(x0, xh, xl, stride, kt + 4, lane);
+        hr_mfma3<MT>(acc, w3, x1);
+    }
+    // last four k-steps: nothing left to prefetch beyond NKT-1
+    hr_load_w(w3, wp, kt0 + NKT - 1, tiles_total, tile, lane);
+    hr_load_x<MT>(x1, xh, xl, stride, NKT - 3, lane);
+    hr_mfma3<MT>(acc, w0, x0);
+    hr_load_x<MT>(x0, xh, xl, stride, NKT - 2, lane);
+    hr_mfma3<MT>(acc, w1, x1);
+    hr_load_x<MT>(x1, xh, xl, stride, NKT - 1, lane);
+    hr_mfma3<MT>(acc, w2, x0);
+    hr_mfma3<MT>(acc, w3, x1);
+}
+
+// Input segment (k0p/16 = 1..4 k-steps): short, no ring.
+template <int MT>
+__device__ __forceinline__ void hr_accumulate3(floatx16 (&acc)[2][MT], const __bf16* xh, const __bf16* xl, int stride, int nkt,
                                                const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[2], int lane)
 {
-    HrOperands cur, nxt;
-    hr_load_operands(cur, xh, xl, stride, 0, wp, kt0, tiles_total, tile, lane);
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
-        hr_load_operands(nxt, xh, xl, stride, kt + 1, wp, kt0 + kt + 1, tiles_total, tile, lane);
-        hr_mfma3(acc, cur);
-        cur = nxt;
+    for (int kt = 0; kt < nkt; ++kt) {
+        HrWOps w;
+        HrXOps<MT> x;
+        hr_load_w(w, wp, kt0 + kt, tiles_total, tile, lane);
+        hr_load_x<MT>(x, xh, xl, stride, kt, lane);
+        hr_mfma3<MT>(acc, w, x);
     }
-    hr_mfma3(acc, cur);
 }
 
 __device__ __forceinline__ void hr_split_store4(__bf16* xh, __bf16* xl, int idx, float v0, float v1, float v2, float v3)
@@ -93,28 +153,34 @@ __device__ __forceinline__ void hr_split_store4(__bf16* xh, __bf16* xl, int idx,
     *reinterpret_cast<bf16x4*>(xl + idx) = l;
 }
 
-template <int W>
-__global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config cfg, const HrMlpArgs a)
+template <int W, int MT>
+__global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(const hr_config cfg, const HrMlpArgs a)
 {
+    constexpr int TM = 32 * MT;           // rays per workgroup
     constexpr int XS = W + 8;             // bf16 elements per activation row
     constexpr int NTW = W / 256;          // passes of 2 x 32 output features per wave in hidden layers
     static_assert(W % 256 == 0, "hidden width must be a multiple of 256");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int k0p = a.k0p;
     const int XSI = k0p + 8;
-    __bf16* Xih = reinterpret_cast<__bf16*>(lds_raw);       // [64][k0p+8] MLP input, hi
-    __bf16* Xil = Xih + HR_TILE_M * XSI;                     //              lo
-    __bf16* Xh = Xil + HR_TILE_M * XSI;                      // [64][W+8] hidden activations, hi
-    __bf16* Xl = Xh + HR_TILE_M * XS;                        //            lo
+    __bf16* Xih = reinterpret_cast<__bf16*>(lds_raw);       // [TM][k0p+8] MLP input, hi
+    __bf16* Xil = Xih + TM * XSI;                            //              lo
+    __bf16* Xh = Xil + TM * XSI;                             // [TM][W+8] hidden activations, hi
+    __bf16* Xl = Xh + TM * XS;                               //            lo
     float* stage = reinterpret_cast<float*>(Xh);             // fp32 features, only before layer 0
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t ray0 = (int64_t)blockIdx.x * HR_TILE_M;
+    const int64_t ray0 = (int64_t)blockIdx.x * TM;
 
+    // optional per-wave phase timeline (hr_debug_trace_mlp): s_memtime stamps, 64 slots per wave
+    unsigned long long* tr = a.trace ? a.trace + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
+    int tri = 0;
+#define HR_STAMP() do { if (tr && lane == 0 && tri < 64) tr[tri] = __builtin_readcyclecounter(); ++tri; } while (0)
+    HR_STAMP();                                              // 0: start
     // ---- prologue: ray parameterisation + positional encoding (fp32), then split
-    if (tid < HR_TILE_M) {
+    if (tid < TM) {
         const int64_t r = ray0 + tid;
         float* row = stage + tid * k0p;
         int n = 0;
@@ -122,12 +188,13 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
         for (int i = n; i < k0p; ++i) row[i] = 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < HR_TILE_M * (k0p / 4); i += 256) {
+    for (int i = tid; i < TM * (k0p / 4); i += 256) {
         const int r = i / (k0p / 4), c4 = i - r * (k0p / 4);
         const float4 v = *reinterpret_cast<const float4*>(stage + r * k0p + 4 * c4);
         hr_split_store4(Xih, Xil, r * XSI + 4 * c4, v.x, v.y, v.z, v.w);
     }
     __syncthreads();
+    HR_STAMP();                                              // 1: prologue done
 
     const int L = cfg.mlp_layers;
     // ---- hidden layers: wave w owns output features [w*W/4, (w+1)*W/4) in NTW passes of 2 tiles
@@ -135,40 +202,40 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
         const bool skip = (cfg.mlp_skip_mask >> l) & 1;
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wsplit[l]);
         const int tiles_total = a.n_tiles[l];
-        floatx16 acc[NTW][2][2];
-#pragma unroll
+        const float* bias = a.bias[l];
+#pragma unroll 1
         for (int p = 0; p < NTW; ++p) {
+            floatx16 acc[2][MT];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[p][nt][mt][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
             const int tile[2] = {wave * (2 * NTW) + 2 * p, wave * (2 * NTW) + 2 * p + 1};
             int kt0 = 0;
             if (l == 0 || skip) {
-                hr_accumulate3(acc[p], Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
+                hr_accumulate3<MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
                 kt0 = k0p / 16;
             }
-            if (l > 0) hr_accumulate3(acc[p], Xh, Xl, XS, W / 16, wp, kt0, tiles_total, tile, lane);
-        }
-        __syncthreads();  // all waves have finished reading Xh/Xl
-        const float* bias = a.bias[l];
-#pragma unroll
-        for (int p = 0; p < NTW; ++p)
+            if (l > 0) hr_accumulate3_pipe<W / 16, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+            HR_STAMP();                          // 2+3l: GEMM of layer l issued
+            if (p == NTW - 1) __syncthreads();   // all waves have finished reading Xh/Xl (NTW == 1 for W = 256)
+            HR_STAMP();                          // 3+3l: barrier passed
+            static_assert(NTW == 1, "W > 256 needs the outputs of a pass staged before X is overwritten");
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int nbase = (wave * (2 * NTW) + 2 * p + nt) * 32 + 4 * (lane >> 5);
+                const int nbase = tile[nt] * 32 + 4 * (lane >> 5);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n0 = nbase + 8 * g;
                     const float4 b = *reinterpret_cast<const float4*>(bias + n0);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        float v0 = acc[p][nt][mt][4 * g + 0] + b.x;
-                        float v1 = acc[p][nt][mt][4 * g + 1] + b.y;
-                        float v2 = acc[p][nt][mt][4 * g + 2] + b.z;
-                        float v3 = acc[p][nt][mt][4 * g + 3] + b.w;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        float v0 = acc[nt][mt][4 * g + 0] + b.x;
+                        float v1 = acc[nt][mt][4 * g + 1] + b.y;
+                        float v2 = acc[nt][mt][4 * g + 2] + b.z;
+                        float v3 = acc[nt][mt][4 * g + 3] + b.w;
                         v0 = (v0 > 0.0f) ? v0 : v0 * cfg.leaky_slope;   // nn.LeakyReLU(0.01), mlp.py:149-154
                         v1 = (v1 > 0.0f) ? v1 : v1 * cfg.leaky_slope;
                         v2 = (v2 > 0.0f) ? v2 : v2 * cfg.leaky_slope;
@@ -177,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
                     }
                 }
             }
+        }
         __syncthreads();
+        HR_STAMP();                              // 4+3l: epilogue + barrier done
     }
 
     // ---- last Linear: N = Z*P features in passes of 4 waves x 2 tiles of 32
@@ -187,23 +256,25 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wsplit[l]);
         const int tiles_total = a.n_tiles[l];
         const float* bias = a.bias[l];
+#pragma unroll 1
         for (int t0 = 0; t0 < tiles_total; t0 += 8) {
             const int tile[2] = {t0 + wave * 2, t0 + wave * 2 + 1};
             if (tile[0] >= tiles_total) continue;                       // wave-uniform
             const int tile_ld[2] = {tile[0], min(tile[1], tiles_total - 1)};
-            floatx16 acc[2][2];
+            floatx16 acc[2][MT];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
             int kt0 = 0;
             if (skip) {
-                hr_accumulate3(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
+                hr_accumulate3<MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
                 kt0 = k0p / 16;
             }
-            hr_accumulate3(acc, Xh, Xl, XS, W / 16, wp, kt0, tiles_total, tile_ld, lane);
+            hr_accumulate3_pipe<W / 16, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
+            HR_STAMP();                          // last layer: GEMM of this pass issued
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (tile[nt] >= tiles_total) continue;
@@ -213,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
                     if (n0 >= a.n_out) continue;
                     const float4 b = *reinterpret_cast<const float4*>(bias + n0);   // bias is padded to the tile
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         const int64_t row = ray0 + mt * 32 + (lane & 31);
                         if (row >= a.n_rays) continue;
                         float4 v;
@@ -221,39 +292,46 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_bf16x3_kernel(const hr_config c
                         v.y = acc[nt][mt][4 * g + 1] + b.y;
                         v.z = acc[nt][mt][4 * g + 2] + b.z;
                         v.w = acc[nt][mt][4 * g + 3] + b.w;
-                        float* dst = a.head + row * a.n_out + n0;
-                        if (n0 + 3 < a.n_out && (a.n_out & 3) == 0) {
-                            *reinterpret_cast<float4*>(dst) = v;
-                        } else {
-                            dst[0] = v.x;
-                            if (n0 + 1 < a.n_out) dst[1] = v.y;
-                            if (n0 + 2 < a.n_out) dst[2] = v.z;
-                            if (n0 + 3 < a.n_out) dst[3] = v.w;
-                        }
+                        // HQ layout: the 32 lanes of a half-wave write 512 contiguous bytes
+                        *reinterpret_cast<float4*>(a.head + hr_head_index(row, n0, a.nq)) = v;
                     }
                 }
             }
+            HR_STAMP();                          // last layer: stores of this pass issued
         }
     }
+#undef HR_STAMP
 }
 
-template <int W>
-static void hr_launch_mlp_bf16x3_w(const hr_config& cfg, const HrMlpArgs& args, unsigned blocks, size_t lds, hipStream_t stream)
+template <int W, int MT>
+static void hr_launch_mlp_bf16x3_t(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
 {
+    constexpr int TM = 32 * MT;
+    const size_t lds = (size_t)TM * 2 * ((args.k0p + 8) + (W + 8)) * sizeof(__bf16);
+    const unsigned blocks = (unsigned)((args.n_rays + TM - 1) / TM);
     static size_t allowed = 0;
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_bf16x3_kernel<W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_bf16x3_kernel<W, MT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         allowed = lds;
     }
-    hipLaunchKernelGGL(hr_mlp_bf16x3_kernel<W>, dim3(blocks), dim3(256), lds, stream, cfg, args);
+    hipLaunchKernelGGL((hr_mlp_bf16x3_kernel<W, MT>), dim3(blocks), dim3(256), lds, stream, cfg, args);
 }
 
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
 {
     if (args.n_rays <= 0) return;
-    const int W = cfg.mlp_hidden;
-    const size_t lds = (size_t)HR_TILE_M * 2 * ((args.k0p + 8) + (W + 8)) * sizeof(__bf16);
-    const unsigned blocks = (unsigned)((args.n_rays + HR_TILE_M - 1) / HR_TILE_M);
-    if (W == 256) hr_launch_mlp_bf16x3_w<256>(cfg, args, blocks, lds, stream);   // other widths: rejected by hr_model_create
+    // rays per workgroup: 64 (default: two workgroups per CU hide each other's epilogues;
+    // measured 1.50 ms per 640k rays) or 128 (one workgroup per CU, half the L1 weight traffic
+    // but nothing to overlap with; 1.83 ms).  HR_MLP_TILE=128 selects the latter for A/B runs.
+    static const int tile_m = [] {
+        const char* e = getenv("HR_MLP_TILE");
+        return (e && atoi(e) == 128) ? 128 : 64;
+    }();
+    // the 128-ray tile needs 2*128*((k0p+8)+(W+8))*2 bytes of LDS <= 160 KiB
+    const bool fits128 = (size_t)128 * 2 * ((args.k0p + 8) + (cfg.mlp_hidden + 8)) * 2 <= 160 * 1024;
+    if (cfg.mlp_hidden == 256) {   // other widths: rejected by hr_model_create
+        if (tile_m == 128 && fits128) hr_launch_mlp_bf16x3_t<256, 4>(cfg, args, stream);
+        else hr_launch_mlp_bf16x3_t<256, 2>(cfg, args, stream);
+    }
 }

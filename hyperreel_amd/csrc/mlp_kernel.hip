@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_kernel(const hr_config cfg, con
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int64_t row = ray0 + mt * 16 + 4 * (lane >> 4) + r;
-                            if (row < a.n_rays) a.head[row * a.n_out + col] = acc[mt][nt][r] + b;
+                            if (row < a.n_rays) a.head[hr_head_index(row, col, a.nq)] = acc[mt][nt][r] + b;
                         }
                     }
                 }

@@ -17,6 +17,25 @@ __global__ void hr_interleave_kernel(const float* __restrict__ src, float* __res
     }
 }
 
+__global__ void hr_head_export_kernel(const float* __restrict__ head, float* __restrict__ out, int64_t n_rays, int n_out, int nq)
+{
+    const int64_t total = n_rays * n_out;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_out;
+        const int n = (int)(i - r * n_out);
+        out[i] = head[hr_head_index(r, n, nq)];
+    }
+}
+
+void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int n_out, int nq, hipStream_t stream)
+{
+    const int64_t total = n_rays * n_out;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(hr_head_export_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, head, out, n_rays, n_out, nq);
+}
+
 void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream)
 {
     const int64_t n = (int64_t)C * H * W;

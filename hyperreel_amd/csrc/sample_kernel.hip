@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Z = cfg.z_channels;
     const int P = cfg.preds_per_z;
-    const int ZPn = Z * P;
     const int CA = a.ca_total;                   // padded appearance slots (multiple of 4)
-    float* s_head = lds;                           // [RPB][Z*P]
-    float* s_M = lds + ((RPB * ZPn + 3) & ~3);     // [RPB][3][CA]
+    const int HS = a.nq * 4 + 4;                   // LDS row stride of a ray's head (+4: conflict-free float4 fills)
+    float* s_head = lds;                           // [RPB][HS]
+    float* s_M = lds + RPB * HS;                   // [RPB][3][CA]
 
     const int tid = threadIdx.x;
     const int rib = tid / ZP;
@@ -86,19 +86,14 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     const bool ray_ok = ray < a.n_rays;
     const bool lane_ok = ray_ok && (k < Z);
 
-    // ---- stage this block's head rows (contiguous in memory) into LDS
+    // ---- stage this block's head into LDS: per feature quad the block's RPB rays are RPB x 16
+    //      contiguous bytes in the HQ layout (RPB divides 64, so a block never straddles a 64-ray group)
     {
-        const int64_t n_here = min((int64_t)RPB, a.n_rays - ray_base);
-        const int total = (int)(n_here * ZPn);
-        const float* src = a.head + ray_base * ZPn;
-        if ((((uintptr_t)src) & 15) == 0) {
-            const int n4 = total >> 2;
-            const float4* src4 = reinterpret_cast<const float4*>(src);
-            float4* dst4 = reinterpret_cast<float4*>(s_head);
-            for (int i = tid; i < n4; i += 256) dst4[i] = src4[i];
-            for (int i = (n4 << 2) + tid; i < total; i += 256) s_head[i] = src[i];
-        } else {
-            for (int i = tid; i < total; i += 256) s_head[i] = src[i];
+        const float4* src4 = reinterpret_cast<const float4*>(a.head) + ((size_t)(ray_base >> 6) * a.nq << 6) + (ray_base & 63);
+        const int total = a.nq * RPB;
+        for (int i = tid; i < total; i += 256) {
+            const int q = i / RPB, r = i - q * RPB;
+            *reinterpret_cast<float4*>(s_head + r * HS + 4 * q) = src4[((size_t)q << 6) + r];
         }
     }
 
@@ -144,7 +139,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     }
     __syncthreads();
 
-    const float* hk = s_head + rib * ZPn + (lane_ok ? k : 0) * P;
+    const float* hk = s_head + rib * HS + (lane_ok ? k : 0) * P;
 
     // ---- distances: intersect + mask, then sort along the ray (base.py:152-210)
     float dist = __builtin_inff();
@@ -320,12 +315,10 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     }
 }
 
-static size_t hr_sample_lds_bytes(const hr_config& cfg, int ca_total, int ZP)
+static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP)
 {
     const int RPB = 256 / ZP;
-    const int CA = ca_total;
-    const size_t head = ((size_t)RPB * cfg.z_channels * cfg.preds_per_z + 3) & ~(size_t)3;
-    return (head + (size_t)RPB * 3 * CA) * sizeof(float);
+    return ((size_t)RPB * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total) * sizeof(float);
 }
 
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream)
@@ -336,7 +329,7 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     while (ZP < Z) ZP <<= 1;
     const int RPB = 256 / ZP;
     const unsigned blocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
-    const size_t lds = hr_sample_lds_bytes(cfg, args.ca_total, ZP);
+    const size_t lds = hr_sample_lds_bytes(args.nq, args.ca_total, ZP);
     switch (ZP) {
         case 8: hipLaunchKernelGGL(hr_sample_kernel<8>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
         case 16: hipLaunchKernelGGL(hr_sample_kernel<16>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;

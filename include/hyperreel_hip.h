@@ -200,6 +200,11 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream);
 int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 
+/* Profiling aid: runs the MLP stage with a per-wave phase timeline.  trace_dev receives 64
+ * s_memtime stamps per wave (4 waves per workgroup, workgroups of 64 or 128 rays); only the
+ * split-precision kernel records stamps. */
+int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsigned long long* trace_dev, void* stream);
+
 /* bytes of device memory held by the model (packed grids + weights + workspace) */
 int64_t hr_model_device_bytes(const hr_model* m);
 
