@@ -358,4 +358,4 @@ class HipLightfieldModel(nn.Module):
         return out
 
 
-model_dict = {'lightfield': HipLightfieldModel}
+model_dict = {'lightfield': HipLightfieldModel, 'lightfield_hip': HipLightfieldModel}

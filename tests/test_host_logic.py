@@ -1,0 +1,124 @@
+"""CPU tests of the host-side mirror: config surface, YAML -> hr_config compiler, C-ABI library
+loading (no compute calls), error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hyperreel_amd import config as C
+from hyperreel_amd import plan, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize('name', C.MODEL_NAMES)
+def test_builtin_model_groups_equal_shipped_yaml(name):
+    ref = C.to_plain(C.load_model_yaml(f'/root/reference/conf/experiment/model/{name}.yaml'))
+    assert C.to_plain(C.model_config(name)) == ref
+
+
+def test_final_grid_sizes():
+    # utils/tensorf_utils.py:65-68 on N_voxel_final
+    want = {'donerf_sphere': [600, 600, 600], 'technicolor_z_plane': [1007, 1007, 503],
+            'neural_3d_z_plane': [823, 617, 514], 'immersive_sphere': [640, 640, 640]}
+    for k, v in want.items():
+        assert C.final_grid_size(C.model_config(k)) == v
+
+
+def test_epoch_to_iter_rewrite():
+    cfg = C.model_config('donerf_sphere')
+    C.epoch_to_iter(cfg, 4000)
+    sig = cfg.embedding.embeddings.ray_prediction_0.outputs.sigma.activation
+    assert sig.window_iters == 12000 and sig.wait_iters == 0 and sig.window_epochs == 3
+    pe = cfg.embedding.embeddings.ray_prediction_0.params.ray.pe
+    assert pe.max_freq_iter == 0
+
+
+def test_yaml_loader_reads_exponent_floats(tmp_path):
+    p = tmp_path / 'm.yaml'
+    p.write_text('a: 1e-3\nb: 2.5e2\nc: [1, 2]\nd: hello\n')
+    cfg = C.load_model_yaml(str(p))
+    assert cfg.a == 1e-3 and cfg.b == 250.0 and cfg.c == [1, 2] and cfg.d == 'hello'
+
+
+@pytest.mark.parametrize('name', C.MODEL_NAMES)
+def test_compile_config_matches_oracle_constants(name):
+    """The flat hr_config and the oracle derive the same anchors / scales / contraction constants
+    from the YAML by independent code."""
+    from hyperreel_oracle import HyperReelOracle
+    cfg, ds = C.model_config(name), C.dataset_scalars(name)
+    grid = [20, 24, 28]
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=1)
+    orc = HyperReelOracle(cfg, ds, sd)
+    hc = plan.compile_config(cfg, ds, grid)
+    Z = hc.z_channels
+    assert Z == orc.Z
+    assert np.array_equal(np.asarray(hc.samples[:Z], np.float32), orc.samples)
+    assert np.float32(hc.z_scale) == np.float32(orc.z_scale)
+    assert np.float32(hc.near) == np.float32(orc.near)
+    assert hc.preds_per_z == sum(orc.out_shapes)
+    assert hc.mlp_in == orc.layers[0][0].shape[1]
+    assert hc.mlp_layers == len(orc.layers)
+    assert [hc.grid[i] for i in range(3)] == grid
+    if hc.contract_type == 1:
+        assert np.float32(hc.c_r0) == np.float32(orc.contract.r0)
+        assert np.float32(hc.c_d_scale) == np.float32(1.0 / (1.0 - orc.contract.d0 / orc.contract.d1))
+    assert hc.mlp_precision == 1          # hidden 256 -> split-bf16 MFMA by default
+    assert plan.compile_config(cfg, ds, grid, mlp_precision='fp32').mlp_precision == 0
+
+
+def test_out_of_scope_keys_raise():
+    ds = C.dataset_scalars('donerf')
+    cfg = C.model_config('donerf_sphere')
+    cfg.embedding.embeddings.ray_intersect_0.intersect.type = 'voxel_grid'
+    with pytest.raises(NotImplementedError, match='voxel_grid'):
+        plan.compile_config(cfg, ds, [8, 8, 8])
+    cfg = C.model_config('donerf_sphere')
+    cfg.color.net.shadingMode = 'MLP_Fea'
+    with pytest.raises(NotImplementedError, match='MLP_Fea'):
+        plan.compile_config(cfg, ds, [8, 8, 8])
+    cfg = C.model_config('donerf_sphere')
+    cfg.embedding.embeddings.ray_prediction_0.outputs.sigma.activation = C.to_cfg({'type': 'softplus'})
+    with pytest.raises(NotImplementedError, match='softplus'):
+        plan.compile_config(cfg, ds, [8, 8, 8])
+    cfg = C.model_config('donerf_sphere')
+    cfg.embedding.embeddings.ray_prediction_0.net.hidden_channels = 128
+    assert plan.compile_config(cfg, ds, [8, 8, 8]).mlp_precision == 0      # falls back to exact fp32 MFMA
+    with pytest.raises(NotImplementedError):
+        plan.compile_config(cfg, ds, [8, 8, 8], mlp_precision='bf16x3')
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """No GPU needed: dlopen the in-tree library and resolve each symbol of the header."""
+    from hyperreel_amd import build, lib
+    build.build()
+    handle = lib.load()
+    header = open(os.path.join(ROOT, 'include', 'hyperreel_hip.h')).read()
+    declared = set(re.findall(r'\b(hr_[a-z_0-9]+)\s*\(', header))
+    declared -= {'hr_model'}
+    assert declared, 'no declarations found'
+    bound = {name for name, _, _ in lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert handle.hr_abi_version() == lib.ABI_VERSION
+    assert handle.hr_sizeof_config() == ctypes.sizeof(plan.hr_config)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'hyperreel_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'hyperreel_oracle' not in src and 'import oracle' not in src, f
+
+
+def test_shard_bounds():
+    from hyperreel_amd.parallel import shard_bounds, shard_range
+    assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]
+    assert shard_bounds(640000, 8)[-1] == 640000 and shard_range(640000, 7, 8) == (560000, 640000)
+    assert shard_bounds(3, 8)[-1] == 3
