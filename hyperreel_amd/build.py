@@ -20,6 +20,8 @@ HEADERS = ['hr_kernels.h', 'hr_math.h', os.path.join('..', '..', 'include', 'hyp
 # places where fusion is wanted use __builtin_fmaf explicitly.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-math-errno', '-Wall', '-Wno-unused-function']
+if os.environ.get('HR_FAST_MATH', '1') != '0':
+    FLAGS.append('-DHR_FAST_MATH')   # 1-ulp rcp/sqrt/exp in the per-sample arithmetic (hr_math.h)
 
 
 def hipcc():

@@ -406,6 +406,7 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.basis = m->basis;
     a.n_basis_cols = m->n_basis_cols;
     a.ca_total = m->ca_total;
+    a.dbg_mode = 0;
 }
 
 static int check_render(const hr_model* m, const float* rays, int64_t n, const float* rgb)
@@ -425,7 +426,9 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     const hr_config& c = m->cfg;
     const int Z = c.z_channels;
     // (Running the sample stage of chunk i on a second stream under the MLP of chunk i+1 was
-    //  measured and is slower than back-to-back launches: 3.04 vs 2.79 ms per 800x800 frame.)
+    //  measured twice -- plain, and with the MLP limited to one workgroup per CU so that sample
+    //  blocks could co-reside -- and is slower than back-to-back launches: 3.0-3.9 vs 2.79 ms per
+    //  800x800 frame; the two kernels do not interleave on the CUs.)
     for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
         const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
         const float* rays = rays_dev + r0 * c.ray_dim;

@@ -67,6 +67,7 @@ struct HrSampleArgs {
     const float* basis;     // (app_dim, n_basis_cols) row-major, torch layout
     int n_basis_cols;       // sum of the real appearance channels of the sampled planes
     int ca_total;           // padded appearance slots (multiple of 4) = sum 4*ca4
+    int dbg_mode;           // profiling only (HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 
 void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);

@@ -19,15 +19,34 @@
 #define HR_FN static inline
 #endif
 
+// Division, square root and exp.  On the device (HR_FAST_MATH) these map to the 1-ulp
+// hardware approximations v_rcp_f32 / v_sqrt_f32 / v_exp_f32 instead of the ~10-instruction
+// correctly-rounded expansions: a relative difference of ~1e-7, far inside the 1e-4 RGB bar.
+#if defined(__HIPCC__) && defined(HR_FAST_MATH)
+#define HR_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define HR_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define HR_EXP(x) __expf(x)
+HR_FN float hr_tanh(float x)
+{
+    const float e = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+#else
+#define HR_DIV(a, b) ((a) / (b))
+#define HR_SQRT(x) sqrtf(x)
+#define HR_EXP(x) expf(x)
+HR_FN float hr_tanh(float x) { return tanhf(x); }
+#endif
+
 // ---------------------------------------------------------------- activations
 // y = act(x*inner + shift)*outer   (nlf/activations.py:53-69,121-137,163-178)
 HR_FN float hr_apply_act(const hr_act& a, float x)
 {
     float y = x * a.inner + a.shift;
     if (a.type == HR_ACT_SIGMOID) {
-        y = 1.0f / (1.0f + expf(-y));
+        y = HR_DIV(1.0f, 1.0f + HR_EXP(-y));
     } else if (a.type == HR_ACT_TANH) {
-        y = tanhf(y);
+        y = hr_tanh(y);
     }
     return y * a.outer;
 }
@@ -37,7 +56,7 @@ HR_FN float hr_apply_act(const hr_act& a, float x)
 HR_FN float hr_axis_plane_t(float val, float o, float d)
 {
     float dd = (fabsf(d) < 1e-5f) ? 1e12f : d;
-    return (val - o) / dd;
+    return HR_DIV(val - o, dd);
 }
 
 // nlf/param.py:244-253 (pluecker), :87-115 (two_plane), :20-24 (identity) followed by
@@ -56,9 +75,9 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
             float oy = ray[pg.start + 1] - pg.origin[1];
             float oz = ray[pg.start + 2] - pg.origin[2];
             float dx = ray[pg.start + 3], dy = ray[pg.start + 4], dz = ray[pg.start + 5];
-            float nrm = sqrtf(dx * dx + dy * dy + dz * dz);      // F.normalize(p=2, eps=1e-12)
+            float nrm = HR_SQRT(dx * dx + dy * dy + dz * dz);    // F.normalize(p=2, eps=1e-12)
             nrm = fmaxf(nrm, 1e-12f);
-            dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
+            dx = HR_DIV(dx, nrm); dy = HR_DIV(dy, nrm); dz = HR_DIV(dz, nrm);
             float mx = oy * dz - oz * dy;                          // torch.cross(o, d)
             float my = oz * dx - ox * dz;
             float mz = ox * dy - oy * dx;
@@ -122,27 +141,27 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
 // inverse_contract_distance, contract.py:143-158 (identity distance_activation)
 HR_FN float hr_inverse_contract_distance(const hr_config& c, float distance)
 {
-    distance = (distance / 2.0f) * 2.0f;
+    distance = (distance * 0.5f) * 2.0f;             // x/2*2, exact either way
     distance = fminf(fmaxf(distance, -2.0f), 2.0f);
     float t = 2.0f - fabsf(distance);
-    float inv = t / c.c_d_scale + c.c_d_inv_end;
+    float inv = HR_DIV(t, c.c_d_scale) + c.c_d_inv_end;
     float sgn = (distance > 0.0f) ? 1.0f : ((distance < 0.0f) ? -1.0f : 0.0f);
-    float r = (fabsf(distance) < 1.0f) ? distance : sgn * (1.0f / inv);
+    float r = (fabsf(distance) < 1.0f) ? distance : sgn * HR_DIV(1.0f, inv);
     return r * c.c_d0;
 }
 
 // contract_points, contract.py:178-192
 HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, float* q)
 {
-    px = px / c.c_r0; py = py / c.c_r0; pz = pz / c.c_r0;
-    float dist = sqrtf(px * px + py * py + pz * pz);
+    px = HR_DIV(px, c.c_r0); py = HR_DIV(py, c.c_r0); pz = HR_DIV(pz, c.c_r0);
+    float dist = HR_SQRT(px * px + py * py + pz * pz);
     if (dist < 1.0f) {
         q[0] = px; q[1] = py; q[2] = pz;
     } else {
-        float inv = 1.0f / fabsf(dist);
+        float inv = HR_DIV(1.0f, fabsf(dist));
         float t = (inv - c.c_r_inv_end) * c.c_r_scale;
         float s = 2.0f - t;
-        q[0] = (px / dist) * s; q[1] = (py / dist) * s; q[2] = (pz / dist) * s;
+        q[0] = HR_DIV(px, dist) * s; q[1] = HR_DIV(py, dist) * s; q[2] = HR_DIV(pz, dist) * s;
     }
 }
 
@@ -155,9 +174,9 @@ HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius)
     float cc = oo - radius * radius;
     float disc = b * b - 4.0f * a * cc;
     disc = (disc < 0.0f) ? 0.0f : disc;
-    float sq = sqrtf(disc + 1e-8f);
-    float t1 = (-b + sq) / (2.0f * a);
-    float t2 = (-b - sq) / (2.0f * a);
+    float sq = HR_SQRT(disc + 1e-8f);
+    float t1 = HR_DIV(-b + sq, 2.0f * a);
+    float t2 = HR_DIV(-b - sq, 2.0f * a);
     t1 = (disc <= 0.0f) ? 0.0f : t1;
     t2 = (disc <= 0.0f) ? 0.0f : t2;
     return ((t2 < 0.0f) || (radius < 0.0f)) ? t1 : t2;
@@ -230,7 +249,7 @@ HR_FN void hr_sample_point(const hr_config& c, const float* hk, float dist_sorte
         float q[3];
         hr_contract_point(c, px, py, pz, q);
         float ex = q[0] - oc[0], ey = q[1] - oc[1], ez = q[2] - oc[2];
-        dist = sqrtf(ex * ex + ey * ey + ez * ez);                   // contract.py:43-50
+        dist = HR_SQRT(ex * ex + ey * ey + ez * ez);                 // contract.py:43-50
         px = q[0]; py = q[1]; pz = q[2];
     }
     dist = zero ? 0.0f : dist;                                       // base.py:246
@@ -282,7 +301,7 @@ HR_FN float hr_density(const hr_config& c, float f)
     if (c.density_act == HR_DENSITY_RELU) return fmaxf(f, 0.0f);
     if (c.density_act == HR_DENSITY_RELU_ABS) return fabsf(f);
     float z = f + c.density_shift;                                   // F.softplus, threshold 20
-    return (z > 20.0f) ? z : log1pf(expf(z));
+    return (z > 20.0f) ? z : log1pf(HR_EXP(z));
 }
 
 // eval_sh_bases(2, d) (utils/sh_utils.py:94-119)

@@ -21,6 +21,8 @@
 //     reference's two);
 //   * the SH / RGB decode matrix is folded with the ray's SH basis once per ray into LDS
 //     (3 x C_app), so the per-sample decode is 3*C_app FMAs regardless of SH degree.
+#include <cstdlib>
+
 #include "hr_kernels.h"
 #include "hr_math.h"
 
@@ -66,6 +68,60 @@ __device__ __forceinline__ float4 hr_lerp4(const float4 v0, const float4 v1, flo
     return r;
 }
 
+// All channel groups of one plane pair for a sample at normalised coordinates pn: bilinear
+// plane tap x (line | time-plane) tap, density partial sum and appearance decode.
+// (Measured alternatives, both slower than this plain loop at 5 waves/SIMD: a 4-lanes-per-sample
+//  gather with LDS hand-over, 1.66 vs 1.27 ms per frame; compile-time unrolled batches of 12-16
+//  loads in flight at 4 waves/SIMD, 1.37 ms.  The gather sits at ~1.1 vector-L1 accesses per
+//  clock per CU, i.e. it is bound by the tag-lookup rate for scattered 16-byte reads.)
+__device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const float (&pn)[4], const float* M, int CA,
+                                                float& sig_feat, float& pre0, float& pre1, float& pre2)
+{
+    const int ng = g.cd4 + g.ca4;
+    const int cd = g.cd4;
+    if (ng == 0) return;
+    const int tex = ng * 4;
+    const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
+    const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
+    const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
+    const hr_axis_tap tx = hr_make_tap(gx, g.aw);
+    const hr_axis_tap ty = hr_make_tap(gy, g.ah);
+    // ATen: nw = (x1-ix)(y1-iy), ne = (ix-x0)(y1-iy), sw = (x1-ix)(iy-y0), se = (ix-x0)(iy-y0)
+    const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+    const float* a00 = g.a + (ty.i0 * g.aw + tx.i0) * tex;
+    const float* a01 = g.a + (ty.i0 * g.aw + tx.i1) * tex;
+    const float* a10 = g.a + (ty.i1 * g.aw + tx.i0) * tex;
+    const float* a11 = g.a + (ty.i1 * g.aw + tx.i1) * tex;
+    const bool line = (g.bw == 1);
+    // line: grid x == 0 on a width-1 image puts weight exactly 1 on column 0 -> 2 taps along the axis;
+    // time plane: x = spatial coordinate, y = keyframe time -> 4 taps
+    const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
+    const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
+    const float* b00 = line ? (g.b + bxp.i0 * tex) : (g.b + (byp.i0 * g.bw + bxp.i0) * tex);
+    const float* b01 = line ? (g.b + bxp.i1 * tex) : (g.b + (byp.i0 * g.bw + bxp.i1) * tex);
+    const float* b10 = g.b + (byp.i1 * g.bw + bxp.i0) * tex;
+    const float* b11 = g.b + (byp.i1 * g.bw + bxp.i1) * tex;
+    const float v00 = bxp.w0 * byp.w0, v01 = bxp.w1 * byp.w0, v10 = bxp.w0 * byp.w1, v11 = bxp.w1 * byp.w1;
+    auto ld = [](const float* p, int q) { return *reinterpret_cast<const float4*>(p + 4 * q); };
+    for (int q = 0; q < ng; ++q) {
+        const float4 pa = hr_bilerp4(ld(a00, q), ld(a01, q), ld(a10, q), ld(a11, q), w00, w01, w10, w11);
+        const float4 pb = line ? hr_lerp4(ld(b00, q), ld(b01, q), bxp.w0, bxp.w1)
+                               : hr_bilerp4(ld(b00, q), ld(b01, q), ld(b10, q), ld(b11, q), v00, v01, v10, v11);
+        const float fx = pa.x * pb.x, fy = pa.y * pb.y, fz = pa.z * pb.z, fw = pa.w * pb.w;
+        if (q < cd) {
+            sig_feat = sig_feat + fx; sig_feat = sig_feat + fy; sig_feat = sig_feat + fz; sig_feat = sig_feat + fw;
+        } else {
+            const int ch = g.app_off + 4 * (q - cd);
+            const float4 m0 = *reinterpret_cast<const float4*>(M + ch);
+            const float4 m1 = *reinterpret_cast<const float4*>(M + CA + ch);
+            const float4 m2 = *reinterpret_cast<const float4*>(M + 2 * CA + ch);
+            pre0 = HR_FMA(m0.w, fw, HR_FMA(m0.z, fz, HR_FMA(m0.y, fy, HR_FMA(m0.x, fx, pre0))));
+            pre1 = HR_FMA(m1.w, fw, HR_FMA(m1.z, fz, HR_FMA(m1.y, fy, HR_FMA(m1.x, fx, pre1))));
+            pre2 = HR_FMA(m2.w, fw, HR_FMA(m2.z, fz, HR_FMA(m2.y, fy, HR_FMA(m2.x, fx, pre2))));
+        }
+    }
+}
+
 template <int ZP>
 __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
 {
@@ -81,7 +137,15 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     const int tid = threadIdx.x;
     const int rib = tid / ZP;
     const int k = tid % ZP;
-    const int64_t ray_base = (int64_t)blockIdx.x * RPB;
+    // XCD-aware block order: the dispatcher places block b on XCD b % 8, so consecutive
+    // blocks (neighbouring rays, overlapping texel footprints) would land on 8 different L2s.
+    // Give each XCD a contiguous range of the ray list instead (bijective for any grid size).
+    unsigned bid = blockIdx.x;
+    if (a.dbg_mode != 2) {
+        const unsigned nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int64_t ray_base = (int64_t)bid * RPB;
     const int64_t ray = ray_base + rib;
     const bool ray_ok = ray < a.n_rays;
     const bool lane_ok = ray_ok && (k < Z);
@@ -163,7 +227,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     const float delta = (k == Z - 1) ? 1e10f : (dist_next - dist_c);
 
     // ---- feature gather
-    const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c);
+    const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c) && (a.dbg_mode != 1);
     float sig_feat = 0.0f;
     float pre0 = 0.0f, pre1 = 0.0f, pre2 = 0.0f;
     if (valid) {
@@ -174,85 +238,12 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
         pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
         const float* M = s_M + rib * 3 * CA;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const HrGridPlane& g = a.planes[j];
-            const int ng = g.cd4 + g.ca4;
-            if (ng == 0) continue;
-            const int tex = ng * 4;
-            const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
-            const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
-            const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
-            const hr_axis_tap tx = hr_make_tap(gx, g.aw);
-            const hr_axis_tap ty = hr_make_tap(gy, g.ah);
-            // ATen: nw = (x1-ix)(y1-iy), ne = (ix-x0)(y1-iy), sw = (x1-ix)(iy-y0), se = (ix-x0)(iy-y0)
-            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-            const float* a00 = g.a + (ty.i0 * g.aw + tx.i0) * tex;
-            const float* a01 = g.a + (ty.i0 * g.aw + tx.i1) * tex;
-            const float* a10 = g.a + (ty.i1 * g.aw + tx.i0) * tex;
-            const float* a11 = g.a + (ty.i1 * g.aw + tx.i1) * tex;
-            if (g.bw == 1) {
-                // vector (line) factor: grid x == 0 on a width-1 image -> weight exactly 1 on column 0
-                const hr_axis_tap tl = hr_make_tap(gb, g.bh);
-                const float* b0 = g.b + tl.i0 * tex;
-                const float* b1 = g.b + tl.i1 * tex;
-                for (int q = 0; q < ng; ++q) {
-                    const float4 pa = hr_bilerp4(*reinterpret_cast<const float4*>(a00 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a01 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a10 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a11 + 4 * q), w00, w01, w10, w11);
-                    const float4 pb = hr_lerp4(*reinterpret_cast<const float4*>(b0 + 4 * q),
-                                               *reinterpret_cast<const float4*>(b1 + 4 * q), tl.w0, tl.w1);
-                    const float fx = pa.x * pb.x, fy = pa.y * pb.y, fz = pa.z * pb.z, fw = pa.w * pb.w;
-                    if (q < g.cd4) {
-                        sig_feat = sig_feat + fx; sig_feat = sig_feat + fy; sig_feat = sig_feat + fz; sig_feat = sig_feat + fw;
-                    } else {
-                        const int ch = g.app_off + 4 * (q - g.cd4);
-                        const float4 m0 = *reinterpret_cast<const float4*>(M + ch);
-                        const float4 m1 = *reinterpret_cast<const float4*>(M + CA + ch);
-                        const float4 m2 = *reinterpret_cast<const float4*>(M + 2 * CA + ch);
-                        pre0 = HR_FMA(m0.w, fw, HR_FMA(m0.z, fz, HR_FMA(m0.y, fy, HR_FMA(m0.x, fx, pre0))));
-                        pre1 = HR_FMA(m1.w, fw, HR_FMA(m1.z, fz, HR_FMA(m1.y, fy, HR_FMA(m1.x, fx, pre1))));
-                        pre2 = HR_FMA(m2.w, fw, HR_FMA(m2.z, fz, HR_FMA(m2.y, fy, HR_FMA(m2.x, fx, pre2))));
-                    }
-                }
-            } else {
-                // (axis, time) plane of the keyframe volume: x = spatial coordinate, y = keyframe time
-                const hr_axis_tap bxp = hr_make_tap(gb, g.bw);
-                const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
-                const float v00 = bxp.w0 * byp.w0, v01 = bxp.w1 * byp.w0, v10 = bxp.w0 * byp.w1, v11 = bxp.w1 * byp.w1;
-                const float* b00 = g.b + (byp.i0 * g.bw + bxp.i0) * tex;
-                const float* b01 = g.b + (byp.i0 * g.bw + bxp.i1) * tex;
-                const float* b10 = g.b + (byp.i1 * g.bw + bxp.i0) * tex;
-                const float* b11 = g.b + (byp.i1 * g.bw + bxp.i1) * tex;
-                for (int q = 0; q < ng; ++q) {
-                    const float4 pa = hr_bilerp4(*reinterpret_cast<const float4*>(a00 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a01 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a10 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(a11 + 4 * q), w00, w01, w10, w11);
-                    const float4 pb = hr_bilerp4(*reinterpret_cast<const float4*>(b00 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(b01 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(b10 + 4 * q),
-                                                 *reinterpret_cast<const float4*>(b11 + 4 * q), v00, v01, v10, v11);
-                    const float fx = pa.x * pb.x, fy = pa.y * pb.y, fz = pa.z * pb.z, fw = pa.w * pb.w;
-                    if (q < g.cd4) {
-                        sig_feat = sig_feat + fx; sig_feat = sig_feat + fy; sig_feat = sig_feat + fz; sig_feat = sig_feat + fw;
-                    } else {
-                        const int ch = g.app_off + 4 * (q - g.cd4);
-                        const float4 m0 = *reinterpret_cast<const float4*>(M + ch);
-                        const float4 m1 = *reinterpret_cast<const float4*>(M + CA + ch);
-                        const float4 m2 = *reinterpret_cast<const float4*>(M + 2 * CA + ch);
-                        pre0 = HR_FMA(m0.w, fw, HR_FMA(m0.z, fz, HR_FMA(m0.y, fy, HR_FMA(m0.x, fx, pre0))));
-                        pre1 = HR_FMA(m1.w, fw, HR_FMA(m1.z, fz, HR_FMA(m1.y, fy, HR_FMA(m1.x, fx, pre1))));
-                        pre2 = HR_FMA(m2.w, fw, HR_FMA(m2.z, fz, HR_FMA(m2.y, fy, HR_FMA(m2.x, fx, pre2))));
-                    }
-                }
-            }
-        }
+        for (int j = 0; j < 3; ++j) hr_gather_plane(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
     }
 
     // ---- density -> alpha -> transmittance -> weight (raw2alpha, tensorf_utils.py:242-253)
     const float sigma = valid ? hr_density(cfg, sig_feat) : 0.0f;
-    const float alpha = lane_ok ? (1.0f - expf(-sigma * (delta * cfg.distance_scale))) : 0.0f;
+    const float alpha = lane_ok ? (1.0f - HR_EXP(-sigma * (delta * cfg.distance_scale))) : 0.0f;
     float inc = lane_ok ? ((1.0f - alpha) + 1e-10f) : 1.0f;
 #pragma unroll
     for (int d = 1; d < ZP; d <<= 1) {
@@ -271,7 +262,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
             if (cfg.shading == HR_SHADING_SH) {    // SHRender, tensorf_utils.py:334-338
                 r0 = fmaxf(pre0 + 0.5f, 0.0f); r1 = fmaxf(pre1 + 0.5f, 0.0f); r2 = fmaxf(pre2 + 0.5f, 0.0f);
             } else {                               // RGBRender, tensorf_utils.py:341-343
-                r0 = 1.0f / (1.0f + expf(-pre0)); r1 = 1.0f / (1.0f + expf(-pre1)); r2 = 1.0f / (1.0f + expf(-pre2));
+                r0 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre0)); r1 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre1)); r2 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre2));
             }
         }
         if (cfg.f_color_scale.offset >= 0) {       // scale_shift_color_all, tensorf_utils.py:267-273
@@ -330,11 +321,14 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     const int RPB = 256 / ZP;
     const unsigned blocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
     const size_t lds = hr_sample_lds_bytes(args.nq, args.ca_total, ZP);
+    static const int dbg = [] { const char* e = getenv("HR_SAMPLE_DBG"); return e ? atoi(e) : 0; }();
+    HrSampleArgs args2 = args;
+    args2.dbg_mode = dbg;
     switch (ZP) {
-        case 8: hipLaunchKernelGGL(hr_sample_kernel<8>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
-        case 16: hipLaunchKernelGGL(hr_sample_kernel<16>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
-        case 32: hipLaunchKernelGGL(hr_sample_kernel<32>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
-        case 64: hipLaunchKernelGGL(hr_sample_kernel<64>, dim3(blocks), dim3(256), lds, stream, cfg, args); break;
+        case 8: hipLaunchKernelGGL(hr_sample_kernel<8>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
+        case 16: hipLaunchKernelGGL(hr_sample_kernel<16>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
+        case 32: hipLaunchKernelGGL(hr_sample_kernel<32>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
+        case 64: hipLaunchKernelGGL(hr_sample_kernel<64>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
         default: break;  // Z > 64 is rejected by hr_model_create
     }
 }
