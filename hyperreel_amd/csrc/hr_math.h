@@ -26,6 +26,7 @@
 #define HR_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #define HR_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define HR_EXP(x) __expf(x)
+#define HR_SINCOS(x, s, c) do { *(s) = __sinf(x); *(c) = __cosf(x); } while (0)   // v_sin/v_cos, |err| ~ 1e-6
 HR_FN float hr_tanh(float x)
 {
     const float e = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
@@ -35,6 +36,7 @@ HR_FN float hr_tanh(float x)
 #define HR_DIV(a, b) ((a) / (b))
 #define HR_SQRT(x) sqrtf(x)
 #define HR_EXP(x) expf(x)
+#define HR_SINCOS(x, s, c) sincosf((x), (s), (c))
 HR_FN float hr_tanh(float x) { return tanhf(x); }
 #endif
 
@@ -116,7 +118,7 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
                 float bf = pg.pe_base_mult * f;
                 for (int i = 0; i < nx; ++i) {                     // [sin(all i), cos(all i)] per frequency
                     float sv, cv;
-                    sincosf(bf * HR_X(i), &sv, &cv);
+                    HR_SINCOS(bf * HR_X(i), &sv, &cv);
                     out[n_out + i] = sv;
                     out[n_out + nx + i] = cv;
                 }
