@@ -87,8 +87,8 @@ def cpu_baseline(cfg, ds, sd, rays, n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--model', default='donerf_sphere')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=800)

@@ -70,6 +70,9 @@ __device__ __forceinline__ void hr_load_x(HrXOps<MT>& o, const __bf16* __restric
 template <int MT>
 __device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][MT], const HrWOps& w, const HrXOps<MT>& x)
 {
+    // raised issue priority for the MFMA burst: the co-resident workgroup's epilogue/prologue
+    // VALU work then fills the gaps instead of delaying the matrix pipe (measured: 1.483 -> 1.395 ms)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -85,6 +88,7 @@ __device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][MT], const HrWOps& w
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[nt], x.h[mt], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // acc += W[:, segment] * X[segment]^T over NKT (multiple of 4, compile-time) 16-wide k-steps.

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for opts in sys.argv[1:]:
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5', '--cpu-sample', '0'] + opts.split()
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '100', '--warmup', '20', '--cpu-sample', '0'] + opts.split()
     p = subprocess.run(cmd, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith('{')]
     if not line:
