@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -41,7 +42,10 @@ struct DevBuf {
 }  // namespace
 
 struct hr_model {
-    hr_config cfg;
+    hr_config cfg;        // as handed over by the caller
+    hr_config kcfg;       // what the kernels see: dead head columns removed (preds_per_z, field offsets)
+    HrColMap col_map;     // user column -> live column (-1: never read by the path, not computed)
+    int p_live = 0;
     bool finalized = false;
     std::map<std::string, DevBuf> raw;     // uploaded tensors, reference layout, device memory
     std::map<std::string, size_t> expect;  // name -> expected byte size
@@ -107,6 +111,55 @@ int validate(const hr_config& c)
     return HR_OK;
 }
 
+// Which of the P per-sample head columns does the path read?  Columns that are not read are
+// dropped from the last Linear (fewer MFMAs, smaller head).  Shipped cases: the three sphere /
+// cylinder origin channels when origin_scale_factor == 0 (primitive.py:410-412 multiplies them
+// by zero) and `point_sigma` in models whose point_offset stage reads `sigma` instead.
+void analyse_live_columns(hr_model* m)
+{
+    const hr_config& c = m->cfg;
+    bool live[64] = {};
+    auto mark = [&](const hr_head_field& f, int first, int count) {
+        if (f.offset < 0) return;
+        for (int i = first; i < first + count && f.offset + i < 64; ++i) live[f.offset + i] = true;
+    };
+    if (c.isect_type == HR_ISECT_Z_PLANE) {
+        mark(c.f_z_vals, 0, 1);
+    } else {
+        mark(c.f_z_vals, 3, 1);
+        if (c.origin_scale != 0.0f) mark(c.f_z_vals, 0, 3);
+    }
+    mark(c.f_isect_sigma, 0, 1);
+    if (c.point_offset) {
+        mark(c.f_point_offset, 0, 3);
+        mark(c.f_offset_sigma, 0, 1);
+    }
+    mark(c.f_color_scale, 0, 3);
+    mark(c.f_color_shift, 0, 3);
+    if (c.advect && c.use_spatial_flow) mark(c.f_spatial_flow, 0, 3);
+    const char* e = getenv("HR_PRUNE");
+    const bool prune = !(e && e[0] == '0');
+    int n = 0;
+    for (int i = 0; i < 64; ++i) {
+        const bool keep = (i < c.preds_per_z) && (live[i] || !prune);
+        m->col_map.col[i] = keep ? n++ : -1;
+    }
+    m->p_live = n;
+    m->kcfg = c;
+    m->kcfg.preds_per_z = n;
+    auto remap = [&](hr_head_field& f, int anchor) {   // anchor: a channel of the field that is always live
+        if (f.offset < 0) return;
+        f.offset = m->col_map.col[f.offset + anchor] - anchor;
+    };
+    remap(m->kcfg.f_z_vals, c.isect_type == HR_ISECT_Z_PLANE ? 0 : 3);   // may become negative: only channel 3 is read then
+    remap(m->kcfg.f_isect_sigma, 0);
+    if (c.point_offset) { remap(m->kcfg.f_point_offset, 0); remap(m->kcfg.f_offset_sigma, 0); }
+    else { m->kcfg.f_point_offset.offset = -1; m->kcfg.f_offset_sigma.offset = -1; }
+    remap(m->kcfg.f_color_scale, 0);
+    remap(m->kcfg.f_color_shift, 0);
+    if (c.advect && c.use_spatial_flow) remap(m->kcfg.f_spatial_flow, 0); else m->kcfg.f_spatial_flow.offset = -1;
+}
+
 void free_dev(float*& p)
 {
     if (p) (void)hipFree(p);
@@ -151,6 +204,7 @@ int hr_model_create(const hr_config* cfg, hr_model** out)
     if (ndev < 1) return fail(HR_E_HIP, "no HIP device");
     hr_model* m = new hr_model();
     m->cfg = *cfg;
+    analyse_live_columns(m);
     const hr_config& c = m->cfg;
     char name[64];
     for (int l = 0; l < c.mlp_layers; ++l) {
@@ -214,16 +268,22 @@ int hr_model_finalize(hr_model* m)
     // ---- MLP: MFMA B-operand tiles (layout documented in hr_kernels.h)
     const int W = c.mlp_hidden;
     m->k0p = (c.mlp_in + 15) & ~15;
-    m->n_out = c.z_channels * c.preds_per_z;
+    m->n_out = c.z_channels * m->p_live;
+    const int P_user = c.preds_per_z, P_live = m->p_live;
+    int live_cols[64];
+    for (int i = 0, j = 0; i < P_user; ++i)
+        if (m->col_map.col[i] >= 0) live_cols[j++] = i;
     for (int l = 0; l < c.mlp_layers; ++l) {
-        const int N = layer_out(c, l), Kt = layer_in(c, l);
+        const bool last = (l == c.mlp_layers - 1);
+        const int N_user = layer_out(c, l), Kt = layer_in(c, l);
+        const int N = last ? m->n_out : N_user;   // rows the kernels compute
         const bool first = (l == 0);
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
         const bool split = (c.mlp_precision == HR_MLP_BF16X3);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
-        std::vector<float> w((size_t)N * Kt), b(N);
+        std::vector<float> w((size_t)N_user * Kt), b(N_user);
         snprintf(name, sizeof(name), "mlp.%d.weight", l);
         HR_HIP(hipMemcpy(w.data(), m->raw[name].p, w.size() * sizeof(float), hipMemcpyDeviceToHost));
         snprintf(name, sizeof(name), "mlp.%d.bias", l);
@@ -239,7 +299,10 @@ int hr_model_finalize(hr_model* m)
             } else {
                 col = kk;
             }
-            return (n < N && col >= 0 && col < Kt) ? w[(size_t)n * Kt + col] : 0.0f;
+            if (!(n < N && col >= 0 && col < Kt)) return 0.0f;
+            // last layer: kernel row n = k*P_live + c' is the user's row k*P + live_cols[c']
+            const int row = last ? (n / P_live) * P_user + live_cols[n % P_live] : n;
+            return w[(size_t)row * Kt + col];
         };
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
@@ -274,7 +337,7 @@ int hr_model_finalize(hr_model* m)
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
-        for (int i = 0; i < N; ++i) bp[i] = b[i];
+        for (int i = 0; i < N; ++i) bp[i] = b[last ? (i / P_live) * P_user + live_cols[i % P_live] : i];
         HR_HIP(hipMalloc((void**)&m->bias[l], nb * sizeof(float)));
         HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         m->n_tiles[l] = nt;
@@ -364,7 +427,7 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     if (rays_per_chunk == m->chunk && m->head) return HR_OK;
     free_dev(m->head);
     m->chunk = 0;
-    const size_t nq = ((size_t)m->cfg.z_channels * m->cfg.preds_per_z + 3) / 4;
+    const size_t nq = ((size_t)m->cfg.z_channels * m->p_live + 3) / 4;
     const size_t bytes = sizeof(float) * (size_t)rays_per_chunk * nq * 4;   // HQ layout, rays_per_chunk is a multiple of 64
     HR_HIP(hipMalloc((void**)&m->head, bytes));
     m->chunk = rays_per_chunk;
@@ -434,7 +497,7 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
         const float* rays = rays_dev + r0 * c.ray_dim;
         HrMlpArgs ma;
         fill_mlp_args(m, ma, rays, n);
-        launch_mlp(c, ma, st);
+        launch_mlp(m->kcfg, ma, st);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
         if (fields) {
@@ -442,9 +505,11 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
             if (fields->points_dev) sa.fields.points_dev = fields->points_dev + r0 * Z * 3;
             if (fields->sigma_dev) sa.fields.sigma_dev = fields->sigma_dev + r0 * Z;
             if (fields->weights_dev) sa.fields.weights_dev = fields->weights_dev + r0 * Z;
-            if (fields->head_dev) hr_launch_head_export(m->head, fields->head_dev + r0 * m->n_out, n, m->n_out, (m->n_out + 3) / 4, st);
+            if (fields->head_dev)
+                hr_launch_head_export(m->head, fields->head_dev + r0 * (int64_t)Z * c.preds_per_z, n, Z, c.preds_per_z, m->p_live,
+                                      (m->n_out + 3) / 4, m->col_map, st);
         }
-        hr_launch_samples(c, sa, st);
+        hr_launch_samples(m->kcfg, sa, st);
     }
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -462,7 +527,7 @@ int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* strea
     if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays_dev, n_rays);
-    launch_mlp(m->cfg, ma, (hipStream_t)stream);
+    launch_mlp(m->kcfg, ma, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -474,7 +539,7 @@ int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
     HrSampleArgs sa;
     fill_sample_args(m, sa, rays_dev, n_rays, rgb_dev);
-    hr_launch_samples(m->cfg, sa, (hipStream_t)stream);
+    hr_launch_samples(m->kcfg, sa, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -487,7 +552,7 @@ int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsig
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays_dev, n_rays);
     ma.trace = trace_dev;
-    launch_mlp(m->cfg, ma, (hipStream_t)stream);
+    launch_mlp(m->kcfg, ma, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -497,7 +562,7 @@ int64_t hr_model_device_bytes(const hr_model* m)
     if (!m) return 0;
     int64_t raw = 0;
     for (auto& kv : m->raw) raw += (int64_t)kv.second.bytes;
-    return raw + m->packed_bytes + (int64_t)sizeof(float) * m->chunk * m->cfg.z_channels * m->cfg.preds_per_z;
+    return raw + m->packed_bytes + (int64_t)sizeof(float) * m->chunk * m->cfg.z_channels * m->p_live;
 }
 
 void hr_model_destroy(hr_model* m)

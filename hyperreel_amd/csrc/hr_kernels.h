@@ -78,8 +78,14 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
 
 // layout kernels (pack_kernels.hip)
 // dst[y][x][c_off + c] = src[c][y][x] for c < C  (dst texel stride = tex floats)
-// out[r * n_out + n] = head[hr_head_index(r, n, nq)]  (diagnostics export of the raw head)
-void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int n_out, int nq, hipStream_t stream);
+// Per-sample head columns the path actually reads (hr_model_finalize drops the others from the
+// last Linear): col[c] = position of user column c among the live ones, or -1.
+struct HrColMap {
+    int col[64];
+};
+// diagnostics export of the raw head in the user's (n, Z*P) layout; pruned columns read as 0
+void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, const HrColMap& map,
+                           hipStream_t stream);
 void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 
 #endif

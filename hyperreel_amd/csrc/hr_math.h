@@ -200,13 +200,20 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
         if (c.contract_samples) z = hr_inverse_contract_distance(c, z);
         dist = hr_axis_plane_t(z, ro[2], rd[2]);                     // z.py:88-95
     } else {
-        float zz[4];
-        for (int i = 0; i < 4; ++i)
-            zz[i] = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + i])) * one_m;
-        float sx = zz[0] * c.origin_scale + c.origin_initial[0];     // primitive.py:410-412
-        float sy = zz[1] * c.origin_scale + c.origin_initial[1];
-        float sz = zz[2] * c.origin_scale + c.origin_initial[2];
-        float radius = zz[3] * c.z_scale + c.samples[k];
+        // origins = z[:3] * origin_scale_factor + origin_initial (primitive.py:410-412).  With the
+        // shipped origin_scale_factor of 0 the three channels are multiplied by zero; they are then
+        // not read at all (and hr_model_finalize drops those columns from the last Linear).
+        float sx = c.origin_initial[0], sy = c.origin_initial[1], sz = c.origin_initial[2];
+        if (c.origin_scale != 0.0f) {
+            const float z0 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 0])) * one_m;
+            const float z1 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 1])) * one_m;
+            const float z2 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 2])) * one_m;
+            sx = z0 * c.origin_scale + c.origin_initial[0];
+            sy = z1 * c.origin_scale + c.origin_initial[1];
+            sz = z2 * c.origin_scale + c.origin_initial[2];
+        }
+        const float z3 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 3])) * one_m;
+        float radius = z3 * c.z_scale + c.samples[k];
         if (c.contract_samples) radius = hr_inverse_contract_distance(c, radius);
         float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
         float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;

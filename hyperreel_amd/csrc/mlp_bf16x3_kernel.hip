@@ -34,19 +34,21 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+template <int NT>
 struct HrWOps {
-    bf16x8 h[2], l[2];   // weights (A operand), hi/lo halves of 2 n-tiles
+    bf16x8 h[NT], l[NT];   // weights (A operand), hi/lo halves of NT n-tiles
 };
 template <int MT>
 struct HrXOps {
     bf16x8 h[MT], l[MT];   // activations (B operand), hi/lo halves of MT m-tiles
 };
 
-__device__ __forceinline__ void hr_load_w(HrWOps& o, const bf16x8* __restrict__ wp, int wkt, int tiles_total,
-                                          const int (&tile)[2], int lane)
+template <int NT>
+__device__ __forceinline__ void hr_load_w(HrWOps<NT>& o, const bf16x8* __restrict__ wp, int wkt, int tiles_total,
+                                          const int (&tile)[NT], int lane)
 {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const size_t base = (((size_t)wkt * tiles_total + tile[nt]) * 2) * 64 + lane;
         o.h[nt] = wp[base];
         o.l[nt] = wp[base + 64];
@@ -67,24 +69,24 @@ __device__ __forceinline__ void hr_load_x(HrXOps<MT>& o, const __bf16* __restric
 
 // 6*MT MFMAs of one k-step; products are the outer loop so that consecutive MFMAs write
 // different accumulators (no back-to-back dependent issue)
-template <int MT>
-__device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][MT], const HrWOps& w, const HrXOps<MT>& x)
+template <int NT, int MT>
+__device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[NT][MT], const HrWOps<NT>& w, const HrXOps<MT>& x)
 {
     // raised issue priority for the MFMA burst: the co-resident workgroup's epilogue/prologue
     // VALU work then fills the gaps instead of delaying the matrix pipe (measured: 1.483 -> 1.395 ms)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l[nt], x.h[mt], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[nt], x.l[mt], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[nt], x.h[mt], acc[nt][mt], 0, 0, 0);
@@ -94,54 +96,54 @@ __device__ __forceinline__ void hr_mfma3(floatx16 (&acc)[2][MT], const HrWOps& w
 // acc += W[:, segment] * X[segment]^T over NKT (multiple of 4, compile-time) 16-wide k-steps.
 // Weights come from L2 (several hundred cycles): a 4-slot register ring keeps them 3 k-steps
 // ahead of their use; activations come from LDS and run one step ahead.
-template <int NKT, int MT>
-__device__ __forceinline__ void hr_accumulate3_pipe(floatx16 (&acc)[2][MT], const __bf16* xh, const __bf16* xl, int stride,
-                                                    const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[2], int lane)
+template <int NKT, int NT, int MT>
+__device__ __forceinline__ void hr_accumulate3_pipe(floatx16 (&acc)[NT][MT], const __bf16* xh, const __bf16* xl, int stride,
+                                                    const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[NT], int lane)
 {
     static_assert(NKT % 4 == 0 && NKT >= 4, "k-steps must come in fours");
-    HrWOps w0, w1, w2, w3;
+    HrWOps<NT> w0, w1, w2, w3;
     HrXOps<MT> x0, x1;
-    hr_load_w(w0, wp, kt0, tiles_total, tile, lane);
-    hr_load_w(w1, wp, kt0 + 1, tiles_total, tile, lane);
-    hr_load_w(w2, wp, kt0 + 2, tiles_total, tile, lane);
+    hr_load_w<NT>(w0, wp, kt0, tiles_total, tile, lane);
+    hr_load_w<NT>(w1, wp, kt0 + 1, tiles_total, tile, lane);
+    hr_load_w<NT>(w2, wp, kt0 + 2, tiles_total, tile, lane);
     hr_load_x<MT>(x0, xh, xl, stride, 0, lane);
 #pragma unroll 1
     for (int kt = 0; kt < NKT - 4; kt += 4) {
-        hr_load_w(w3, wp, kt0 + kt + 3, tiles_total, tile, lane);
+        hr_load_w<NT>(w3, wp, kt0 + kt + 3, tiles_total, tile, lane);
         hr_load_x<MT>(x1, xh, xl, stride, kt + 1, lane);
-        hr_mfma3<MT>(acc, w0, x0);
-        hr_load_w(w0, wp, kt0 + kt + 4, tiles_total, tile, lane);
+        hr_mfma3<NT, MT>(acc, w0, x0);
+        hr_load_w<NT>(w0, wp, kt0 + kt + 4, tiles_total, tile, lane);
         hr_load_x<MT>(x0, xh, xl, stride, kt + 2, lane);
-        hr_mfma3<MT>(acc, w1, x1);
-        hr_load_w(w1, wp, kt0 + kt + 5, tiles_total, tile, lane);
+        hr_mfma3<NT, MT>(acc, w1, x1);
+        hr_load_w<NT>(w1, wp, kt0 + kt + 5, tiles_total, tile, lane);
         hr_load_x<MT>(x1, xh, xl, stride, kt + 3, lane);
-        hr_mfma3<MT>(acc, w2, x0);
-        hr_load_w(w2, wp, kt0 + kt + 6, tiles_total, tile, lane);
+        hr_mfma3<NT, MT>(acc, w2, x0);
+        hr_load_w<NT>(w2, wp, kt0 + kt + 6, tiles_total, tile, lane);
         hr_load_x<MT>(x0, xh, xl, stride, kt + 4, lane);
-        hr_mfma3<MT>(acc, w3, x1);
+        hr_mfma3<NT, MT>(acc, w3, x1);
     }
     // last four k-steps: nothing left to prefetch beyond NKT-1
-    hr_load_w(w3, wp, kt0 + NKT - 1, tiles_total, tile, lane);
+    hr_load_w<NT>(w3, wp, kt0 + NKT - 1, tiles_total, tile, lane);
     hr_load_x<MT>(x1, xh, xl, stride, NKT - 3, lane);
-    hr_mfma3<MT>(acc, w0, x0);
+    hr_mfma3<NT, MT>(acc, w0, x0);
     hr_load_x<MT>(x0, xh, xl, stride, NKT - 2, lane);
-    hr_mfma3<MT>(acc, w1, x1);
+    hr_mfma3<NT, MT>(acc, w1, x1);
     hr_load_x<MT>(x1, xh, xl, stride, NKT - 1, lane);
-    hr_mfma3<MT>(acc, w2, x0);
-    hr_mfma3<MT>(acc, w3, x1);
+    hr_mfma3<NT, MT>(acc, w2, x0);
+    hr_mfma3<NT, MT>(acc, w3, x1);
 }
 
 // Input segment (k0p/16 = 1..4 k-steps): short, no ring.
-template <int MT>
-__device__ __forceinline__ void hr_accumulate3(floatx16 (&acc)[2][MT], const __bf16* xh, const __bf16* xl, int stride, int nkt,
-                                               const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[2], int lane)
+template <int NT, int MT>
+__device__ __forceinline__ void hr_accumulate3(floatx16 (&acc)[NT][MT], const __bf16* xh, const __bf16* xl, int stride, int nkt,
+                                               const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[NT], int lane)
 {
     for (int kt = 0; kt < nkt; ++kt) {
-        HrWOps w;
+        HrWOps<NT> w;
         HrXOps<MT> x;
-        hr_load_w(w, wp, kt0 + kt, tiles_total, tile, lane);
+        hr_load_w<NT>(w, wp, kt0 + kt, tiles_total, tile, lane);
         hr_load_x<MT>(x, xh, xl, stride, kt, lane);
-        hr_mfma3<MT>(acc, w, x);
+        hr_mfma3<NT, MT>(acc, w, x);
     }
 }
 
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
             const int tile[2] = {wave * (2 * NTW) + 2 * p, wave * (2 * NTW) + 2 * p + 1};
             int kt0 = 0;
             if (l == 0 || skip) {
-                hr_accumulate3<MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
+                hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
                 kt0 = k0p / 16;
             }
-            if (l > 0) hr_accumulate3_pipe<W / 16, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+            if (l > 0) hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
             HR_STAMP();                          // 2+3l: GEMM of layer l issued
             if (p == NTW - 1) __syncthreads();   // all waves have finished reading Xh/Xl (NTW == 1 for W = 256)
             HR_STAMP();                          // 3+3l: barrier passed
@@ -253,15 +255,40 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
         HR_STAMP();                              // 4+3l: epilogue + barrier done
     }
 
-    // ---- last Linear: N = Z*P features in passes of 4 waves x 2 tiles of 32
+    // ---- last Linear: N = Z*P_live features.  Full passes of 4 waves x 2 tiles of 32 features; a
+    //      remainder of up to 4 tiles runs as one tile per wave so that the waves stay balanced
+    //      (11 tiles for DoNeRF after dead-column pruning: 8 + 3).
     {
         const int l = L - 1;
         const bool skip = (cfg.mlp_skip_mask >> l) & 1;
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wsplit[l]);
         const int tiles_total = a.n_tiles[l];
         const float* bias = a.bias[l];
+        auto store_tile = [&](int tile_n, const floatx16 (&acc)[MT]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = tile_n * 32 + 8 * g + 4 * (lane >> 5);
+                if (n0 >= a.n_out) continue;
+                const float4 b = *reinterpret_cast<const float4*>(bias + n0);   // bias is padded to the tile
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int64_t row = ray0 + mt * 32 + (lane & 31);
+                    if (row >= a.n_rays) continue;
+                    float4 v;
+                    v.x = acc[mt][4 * g + 0] + b.x;
+                    v.y = acc[mt][4 * g + 1] + b.y;
+                    v.z = acc[mt][4 * g + 2] + b.z;
+                    v.w = acc[mt][4 * g + 3] + b.w;
+                    // HQ layout: the 32 lanes of a half-wave write 512 contiguous bytes.  (Plain stores on
+                    // purpose: non-temporal ones shave 4 % off this kernel but evict the head from the caches
+                    // the sample kernel then reads it through: 2.90 vs 2.73 ms per frame end to end.)
+                    *reinterpret_cast<float4*>(a.head + hr_head_index(row, n0, a.nq)) = v;
+                }
+            }
+        };
+        int t0 = 0;
 #pragma unroll 1
-        for (int t0 = 0; t0 < tiles_total; t0 += 8) {
+        for (; tiles_total - t0 > 4; t0 += 8) {                        // two tiles per wave
             const int tile[2] = {t0 + wave * 2, t0 + wave * 2 + 1};
             if (tile[0] >= tiles_total) continue;                       // wave-uniform
             const int tile_ld[2] = {tile[0], min(tile[1], tiles_total - 1)};
@@ -274,37 +301,31 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
                     for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
             int kt0 = 0;
             if (skip) {
-                hr_accumulate3<MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
+                hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
                 kt0 = k0p / 16;
             }
-            hr_accumulate3_pipe<W / 16, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
+            hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
             HR_STAMP();                          // last layer: GEMM of this pass issued
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (tile[nt] >= tiles_total) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n0 = tile[nt] * 32 + 8 * g + 4 * (lane >> 5);
-                    if (n0 >= a.n_out) continue;
-                    const float4 b = *reinterpret_cast<const float4*>(bias + n0);   // bias is padded to the tile
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int64_t row = ray0 + mt * 32 + (lane & 31);
-                        if (row >= a.n_rays) continue;
-                        float4 v;
-                        v.x = acc[nt][mt][4 * g + 0] + b.x;
-                        v.y = acc[nt][mt][4 * g + 1] + b.y;
-                        v.z = acc[nt][mt][4 * g + 2] + b.z;
-                        v.w = acc[nt][mt][4 * g + 3] + b.w;
-                        // HQ layout: the 32 lanes of a half-wave write 512 contiguous bytes
-                        // HQ layout: the 32 lanes of a half-wave write 512 contiguous bytes.  (Plain stores on
-                        // purpose: non-temporal ones shave 4 % off this kernel but evict the head from the caches
-                        // the sample kernel then reads it through: 2.90 vs 2.73 ms per frame end to end.)
-                        *reinterpret_cast<float4*>(a.head + hr_head_index(row, n0, a.nq)) = v;
-                    }
-                }
-            }
+            store_tile(tile[0], acc[0]);
+            if (tile[1] < tiles_total) store_tile(tile[1], acc[1]);
             HR_STAMP();                          // last layer: stores of this pass issued
+        }
+        if (t0 + wave < tiles_total) {                                  // remainder: one tile per wave
+            const int tile[1] = {t0 + wave};
+            floatx16 acc[1][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.0f;
+            int kt0 = 0;
+            if (skip) {
+                hr_accumulate3<1, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
+                kt0 = k0p / 16;
+            }
+            hr_accumulate3_pipe<W / 16, 1, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+            HR_STAMP();
+            store_tile(tile[0], acc[0]);
+            HR_STAMP();
         }
     }
 #undef HR_STAMP

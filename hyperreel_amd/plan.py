@@ -439,6 +439,33 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     return hc
 
 
+def live_head_columns(hc):
+    """Per-sample head columns the path reads (mirror of analyse_live_columns in csrc/api.hip).
+    The library drops the others from the last Linear; `hr_render_fields` reports them as 0."""
+    live = [False] * hc.preds_per_z
+
+    def mark(f, first, count):
+        if f.offset >= 0:
+            for i in range(first, first + count):
+                live[f.offset + i] = True
+
+    if hc.isect_type == ISECT['z_plane']:
+        mark(hc.f_z_vals, 0, 1)
+    else:
+        mark(hc.f_z_vals, 3, 1)
+        if hc.origin_scale != 0.0:
+            mark(hc.f_z_vals, 0, 3)
+    mark(hc.f_isect_sigma, 0, 1)
+    if hc.point_offset:
+        mark(hc.f_point_offset, 0, 3)
+        mark(hc.f_offset_sigma, 0, 1)
+    mark(hc.f_color_scale, 0, 3)
+    mark(hc.f_color_shift, 0, 3)
+    if hc.advect and hc.use_spatial_flow:
+        mark(hc.f_spatial_flow, 0, 3)
+    return live
+
+
 def upload_names(hc):
     """[(ABI tensor name, reference state_dict key suffix)] for hr_model_upload."""
     names = []
