@@ -17,8 +17,8 @@ The JSON line also carries
   roofline      the dominant kernel of the step, timed live with HIP events on the launch
                 stream, against the MI355X peak of the unit that bounds it;
   roofline_other  the other kernel, same treatment;
-  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on the
-                host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  cpu_baseline  the CPU port of the reference's algorithm (oracle/torch_port.py, PyTorch CPU ops on
+                all host cores) timed on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -71,15 +71,19 @@ def time_stage(fn, reps):
 
 
 def cpu_baseline(cfg, ds, sd, rays, n_sample):
-    """The numpy oracle on a bounded random sample of the same frame (checker code used
-    here only as the reported CPU baseline, never on the measured path)."""
+    """The torch-op CPU port of the reference's algorithm (oracle/torch_port.py: the same ATen
+    kernels the reference runs on a CPU -- grid_sample, cumprod, sort, addmm -- on all host
+    cores) on a bounded sample of the same frame.  Checker code, used here only as the reported
+    CPU baseline; never on the measured path."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    from hyperreel_oracle import HyperReelOracle
-    idx = np.random.default_rng(0).choice(rays.shape[0], n_sample, replace=False)
-    orc = HyperReelOracle(cfg, ds, sd)
-    orc.render(rays[idx[:256]])
+    from torch_port import TorchPort
+    n_sample = min(n_sample, rays.shape[0])
+    idx = np.arange(rays.shape[0]) if n_sample == rays.shape[0] else \
+        np.sort(np.random.default_rng(0).choice(rays.shape[0], n_sample, replace=False))
+    port = TorchPort(cfg, ds, sd)
+    port.render(rays[idx[:16384]])
     t0 = time.perf_counter()
-    out = orc.render(rays[idx], chunk=16384)
+    out = port.render(rays[idx], chunk=16384)
     dt = time.perf_counter() - t0
     return n_sample / dt, dt, idx, out['rgb']
 
@@ -93,7 +97,7 @@ def main():
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=800)
     ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
-    ap.add_argument('--cpu-sample', type=int, default=65536, help='rays of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'fp32'],
                     help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
@@ -219,6 +223,18 @@ def main():
                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
                  'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video)} B/ray x {min(chunk, B)} rays'}
+        # HBM-side traffic per launch: measured separately with rocprofv3 --pmc (never inside a timed
+        # run) and committed under profiles/; attached only when the workload matches the profiled one
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+            w = tr['workload']
+            if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
+                    and (w['mlp_precision'] == 'bf16x3') == split):
+                r_mlp['traffic'] = tr[r_mlp['kernel']]['traffic_bytes'] if r_mlp['kernel'] in tr else None
+                r_smp['traffic'] = tr['hr_sample_kernel']['traffic_bytes']
+                r_mlp['traffic_unit'] = r_smp['traffic_unit'] = 'bytes per launch (profiles/r01_traffic.json)'
+        except (OSError, KeyError, ValueError):
+            pass
         dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
         result['roofline'] = dom
         result['roofline_other'] = oth
@@ -228,9 +244,9 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd, rays_np, min(args.cpu_sample, B))
         got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
-        result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': 1, 'kind': 'port',
-                                  'sample': f'{len(idx)} random rays of the same frame through oracle/hyperreel_oracle.py '
-                                            f'(numpy fp32, single process) in {secs:.1f} s'}
+        result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                  'sample': f'{len(idx)} rays of the same frame through oracle/torch_port.py (the reference\'s '
+                                            f'algorithm on PyTorch CPU ops, fp32, chunk 16384) in {secs:.1f} s'}
         result['parity_vs_oracle_linf'] = float(np.abs(got - ref_rgb).max())
 
     result['mlp_gemm'] = ('bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)'

@@ -1,0 +1,204 @@
+"""CPU port of the reference hot path in PyTorch CPU ops (multi-threaded ATen kernels).
+
+TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT (same rules as hyperreel_oracle.py: only
+tests/ and bench.py's `cpu_baseline` leg may import it).
+
+Why a second restatement: the numpy oracle is the parity checker (straight-line, easy to
+audit) but single-threaded; the CPU baseline next to the device number should run the way the
+reference itself runs on a CPU -- `F.grid_sample`, `torch.cumprod`, `torch.sort`, `addmm` on all
+host cores.  This file restates the same path with exactly those ops, following the same
+reference lines as the numpy oracle (see its header for the file:line list); it reuses the
+oracle's setup-time constants (anchors, contraction constants, head layout) and replaces only
+the per-ray arithmetic.  `tests/test_oracle_golden.py` pins it against the reference goldens too.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from hyperreel_oracle import C0, C1, C2, HyperReelOracle
+
+
+def _act(a, x):
+    y = x * float(a.inner) + float(a.shift)
+    if a.type == 'sigmoid':
+        y = torch.sigmoid(y)
+    elif a.type == 'tanh':
+        y = torch.tanh(y)
+    return y * float(a.outer)
+
+
+class TorchPort:
+    def __init__(self, cfg, dataset, sd):
+        self.o = HyperReelOracle(cfg, dataset, sd)          # setup-time constants only
+        o = self.o
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        self.layers = [(t(w), t(b)) for w, b in o.layers]
+        self.samples = t(o.samples)
+        self.aabb = t(o.aabb)
+        self.inv_size = t(o.inv_size)
+        self.basis = t(o.basis)
+        if o.video:
+            self.d_a, self.d_b = [t(p)[None] for p in o.d_space], [t(p)[None] for p in o.d_time]
+            self.a_a, self.a_b = [t(p)[None] for p in o.a_space], [t(p)[None] for p in o.a_time]
+        else:
+            self.d_a, self.d_b = [t(p)[None] for p in o.d_plane], [t(p)[None] for p in o.d_line]
+            self.a_a, self.a_b = [t(p)[None] for p in o.a_plane], [t(p)[None] for p in o.a_line]
+
+    # ---- embedding ----------------------------------------------------------------------
+    def _mlp(self, x):                                      # nlf/nets/mlp.py:159-172
+        o = self.o
+        inp = x
+        for i, (w, b) in enumerate(self.layers):
+            if i in o.skips:
+                x = torch.cat([inp, x], -1)
+            x = F.linear(x, w, b)
+            if i < o.D + 1:
+                x = F.leaky_relu(x, 0.01)
+        return x
+
+    def _contract_points(self, p):                          # nlf/contract.py:178-192
+        c = self.o.contract
+        p = p / c.r0
+        d = torch.norm(p, dim=-1, keepdim=True)
+        inv_end = c.r0 / c.r1
+        t = (1.0 / d.abs() - inv_end) * (1.0 / (1.0 - inv_end))
+        return torch.where(d < 1, p, (p / d) * (2.0 - t))
+
+    def _inv_contract_distance(self, z):                    # nlf/contract.py:143-158
+        c = self.o.contract
+        inv_end = c.d0 / c.d1
+        z = (z / 2.0) * 2.0
+        z = z.clamp(-2.0, 2.0)
+        inv = (2.0 - z.abs()) / (1.0 / (1.0 - inv_end)) + inv_end
+        return torch.where(z.abs() < 1, z, torch.sign(z) * (1.0 / inv)) * c.d0
+
+    def embed(self, rays):
+        o = self.o
+        B, Z = rays.shape[0], o.Z
+        x = {}
+        h = self._mlp(torch.from_numpy(o._param_pe(rays.numpy())))     # PE is per-ray and tiny: reuse
+        h = h.view(B, Z, -1)
+        off = 0
+        for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
+            x[name] = _act(act, h[..., off:off + n])
+            off += n
+        r = torch.cat([rays[:, :3] - torch.from_numpy(o.origin)[None], rays[:, 3:6]], -1)
+        sigma = x[o.in_density_field].reshape(B, -1) if (o.use_sigma and o.in_density_field in x) else torch.zeros(B, Z)
+        zv = _act(o.z_act, x['z_vals'].reshape(B, Z, -1)) * (1 - sigma[..., None])
+
+        def proc(z):                                        # intersect/base.py:128-140
+            z = z * float(o.z_scale) + self.samples[None]
+            return self._inv_contract_distance(z) if o.contract.contract_samples else z
+
+        if o.isect_type == 'z_plane':                       # z.py:77-97, intersect_utils.py:127-150
+            z = proc(zv.reshape(B, Z))
+            d = r[:, None, 3:6]
+            d = torch.where(d.abs() < 1e-5, torch.full_like(d, 1e12), d)
+            dists = (z - r[:, None, 2]) / d[..., 2]
+        else:                                               # primitive.py:420-438 / 235-253
+            origins = zv[..., :3] * float(o.origin_scale) + torch.from_numpy(o.origin_initial)[None, None]
+            radii = proc(zv[..., 3])
+            oo, dd = r[:, None, 0:3] * origins, r[:, None, 3:6] * origins
+            if o.isect_type == 'cylinder':
+                oo, dd = oo[..., [0, 2]], dd[..., [0, 2]]
+            a = (dd * dd).sum(-1)
+            b = 2 * (oo * dd).sum(-1)
+            c = (oo * oo).sum(-1) - radii * radii
+            disc = b * b - 4 * a * c
+            disc = torch.where(disc < 0, torch.zeros_like(disc), disc)
+            sq = torch.sqrt(disc + 1e-8)
+            t1, t2 = (-b + sq) / (2 * a), (-b - sq) / (2 * a)
+            t1 = torch.where(disc <= 0, torch.zeros_like(t1), t1)
+            t2 = torch.where(disc <= 0, torch.zeros_like(t2), t2)
+            dists = torch.where((t2 < 0) | (radii < 0), t1, t2)
+        mask = (dists <= float(o.near)) | (dists >= float(o.far))
+        dists = torch.where(mask, torch.zeros_like(dists), dists)
+        if o.sort:
+            dists = torch.sort(dists, dim=1)[0]
+        dists = dists[..., None]
+        mask = dists == 0
+        points = r[:, None, :3] + r[:, None, 3:6] * dists
+        if hasattr(o.contract, 'r0'):                       # contract.py:43-50
+            oc = self._contract_points(r[:, :3])
+            points = self._contract_points(points)
+            dists = torch.norm(points - oc[:, None], dim=-1, keepdim=True)
+        dists = torch.where(mask, torch.zeros_like(dists), dists)
+        x['points'], x['distances'] = points, dists
+        for idx, typ, ecfg in o.stages:
+            if typ == 'advect_points':                      # point.py:780-831, flow_utils.py:10-35
+                t = rays[:, -1:]
+                K, Fr = o.ds['num_keyframes'], o.ds['num_frames']
+                fac = K * (Fr - 1) / Fr
+                base = torch.round((t * fac).clamp(0.0, K - 1.0) - 1e-5) * (1.0 / fac)
+                if ecfg.get('use_spatial_flow', False):
+                    from hyperreel_oracle import Act
+                    x['points'] = x['points'] + _act(Act(ecfg.get('spatial_flow_activation')), x['spatial_flow']) * (t - base)[:, None, :]
+                x['base_times'] = base[:, None, :].expand(B, Z, 1)
+            elif typ == 'point_offset':                     # point.py:371-396
+                from hyperreel_oracle import Act
+                fld = ecfg.get('in_density_field', 'sigma')
+                sg = x[fld] if (ecfg.get('use_sigma', True) and fld in x) else torch.zeros(B, Z, 1)
+                x['points'] = x['points'] + _act(Act(ecfg.get('activation')), x['point_offset']) * (1 - sg)
+        x['viewdirs'] = rays[:, None, 3:6].expand(B, Z, 3)
+        return x
+
+    # ---- colour -------------------------------------------------------------------------
+    def _feat(self, planes_a, planes_b, pn):                # tensorf_no_sample.py:47-126, tensorf_dynamic.py:287-371
+        o = self.o
+        out = []
+        N = pn.shape[0]
+        for i in range(3):
+            if o.video and self.d_a[i].shape[1] == 0:
+                continue
+            ga = pn[:, o.MAT[i]].view(1, N, 1, 2)
+            pa = F.grid_sample(planes_a[i], ga, align_corners=True).view(-1, N)
+            if o.video:
+                gb = pn[:, o.MAT_T[i]].view(1, N, 1, 2)
+            else:
+                gb = torch.stack([torch.zeros(N), pn[:, o.VEC[i]]], -1).view(1, N, 1, 2)
+            pb = F.grid_sample(planes_b[i], gb, align_corners=True).view(-1, N)
+            out.append(pa * pb)
+        return torch.cat(out, 0)
+
+    def color(self, x):
+        o = self.o
+        pts = x['points']
+        B, Z = pts.shape[:2]
+        dist = x['distances'].reshape(B, Z)
+        deltas = torch.cat([dist[:, 1:] - dist[:, :-1], torch.full((B, 1), 1e10)], 1)
+        valid = ~(((self.aabb[0] > pts) | (pts > self.aabb[1])).any(-1)) & (dist > 0)
+        pn = (pts - self.aabb[0]) * self.inv_size - 1
+        if o.video:
+            pn = torch.cat([pn, (x['base_times'] * o.tsf + o.tpo) * 2 - 1], -1)
+        sigma = torch.zeros(B, Z)
+        if valid.any():
+            f = self._feat(self.d_a, self.d_b, pn[valid]).sum(0)
+            sigma[valid] = F.relu(f) if o.act == 'relu' else (f.abs() if o.act == 'relu_abs' else F.softplus(f + float(o.density_shift)))
+        alpha = 1.0 - torch.exp(-sigma * (deltas * float(o.distance_scale)))
+        T = torch.cumprod(torch.cat([torch.ones(B, 1), 1.0 - alpha + 1e-10], -1), -1)
+        weight = alpha * T[:, :-1]
+        app = weight > float(o.thr)
+        rgb = torch.zeros(B, Z, 3)
+        if app.any():
+            feat = F.linear(self._feat(self.a_a, self.a_b, pn[app]).T, self.basis)
+            if o.shading == 'RGB':
+                col = torch.sigmoid(feat)
+            else:
+                d = x['viewdirs'][app]
+                xx, yy, zz = d[:, 0], d[:, 1], d[:, 2]
+                sh = torch.stack([torch.full_like(xx, C0), -C1 * yy, C1 * zz, -C1 * xx, C2[0] * xx * yy, C2[1] * yy * zz,
+                                  C2[2] * (2.0 * zz * zz - xx * xx - yy * yy), C2[3] * xx * zz, C2[4] * (xx * xx - yy * yy)], -1)
+                col = torch.relu((sh[:, None] * feat.view(-1, 3, 9)).sum(-1) + 0.5)
+            rgb[app] = col
+        if 'color_scale' in x:
+            rgb = rgb * (x['color_scale'] + 1.0) + x['color_shift']
+        out = (weight[..., None] * rgb).sum(-2)
+        if o.white_bg:
+            out = out + (1.0 - weight.sum(-1)[:, None])
+        return out.clamp(0, 1)
+
+    @torch.no_grad()
+    def render(self, rays, chunk=16384):
+        rays = torch.from_numpy(np.ascontiguousarray(rays, np.float32))
+        outs = [self.color(self.embed(rays[i:i + chunk])) for i in range(0, rays.shape[0], chunk)]
+        return {'rgb': torch.cat(outs, 0).numpy()}

@@ -33,3 +33,12 @@ def test_golden_rgb_is_not_degenerate():
         g = Golden.__new__(Golden)
         z = np.load(__import__('os').path.join(__import__('helpers').GOLDEN_DIR, case + '.npz'))
         assert z['rgb'].std() > 0.02 and np.isfinite(z['rgb']).all()
+
+
+@pytest.mark.parametrize('case', golden_cases())
+def test_torch_port_matches_reference_golden(case):
+    """The multi-threaded torch-op port used as bench.py's CPU baseline computes the same image."""
+    from torch_port import TorchPort
+    g = Golden(case)
+    out = TorchPort(g.cfg, g.dataset, g.state_dict).render(g.rays)
+    assert linf(out['rgb'], g.rgb) <= 2e-5
