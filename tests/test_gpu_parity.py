@@ -231,3 +231,112 @@ def test_full_frame_800x800_properties(precision):
     assert err.max() <= RGB_TOL, f'L-inf {err.max():.3e}, {(err > RGB_TOL).sum()} of 4096 over'
     psnr = -10.0 * np.log10(np.mean((got - ref) ** 2) + 1e-20)
     assert psnr > 90.0
+
+
+def _variant(name, edit, Z=None):
+    cfg = C.model_config(name, z_channels=Z)
+    edit(cfg)
+    return cfg
+
+
+def _emb(cfg):
+    return cfg.embedding.embeddings
+
+
+VARIANTS = {
+    # Z that is not a power of two: lanes beyond Z idle, sort pads with +inf
+    'z24_sphere': lambda: _variant('donerf_sphere', lambda c: None, Z=24),
+    'z7_zplane': lambda: _variant('technicolor_z_plane', lambda c: None, Z=7),
+    # sphere origins actually driven by the network (origin_scale_factor != 0): no column pruning
+    'sphere_origin_scale': lambda: _variant('donerf_sphere', lambda c: _emb(c).ray_intersect_0.intersect.update(origin_scale_factor=0.05)),
+    # hidden width 128: exact fp32-MFMA kernel (the split kernel needs 256)
+    'hidden128': lambda: _variant('donerf_cylinder', lambda c: _emb(c).ray_prediction_0.net.update(hidden_channels=128)),
+    # two skip layers, deeper net
+    'skips_2_4_depth8': lambda: _variant('donerf_sphere', lambda c: _emb(c).ray_prediction_0.net.update(depth=8, skips=[2, 4])),
+    # BasicPE with 3 frequencies on Pluecker coordinates
+    'basic_pe': lambda: _variant('donerf_sphere', lambda c: _emb(c).ray_prediction_0.params.ray.update(
+        pe=C.to_cfg({'type': 'basic', 'n_freqs': 2, 'freq_multiplier': 2.0}))),
+    # no contraction at all on a sphere scene, explicit near/far and anchors
+    'sphere_no_contract': lambda: _variant('donerf_sphere', lambda c: (
+        _emb(c).ray_intersect_0.intersect.pop('contract'),
+        _emb(c).ray_intersect_0.intersect.update(use_dataset_bounds=False, initial=0.3, end=2.5, near=0.1, far=2.4))),
+    # white background + softplus density + SH shading on the static net
+    'static_sh_softplus_white': lambda: _variant('donerf_sphere', lambda c: c.color.net.update(
+        white_bg=1, fea2denseAct='softplus', density_shift=-1.0, shadingMode='SH', data_dim_color=27)),
+    # RGB shading on the keyframe net, unsorted samples, weight threshold > 0
+    'video_rgb_unsorted_thr': lambda: _variant('immersive_sphere', lambda c: (
+        c.color.net.update(shadingMode='RGB', data_dim_color=3, rm_weight_mask_thre=1e-3),
+        _emb(c).ray_intersect_0.intersect.update(sort=False))),
+    # channel counts that are not multiples of four and differ between density and appearance
+    'odd_channels': lambda: _variant('donerf_sphere', lambda c: c.color.net.update(n_lamb_sigma=[6, 3, 5], n_lamb_sh=[10, 2, 7])),
+    'video_odd_channels': lambda: _variant('neural_3d_z_plane', lambda c: c.color.net.update(n_lamb_sigma=[5, 0, 3], n_lamb_sh=[9, 0, 2]), Z=16),
+}
+
+
+@pytest.mark.parametrize('variant', sorted(VARIANTS))
+def test_config_variants_match_oracle(variant):
+    """Options of the supported path that the five shipped families do not exercise."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    cfg = VARIANTS[variant]()
+    base = 'immersive' if 'video_rgb' in variant else ('neural_3d' if 'video_odd' in variant else
+                                                        ('technicolor' if 'zplane' in variant else 'donerf'))
+    ds = C.dataset_scalars(base)
+    grid = [33, 27, 30]
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=321, density='dense', app_scale=1.0)
+    video = cfg.color.net.type == 'tensor_vm_split_time'
+    zp = cfg.embedding.embeddings.ray_intersect_0.intersect.type == 'z_plane'
+    rays = scenes.random_rays(515, 6, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5) if zp \
+        else scenes.random_rays(515, 6, video)
+    fn = make_render_fn(cfg, ds, sd)
+    out = render_np(fn, rays, want=('distances', 'render_weights'))
+    ref = HyperReelOracle(cfg, ds, sd).render(rays, keep='all')
+    Z = ref['distances'].shape[1]
+    d_ref = ref['distances'].reshape(-1, Z)
+    assert float(np.max(np.abs(out['distances'] - d_ref) / (1 + np.abs(d_ref)))) <= 2e-5
+    assert linf(out['render_weights'], ref['render_weights']) <= 5e-5
+    assert linf(out['rgb'], ref['rgb']) <= RGB_TOL
+    assert ref['rgb'].std() > 0.01
+
+
+def test_all_samples_masked_and_degenerate_rays(fns):
+    """Rays whose every sample is masked (outside the box / behind near) must give the reference's
+    value: colour_shift-weighted zero, i.e. exactly what the oracle returns."""
+    from gpu_common import render_np
+    g, fn = fns('donerf_sphere_small')
+    orc = _oracle(g)
+    rays = np.asarray([[50.0, 50.0, 50.0, 0.57735027, 0.57735027, 0.57735027],
+                       [0.0, 0.0, 0.0, 1.0, 0.0, 0.0],
+                       [1.999, 1.999, 1.999, 0.0, 0.0, 1.0],
+                       [0.0, 0.0, 0.0, 1e-6, 1e-6, 1.0]], np.float32)
+    out = render_np(fn, rays, want=('render_weights',))
+    ref = orc.render(rays, keep='all')
+    assert linf(out['rgb'], ref['rgb']) <= RGB_TOL
+    assert linf(out['render_weights'], ref['render_weights']) <= 5e-5
+
+
+def test_hipgraph_capture_and_replay(fns):
+    """Render calls only enqueue kernels on the caller's stream (no allocation, no sync inside the
+    library), so a frame can be captured once and replayed -- the viewer path of BASELINE config 5."""
+    g, fn = fns('immersive_sphere_small')
+    rays = torch.from_numpy(np.concatenate([g.rays] * 4, 0)).cuda()
+    ref = fn(rays)['rgb'].clone()
+    fn.model.native()
+    static_rays = rays.clone()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn(static_rays)            # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(graph):
+        static_out = fn(static_rays)['rgb']
+    static_out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref)
+    # new rays through the same captured graph
+    static_rays.copy_(torch.flip(rays, dims=[0]))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, torch.flip(ref, dims=[0]))
