@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--torch-gpu', action='store_true', help='also time the PyTorch-ROCm port of the reference algorithm on this GPU')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'fp32'],
                     help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -265,6 +266,30 @@ def main():
 
     result['mlp_gemm'] = ('bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)'
                           if model._hc.mlp_precision == 1 else 'fp32 MFMA')
+    # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same
+    #      algorithm as stock PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda';
+    #      the reference itself cannot travel to the GPU box).  Reported, never part of `value`.
+    if rank == 0 and world == 1 and args.torch_gpu:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        from torch_port import TorchPort
+        tp = TorchPort(cfg, ds, sd, device='cuda')
+        best = None
+        for ck in (16384, 1048576):          # the reference's shipped ray_chunk and its demo setting
+            tp.render(rays, chunk=ck)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                out_t = tp.render(rays, chunk=ck)['rgb']
+            torch.cuda.synchronize()
+            r = 3 * B / (time.perf_counter() - t1) / 1e6
+            if best is None or r > best[0]:
+                best = (r, ck)
+        result['pytorch_gpu_baseline'] = {
+            'value': round(best[0], 3), 'unit': 'Mrays/s', 'chunk': best[1], 'kind': 'port',
+            'what': 'the reference algorithm as stock PyTorch-ROCm ops (grid_sample, addmm, sort, cumprod) on the same MI355X',
+            'speedup_of_value': round(value / best[0], 1),
+            'linf_vs_hip': float((out_t - rgb).abs().max())}
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -28,10 +28,11 @@ def _act(a, x):
 
 
 class TorchPort:
-    def __init__(self, cfg, dataset, sd):
+    def __init__(self, cfg, dataset, sd, device='cpu'):
         self.o = HyperReelOracle(cfg, dataset, sd)          # setup-time constants only
         o = self.o
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        self.dev = torch.device(device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.layers = [(t(w), t(b)) for w, b in o.layers]
         self.samples = t(o.samples)
         self.aabb = t(o.aabb)
@@ -72,18 +73,53 @@ class TorchPort:
         inv = (2.0 - z.abs()) / (1.0 / (1.0 - inv_end)) + inv_end
         return torch.where(z.abs() < 1, z, torch.sign(z) * (1.0 / inv)) * c.d0
 
+    def _param_pe(self, rays):                              # nlf/param.py:87-115,244-253; nlf/pe.py:210-221,53-66
+        cols = []
+        for pcfg in self.o.pred_cfg['params'].values():
+            x = rays[:, pcfg['start']:pcfg['end']]
+            p = pcfg['param']
+            if p['fn'] == 'pluecker':
+                org = torch.tensor(p.get('origin', [0.0, 0.0, 0.0]), device=self.dev)
+                d = F.normalize(x[:, 3:6], p=2.0, dim=-1)
+                m = torch.cross(x[:, :3] - org[None], d, dim=-1)
+                y = torch.cat([d * p.get('direction_multiplier', 1.0), m * p.get('moment_multiplier', 1.0)], -1)
+            elif p['fn'] == 'two_plane':
+                org = torch.tensor(p.get('origin', [0.0, 0.0, 0.0]), device=self.dev)
+                oo, dd = x[:, :3] - org[None], x[:, 3:6]
+                dz = torch.where(dd.abs() < 1e-5, torch.full_like(dd, 1e12), dd)[:, 2]
+                t1 = (p.get('near', -1.0) - oo[:, 2]) / dz
+                t2 = (p.get('far', 0.0) - oo[:, 2]) / dz
+                y = torch.cat([oo[:, :2] + dd[:, :2] * t1[:, None], oo[:, :2] + dd[:, :2] * t2[:, None]], -1)
+            else:
+                y = x
+            pe = pcfg.get('pe')
+            if pe is not None and pe['n_freqs'] > 0:
+                n = int(pe['n_freqs'])
+                freqs = [float(pe.get('freq_multiplier', 2.0)) ** (j + 1) for j in range(n)]
+                if pe['type'] == 'windowed':
+                    bm = float(pe.get('base_multiplier', 1.0))
+                    out = [] if pe.get('exclude_identity', False) else [y]
+                    for f in freqs:
+                        out += [torch.sin(bm * f * y), torch.cos(bm * f * y)]
+                else:
+                    cur = (torch.tensor(freqs, device=self.dev)[None, None] * y[..., None]).reshape(y.shape[0], -1)
+                    out = [y, torch.sin(cur), torch.cos(cur)]
+                y = torch.cat(out, -1)
+            cols.append(y)
+        return torch.cat(cols, -1)
+
     def embed(self, rays):
         o = self.o
         B, Z = rays.shape[0], o.Z
         x = {}
-        h = self._mlp(torch.from_numpy(o._param_pe(rays.numpy())))     # PE is per-ray and tiny: reuse
+        h = self._mlp(self._param_pe(rays))
         h = h.view(B, Z, -1)
         off = 0
         for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
             x[name] = _act(act, h[..., off:off + n])
             off += n
-        r = torch.cat([rays[:, :3] - torch.from_numpy(o.origin)[None], rays[:, 3:6]], -1)
-        sigma = x[o.in_density_field].reshape(B, -1) if (o.use_sigma and o.in_density_field in x) else torch.zeros(B, Z)
+        r = torch.cat([rays[:, :3] - torch.from_numpy(o.origin).to(self.dev)[None], rays[:, 3:6]], -1)
+        sigma = x[o.in_density_field].reshape(B, -1) if (o.use_sigma and o.in_density_field in x) else torch.zeros(B, Z, device=self.dev)
         zv = _act(o.z_act, x['z_vals'].reshape(B, Z, -1)) * (1 - sigma[..., None])
 
         def proc(z):                                        # intersect/base.py:128-140
@@ -96,7 +132,7 @@ class TorchPort:
             d = torch.where(d.abs() < 1e-5, torch.full_like(d, 1e12), d)
             dists = (z - r[:, None, 2]) / d[..., 2]
         else:                                               # primitive.py:420-438 / 235-253
-            origins = zv[..., :3] * float(o.origin_scale) + torch.from_numpy(o.origin_initial)[None, None]
+            origins = zv[..., :3] * float(o.origin_scale) + torch.from_numpy(o.origin_initial).to(self.dev)[None, None]
             radii = proc(zv[..., 3])
             oo, dd = r[:, None, 0:3] * origins, r[:, None, 3:6] * origins
             if o.isect_type == 'cylinder':
@@ -137,7 +173,7 @@ class TorchPort:
             elif typ == 'point_offset':                     # point.py:371-396
                 from hyperreel_oracle import Act
                 fld = ecfg.get('in_density_field', 'sigma')
-                sg = x[fld] if (ecfg.get('use_sigma', True) and fld in x) else torch.zeros(B, Z, 1)
+                sg = x[fld] if (ecfg.get('use_sigma', True) and fld in x) else torch.zeros(B, Z, 1, device=self.dev)
                 x['points'] = x['points'] + _act(Act(ecfg.get('activation')), x['point_offset']) * (1 - sg)
         x['viewdirs'] = rays[:, None, 3:6].expand(B, Z, 3)
         return x
@@ -155,7 +191,7 @@ class TorchPort:
             if o.video:
                 gb = pn[:, o.MAT_T[i]].view(1, N, 1, 2)
             else:
-                gb = torch.stack([torch.zeros(N), pn[:, o.VEC[i]]], -1).view(1, N, 1, 2)
+                gb = torch.stack([torch.zeros(N, device=self.dev), pn[:, o.VEC[i]]], -1).view(1, N, 1, 2)
             pb = F.grid_sample(planes_b[i], gb, align_corners=True).view(-1, N)
             out.append(pa * pb)
         return torch.cat(out, 0)
@@ -165,20 +201,20 @@ class TorchPort:
         pts = x['points']
         B, Z = pts.shape[:2]
         dist = x['distances'].reshape(B, Z)
-        deltas = torch.cat([dist[:, 1:] - dist[:, :-1], torch.full((B, 1), 1e10)], 1)
+        deltas = torch.cat([dist[:, 1:] - dist[:, :-1], torch.full((B, 1), 1e10, device=self.dev)], 1)
         valid = ~(((self.aabb[0] > pts) | (pts > self.aabb[1])).any(-1)) & (dist > 0)
         pn = (pts - self.aabb[0]) * self.inv_size - 1
         if o.video:
             pn = torch.cat([pn, (x['base_times'] * o.tsf + o.tpo) * 2 - 1], -1)
-        sigma = torch.zeros(B, Z)
+        sigma = torch.zeros(B, Z, device=self.dev)
         if valid.any():
             f = self._feat(self.d_a, self.d_b, pn[valid]).sum(0)
             sigma[valid] = F.relu(f) if o.act == 'relu' else (f.abs() if o.act == 'relu_abs' else F.softplus(f + float(o.density_shift)))
         alpha = 1.0 - torch.exp(-sigma * (deltas * float(o.distance_scale)))
-        T = torch.cumprod(torch.cat([torch.ones(B, 1), 1.0 - alpha + 1e-10], -1), -1)
+        T = torch.cumprod(torch.cat([torch.ones(B, 1, device=self.dev), 1.0 - alpha + 1e-10], -1), -1)
         weight = alpha * T[:, :-1]
         app = weight > float(o.thr)
-        rgb = torch.zeros(B, Z, 3)
+        rgb = torch.zeros(B, Z, 3, device=self.dev)
         if app.any():
             feat = F.linear(self._feat(self.a_a, self.a_b, pn[app]).T, self.basis)
             if o.shading == 'RGB':
@@ -199,6 +235,9 @@ class TorchPort:
 
     @torch.no_grad()
     def render(self, rays, chunk=16384):
-        rays = torch.from_numpy(np.ascontiguousarray(rays, np.float32))
+        if not torch.is_tensor(rays):
+            rays = torch.from_numpy(np.ascontiguousarray(rays, np.float32))
+        rays = rays.to(self.dev)
         outs = [self.color(self.embed(rays[i:i + chunk])) for i in range(0, rays.shape[0], chunk)]
-        return {'rgb': torch.cat(outs, 0).numpy()}
+        out = torch.cat(outs, 0)
+        return {'rgb': out.cpu().numpy() if self.dev.type == 'cpu' else out}
