@@ -159,13 +159,16 @@ __device__ __forceinline__ void hr_split_store4(__bf16* xh, __bf16* xl, int idx,
     *reinterpret_cast<bf16x4*>(xl + idx) = l;
 }
 
-template <int W, int MT>
-__global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(const hr_config cfg, const HrMlpArgs a)
+// W: hidden width (256).  MT: 32-ray m-tiles per workgroup (2 -> 64 rays, 4 -> 128).  NW: waves
+// per workgroup (4 or 8); a wave owns NT = 8 / NW tiles of 32 hidden features.
+template <int W, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_mlp_bf16x3_kernel(const hr_config cfg, const HrMlpArgs a)
 {
     constexpr int TM = 32 * MT;           // rays per workgroup
     constexpr int XS = W + 8;             // bf16 elements per activation row
-    constexpr int NTW = W / 256;          // passes of 2 x 32 output features per wave in hidden layers
-    static_assert(W % 256 == 0, "hidden width must be a multiple of 256");
+    constexpr int NT = (W / 32) / NW;     // hidden-layer tiles per wave
+    constexpr int NTHREADS = 64 * NW;
+    static_assert(W == 256 && (NT == 1 || NT == 2), "hidden width 256 with 4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int k0p = a.k0p;
     const int XSI = k0p + 8;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
     const int64_t ray0 = (int64_t)blockIdx.x * TM;
 
     // optional per-wave phase timeline (hr_debug_trace_mlp): s_memtime stamps, 64 slots per wave
-    unsigned long long* tr = a.trace ? a.trace + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
+    unsigned long long* tr = a.trace ? a.trace + ((size_t)blockIdx.x * NW + wave) * 64 : nullptr;
     int tri = 0;
 #define HR_STAMP() do { if (tr && lane == 0 && tri < 64) tr[tri] = __builtin_readcyclecounter(); ++tri; } while (0)
     HR_STAMP();                                              // 0: start
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
         for (int i = n; i < k0p; ++i) row[i] = 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < TM * (k0p / 4); i += 256) {
+    for (int i = tid; i < TM * (k0p / 4); i += NTHREADS) {
         const int r = i / (k0p / 4), c4 = i - r * (k0p / 4);
         const float4 v = *reinterpret_cast<const float4*>(stage + r * k0p + 4 * c4);
         hr_split_store4(Xih, Xil, r * XSI + 4 * c4, v.x, v.y, v.z, v.w);
@@ -203,51 +206,49 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
     HR_STAMP();                                              // 1: prologue done
 
     const int L = cfg.mlp_layers;
-    // ---- hidden layers: wave w owns output features [w*W/4, (w+1)*W/4) in NTW passes of 2 tiles
+    // ---- hidden layers: wave w owns output features [w*W/NW, (w+1)*W/NW)
     for (int l = 0; l + 1 < L; ++l) {
         const bool skip = (cfg.mlp_skip_mask >> l) & 1;
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wsplit[l]);
         const int tiles_total = a.n_tiles[l];
         const float* bias = a.bias[l];
-#pragma unroll 1
-        for (int p = 0; p < NTW; ++p) {
-            floatx16 acc[2][MT];
+        floatx16 acc[NT][MT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
-            const int tile[2] = {wave * (2 * NTW) + 2 * p, wave * (2 * NTW) + 2 * p + 1};
-            int kt0 = 0;
-            if (l == 0 || skip) {
-                hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
-                kt0 = k0p / 16;
-            }
-            if (l > 0) hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
-            HR_STAMP();                          // 2+3l: GEMM of layer l issued
-            if (p == NTW - 1) __syncthreads();   // all waves have finished reading Xh/Xl (NTW == 1 for W = 256)
-            HR_STAMP();                          // 3+3l: barrier passed
-            static_assert(NTW == 1, "W > 256 needs the outputs of a pass staged before X is overwritten");
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+        int tile[NT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int nbase = tile[nt] * 32 + 4 * (lane >> 5);
+        for (int nt = 0; nt < NT; ++nt) tile[nt] = wave * NT + nt;
+        int kt0 = 0;
+        if (l == 0 || skip) {
+            hr_accumulate3<NT, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
+            kt0 = k0p / 16;
+        }
+        if (l > 0) hr_accumulate3_pipe<W / 16, NT, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+        HR_STAMP();                          // 2+3l: GEMM of layer l issued
+        __syncthreads();                     // all waves have finished reading Xh/Xl
+        HR_STAMP();                          // 3+3l: barrier passed
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n0 = nbase + 8 * g;
-                    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nbase = tile[nt] * 32 + 4 * (lane >> 5);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        float v0 = acc[nt][mt][4 * g + 0] + b.x;
-                        float v1 = acc[nt][mt][4 * g + 1] + b.y;
-                        float v2 = acc[nt][mt][4 * g + 2] + b.z;
-                        float v3 = acc[nt][mt][4 * g + 3] + b.w;
-                        v0 = (v0 > 0.0f) ? v0 : v0 * cfg.leaky_slope;   // nn.LeakyReLU(0.01), mlp.py:149-154
-                        v1 = (v1 > 0.0f) ? v1 : v1 * cfg.leaky_slope;
-                        v2 = (v2 > 0.0f) ? v2 : v2 * cfg.leaky_slope;
-                        v3 = (v3 > 0.0f) ? v3 : v3 * cfg.leaky_slope;
-                        hr_split_store4(Xh, Xl, (mt * 32 + (lane & 31)) * XS + n0, v0, v1, v2, v3);
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = nbase + 8 * g;
+                const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float v0 = acc[nt][mt][4 * g + 0] + b.x;
+                    float v1 = acc[nt][mt][4 * g + 1] + b.y;
+                    float v2 = acc[nt][mt][4 * g + 2] + b.z;
+                    float v3 = acc[nt][mt][4 * g + 3] + b.w;
+                    v0 = (v0 > 0.0f) ? v0 : v0 * cfg.leaky_slope;   // nn.LeakyReLU(0.01), mlp.py:149-154
+                    v1 = (v1 > 0.0f) ? v1 : v1 * cfg.leaky_slope;
+                    v2 = (v2 > 0.0f) ? v2 : v2 * cfg.leaky_slope;
+                    v3 = (v3 > 0.0f) ? v3 : v3 * cfg.leaky_slope;
+                    hr_split_store4(Xh, Xl, (mt * 32 + (lane & 31)) * XS + n0, v0, v1, v2, v3);
                 }
             }
         }
@@ -255,9 +256,10 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
         HR_STAMP();                              // 4+3l: epilogue + barrier done
     }
 
-    // ---- last Linear: N = Z*P_live features.  Full passes of 4 waves x 2 tiles of 32 features; a
-    //      remainder of up to 4 tiles runs as one tile per wave so that the waves stay balanced
-    //      (11 tiles for DoNeRF after dead-column pruning: 8 + 3).
+    // ---- last Linear: N = Z*P_live features in tiles of 32.  With 4 waves: full passes of 2 tiles
+    //      per wave, and a remainder of up to 4 tiles as one tile per wave so that the waves stay
+    //      balanced (DoNeRF after dead-column pruning: 11 tiles = 8 + 3).  With 8 waves: one tile per
+    //      wave per pass.
     {
         const int l = L - 1;
         const bool skip = (cfg.mlp_skip_mask >> l) & 1;
@@ -287,30 +289,34 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
             }
         };
         int t0 = 0;
+        if constexpr (NT == 2) {
 #pragma unroll 1
-        for (; tiles_total - t0 > 4; t0 += 8) {                        // two tiles per wave
-            const int tile[2] = {t0 + wave * 2, t0 + wave * 2 + 1};
-            if (tile[0] >= tiles_total) continue;                       // wave-uniform
-            const int tile_ld[2] = {tile[0], min(tile[1], tiles_total - 1)};
-            floatx16 acc[2][MT];
+            for (; tiles_total - t0 > NW; t0 += 2 * NW) {              // two tiles per wave
+                const int tile[2] = {t0 + wave * 2, t0 + wave * 2 + 1};
+                if (tile[0] >= tiles_total) continue;                   // wave-uniform
+                const int tile_ld[2] = {tile[0], min(tile[1], tiles_total - 1)};
+                floatx16 acc[2][MT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
-            int kt0 = 0;
-            if (skip) {
-                hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
-                kt0 = k0p / 16;
+                        for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+                int kt0 = 0;
+                if (skip) {
+                    hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
+                    kt0 = k0p / 16;
+                }
+                hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
+                HR_STAMP();                      // last layer: GEMM of this pass issued
+                store_tile(tile[0], acc[0]);
+                if (tile[1] < tiles_total) store_tile(tile[1], acc[1]);
+                HR_STAMP();                      // last layer: stores of this pass issued
             }
-            hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
-            HR_STAMP();                          // last layer: GEMM of this pass issued
-            store_tile(tile[0], acc[0]);
-            if (tile[1] < tiles_total) store_tile(tile[1], acc[1]);
-            HR_STAMP();                          // last layer: stores of this pass issued
         }
-        if (t0 + wave < tiles_total) {                                  // remainder: one tile per wave
+#pragma unroll 1
+        for (; t0 < tiles_total; t0 += NW) {                            // one tile per wave
+            if (t0 + wave >= tiles_total) continue;
             const int tile[1] = {t0 + wave};
             floatx16 acc[1][MT];
 #pragma unroll
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256, (MT == 2) ? 2 : 1) void hr_mlp_bf16x3_kernel(c
 #undef HR_STAMP
 }
 
-template <int W, int MT>
+template <int W, int MT, int NW>
 static void hr_launch_mlp_bf16x3_t(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
 {
     constexpr int TM = 32 * MT;
@@ -339,11 +345,11 @@ static void hr_launch_mlp_bf16x3_t(const hr_config& cfg, const HrMlpArgs& args, 
     const unsigned blocks = (unsigned)((args.n_rays + TM - 1) / TM);
     static size_t allowed = 0;
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_bf16x3_kernel<W, MT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_bf16x3_kernel<W, MT, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         allowed = lds;
     }
-    hipLaunchKernelGGL((hr_mlp_bf16x3_kernel<W, MT>), dim3(blocks), dim3(256), lds, stream, cfg, args);
+    hipLaunchKernelGGL((hr_mlp_bf16x3_kernel<W, MT, NW>), dim3(blocks), dim3(64 * NW), lds, stream, cfg, args);
 }
 
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
@@ -359,7 +365,9 @@ void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream
     // the 128-ray tile needs 2*128*((k0p+8)+(W+8))*2 bytes of LDS <= 160 KiB
     const bool fits128 = (size_t)128 * 2 * ((args.k0p + 8) + (cfg.mlp_hidden + 8)) * 2 <= 160 * 1024;
     if (cfg.mlp_hidden == 256) {   // other widths: rejected by hr_model_create
-        if (tile_m == 128 && fits128) hr_launch_mlp_bf16x3_t<256, 4>(cfg, args, stream);
-        else hr_launch_mlp_bf16x3_t<256, 2>(cfg, args, stream);
+        static const int nwaves = [] { const char* e = getenv("HR_MLP_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+        if (tile_m == 128 && fits128) hr_launch_mlp_bf16x3_t<256, 4, 4>(cfg, args, stream);
+        else if (nwaves == 8) hr_launch_mlp_bf16x3_t<256, 2, 8>(cfg, args, stream);
+        else hr_launch_mlp_bf16x3_t<256, 2, 4>(cfg, args, stream);
     }
 }
