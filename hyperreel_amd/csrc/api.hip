@@ -520,6 +520,18 @@ int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev
     return hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
 }
 
+int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays_dev, void* stream)
+{
+    if (!cam || (n_pixels > 0 && !rays_dev)) return fail(HR_E_INVALID, "null argument");
+    if (ray_dim != 6 && ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8");
+    if (cam->width < 1 || cam->height < 1 || cam->fx == 0.0f || cam->fy == 0.0f) return fail(HR_E_INVALID, "bad camera");
+    if (first_pixel < 0 || n_pixels < 0 || first_pixel + n_pixels > (int64_t)cam->width * cam->height)
+        return fail(HR_E_INVALID, "pixel range outside the image");
+    hr_launch_generate_rays(*cam, ray_dim, first_pixel, n_pixels, rays_dev, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream)
 {
     int rc = check_render(m, rays_dev, n_rays, rays_dev);

@@ -76,6 +76,8 @@ void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stre
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 
+void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
+
 // layout kernels (pack_kernels.hip)
 // dst[y][x][c_off + c] = src[c][y][x] for c < C  (dst texel stride = tex floats)
 // Per-sample head columns the path actually reads (hr_model_finalize drops the others from the

@@ -42,6 +42,36 @@ void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z,
     hipLaunchKernelGGL(hr_head_export_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, head, out, n_rays, Z, P, P_live, nq, map);
 }
 
+// Camera -> rays (utils/ray_utils.py:98-135, datasets/base.py:485-518): pixel centres +0.5,
+// directions (x, -y, -1) / focal, rotated by the pose, normalised; origin = pose translation.
+__global__ void hr_generate_rays_kernel(const hr_camera cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* __restrict__ rays)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_pixels; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = first_pixel + t;
+        const float i = (float)(p % cam.width), j = (float)(p / cam.width);
+        const float dx = (i - cam.cx + 0.5f) / cam.fx;
+        const float dy = -(j - cam.cy + 0.5f) / cam.fy;
+        const float dz = -1.0f;
+        float wx = dx * cam.c2w[0] + dy * cam.c2w[1] + dz * cam.c2w[2];
+        float wy = dx * cam.c2w[4] + dy * cam.c2w[5] + dz * cam.c2w[6];
+        float wz = dx * cam.c2w[8] + dy * cam.c2w[9] + dz * cam.c2w[10];
+        const float nrm = fmaxf(sqrtf(wx * wx + wy * wy + wz * wz), 1e-12f);   // F.normalize(p=2, eps=1e-12)
+        wx = wx / nrm; wy = wy / nrm; wz = wz / nrm;
+        float* r = rays + t * ray_dim;
+        r[0] = cam.c2w[3]; r[1] = cam.c2w[7]; r[2] = cam.c2w[11];
+        r[3] = wx; r[4] = wy; r[5] = wz;
+        if (ray_dim == 8) { r[6] = cam.cam_id; r[7] = cam.time; }
+    }
+}
+
+void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream)
+{
+    if (n_pixels <= 0) return;
+    int64_t blocks = (n_pixels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hr_generate_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cam, ray_dim, first_pixel, n_pixels, rays);
+}
+
 void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream)
 {
     const int64_t n = (int64_t)C * H * W;

@@ -291,6 +291,37 @@ class HipLightfieldModel(nn.Module):
                                           C.byref(f), stream), 'hr_render_fields')
         return out
 
+    def generate_rays(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None, device=None):
+        """get_coords_from_camera (datasets/base.py:485-518) on the device: 3x4 camera-to-world
+        `pose`, 3x3 intrinsics `K` -> rays (n, 6|8) for pixels [lo, hi) of the row-major image
+        (whole image by default).  80 bytes cross the PCIe bus instead of the ray list."""
+        import ctypes as C
+        import numpy as np
+        from .plan import hr_camera
+        self.native()
+        L = _lib.load()
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        lo, hi = (0, int(width) * int(height)) if pixel_range is None else (int(pixel_range[0]), int(pixel_range[1]))
+        cam = hr_camera()
+        p = np.asarray(pose, np.float32)[:3, :4].reshape(-1)
+        for i in range(12):
+            cam.c2w[i] = float(p[i])
+        Km = np.asarray(K, np.float32)
+        cam.fx, cam.fy, cam.cx, cam.cy = float(Km[0, 0]), float(Km[1, 1]), float(Km[0, 2]), float(Km[1, 2])
+        cam.width, cam.height = int(width), int(height)
+        cam.cam_id, cam.time = float(cam_id), float(0.0 if time is None else time)
+        rd = self._hc.ray_dim
+        rays = torch.empty((hi - lo, rd), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_generate_rays(C.byref(cam), rd, lo, hi - lo, C.c_void_p(rays.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'hr_generate_rays')
+        return rays
+
+    def render_camera(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None):
+        """The viewer's frame path (utils/gui_utils.py:139-212, nlf/__init__.py:754-807) without
+        its host round trips: pose -> rays -> rgb, all on the device and on the current stream."""
+        return self.render(self.generate_rays(pose, K, width, height, time, cam_id, pixel_range))['rgb']
+
     def forward(self, rays, render_kwargs=None):
         """LightfieldModel.forward (models.py:135-138)."""
         render_kwargs = render_kwargs or {}

@@ -48,6 +48,26 @@ def render_sharded(render_local, rays, group=None):
     return torch.cat(pieces, 0)
 
 
+def render_camera_sharded(model, pose, K, width, height, time=None, cam_id=0.0, group=None):
+    """Image-parallel frame straight from the camera: every rank generates only the rays of its
+    own pixel range on its GPU (`HipLightfieldModel.generate_rays`: 80 bytes of camera instead of a
+    scattered ray list), renders them and takes part in one all-gather of the tiles."""
+    n = int(width) * int(height)
+    if not (dist.is_available() and dist.is_initialized()):
+        return model.render_camera(pose, K, width, height, time, cam_id)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = shard_bounds(n, world)
+    tile = model.render_camera(pose, K, width, height, time, cam_id, pixel_range=(bounds[rank], bounds[rank + 1]))
+    per = bounds[1] - bounds[0]
+    if tile.shape[0] < per:
+        tile = torch.cat([tile, tile.new_zeros((per - tile.shape[0], 3))], 0)
+    out = tile.new_empty((world * per, 3))
+    dist.all_gather_into_tensor(out, tile.contiguous(), group=group)
+    if world * per == n:
+        return out
+    return torch.cat([out[r * per:r * per + (bounds[r + 1] - bounds[r])] for r in range(world)], 0)
+
+
 class ShardedRenderFn(torch.nn.Module):
     """Wraps a render_fn (e.g. HipRenderLightfield) so that `forward(rays)['rgb']` renders
     image-parallel across the default process group."""

@@ -77,6 +77,11 @@ class hr_config(C.Structure):
     ]
 
 
+class hr_camera(C.Structure):
+    _fields_ = [('c2w', C.c_float * 12), ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+                ('width', C.c_int32), ('height', C.c_int32), ('cam_id', C.c_float), ('time', C.c_float)]
+
+
 class hr_fields(C.Structure):
     _fields_ = [('distances_dev', C.c_void_p), ('points_dev', C.c_void_p), ('sigma_dev', C.c_void_p),
                 ('weights_dev', C.c_void_p), ('head_dev', C.c_void_p)]

@@ -159,6 +159,15 @@ typedef struct hr_fields {
     float* head_dev;            /* (n, Z*P)  raw MLP output */
 } hr_fields;
 
+/* Pinhole camera of the viewer / offline-render path: what get_coords_from_camera
+ * (datasets/base.py:485-518) consumes -- a 3x4 camera-to-world pose and intrinsics K. */
+typedef struct hr_camera {
+    float c2w[12];              /* row-major 3x4 [R | t], -z forward (utils/ray_utils.py:121-135) */
+    float fx, fy, cx, cy;       /* K[0,0], K[1,1], K[0,2], K[1,2] */
+    int32_t width, height;
+    float cam_id, time;         /* columns 6 and 7 of 8-column rays (datasets/base.py:511-515) */
+} hr_camera;
+
 typedef struct hr_model hr_model;
 
 int hr_abi_version(void);
@@ -193,6 +202,13 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,
                      const hr_fields* fields, void* stream);
+
+/* rays_dev[n_pixels, ray_dim] for pixels [first_pixel, first_pixel + n_pixels) of the image in
+ * row-major order: get_ray_directions_K(centered_pixels=True) + get_rays(normalize=True)
+ * (utils/ray_utils.py:98-135) [+ cam_id, time when ray_dim == 8].  Generating the rays on the
+ * device from 80 bytes of camera replaces the 15-20 MB host->device copy of a frame's ray list;
+ * with image-parallel rendering every rank generates only its own pixel range. */
+int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays_dev, void* stream);
 
 /* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
  * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays

@@ -340,3 +340,26 @@ def test_hipgraph_capture_and_replay(fns):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, torch.flip(ref, dims=[0]))
+
+
+def test_device_ray_generation_matches_ray_utils(fns):
+    """hr_generate_rays == get_ray_directions_K(centered) + get_rays (restated in scenes.pinhole_rays),
+    for whole images and for pixel sub-ranges (image-parallel shards), static and video rays."""
+    import math
+    for case in ('donerf_sphere_small', 'immersive_sphere_small'):
+        g, fn = fns(case)
+        H, W, fov = 37, 53, 40.0
+        pose = scenes.look_at_pose((0.3, -0.1, 0.2), (1.0, 0.1, 0.05))
+        focal = 0.5 * W / math.tan(0.5 * math.radians(fov))
+        K = np.asarray([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], np.float32)
+        video = case.startswith('immersive')
+        ref = scenes.pinhole_rays(H, W, fov, pose, cam_id=0 if video else None, time=0.25 if video else None)
+        got = fn.model.generate_rays(pose, K, W, H, time=0.25 if video else None).cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 2e-7
+        part = fn.model.generate_rays(pose, K, W, H, time=0.25 if video else None, pixel_range=(500, 1500)).cpu().numpy()
+        assert np.array_equal(part, got[500:1500])
+        a = fn.model.render_camera(pose, K, W, H, time=0.25 if video else None)
+        b = fn.model.render(torch.from_numpy(got).cuda())['rgb']
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
