@@ -1,0 +1,120 @@
+"""Coverage sweep: one small golden per SHIPPED model YAML that the HIP backend accepts.
+
+    python oracle/refgen/make_sweep.py [name ...]
+
+TEST INFRASTRUCTURE ONLY (authoring container; imports the reference through ref_shim.py).
+For every conf/experiment/model/*.yaml that `hyperreel_amd.plan.compile_config` accepts, the
+reference itself is built from that YAML (grid overridden to a small one), loaded with seeded
+weights and run on seeded rays.  The fixture tests/golden/sweep/<name>.npz stores the rays, the
+reference's rgb and the recipe -- including the parsed `experiment.model` group, because the GPU
+box has no /root/reference to read the YAML from.  YAMLs the backend rejects are listed with the
+reason in tests/golden/sweep/coverage.json (read by tests and DESIGN.md).
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+from hyperreel_amd import config as C  # noqa: E402
+from hyperreel_amd import plan, scenes  # noqa: E402
+from make_golden import special_rays  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'sweep')
+GRID = [28, 24, 20]
+
+# dataset scalars the reference constructors read (synthetic)
+DEFAULT_DS = {'near': 0.5, 'far': 20.0, 'depth_range': [0.5, 20.0], 'num_keyframes': 12, 'num_frames': 50}
+
+
+def dataset_for(name):
+    try:
+        return C.dataset_scalars(name)
+    except KeyError:
+        return dict(DEFAULT_DS)
+
+
+def sweep_rays(cfg, seed):
+    video = cfg.color.net.type == 'tensor_vm_split_time' or any(
+        e.get('type') == 'advect_points' for e in cfg.embedding.embeddings.values())
+    isect = [e for e in cfg.embedding.embeddings.values() if e.get('type') == 'ray_intersect'][0]
+    z_plane = isect.intersect.type == 'z_plane'
+    if z_plane:
+        r = scenes.random_rays(88, seed, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
+    else:
+        r = scenes.random_rays(88, seed, video)
+    ray_dim = r.shape[1]
+    sp = special_rays(ray_dim == 8, z_plane)
+    return np.ascontiguousarray(np.concatenate([r, sp], 0), np.float32)
+
+
+def main(only=None):
+    os.makedirs(OUT, exist_ok=True)
+    coverage = {}
+    names = sorted(os.path.basename(p)[:-5] for p in glob.glob(f'{ref_shim.REF}/conf/experiment/model/*.yaml'))
+    for i, name in enumerate(names):
+        if only and name not in only:
+            continue
+        path = f'{ref_shim.REF}/conf/experiment/model/{name}.yaml'
+        ds = dataset_for(name)
+        raw = C.load_model_yaml(path)
+        if raw is None:
+            coverage[name] = {'status': 'rejected', 'reason': 'the shipped YAML is empty'}
+            continue
+        raw.color.net.grid_size = C.to_cfg({'start': list(GRID), 'end': list(GRID)})
+        model_cfg = C.epoch_to_iter(C.to_cfg(C.to_plain(raw)), 4000)
+        try:
+            plan.compile_config(model_cfg, ds, GRID)
+        except (NotImplementedError, ValueError) as e:
+            coverage[name] = {'status': 'rejected', 'reason': str(e)}
+            print(f'{name:36s} rejected: {e}')
+            continue
+
+        def overrides(cfg):
+            cfg.color.net.grid_size = ref_shim.to_attr({'start': list(GRID), 'end': list(GRID)})
+        ref_cfg = ref_shim.load_model_cfg(name, overrides)
+        fn = ref_shim.build_reference(ref_cfg, ds)
+        seed = 100 + i
+        sd = scenes.make_state_dict(model_cfg, ds, GRID, seed, 'dense', 1.0)
+        own = dict(fn.state_dict())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k.endswith('gridSize'):
+                    assert own[k].tolist() == v.tolist(), (k, own[k], v)
+                    continue
+                assert tuple(own[k].shape) == tuple(v.shape), (name, k, own[k].shape, v.shape)
+                own[k].copy_(torch.from_numpy(v))
+        missing = [k for k in own if k not in sd and 'dummy_layer' not in k]
+        assert not missing, (name, missing)
+        rays = sweep_rays(model_cfg, seed)
+        try:
+            out = ref_shim.run_reference(fn, torch.from_numpy(rays))
+        except RuntimeError as e:       # a shipped YAML the reference itself cannot run
+            coverage[name] = {'status': 'reference_fails', 'reason': str(e).splitlines()[0]}
+            print(f'{name:36s} the reference raises: {coverage[name]["reason"]}')
+            continue
+        rgb = out['rgb'].numpy().astype(np.float32)
+        recipe = {'case': 'sweep/' + name, 'model': name, 'model_cfg': C.to_plain(raw), 'z_channels': None,
+                  'grid': GRID, 'seed': seed, 'density': 'dense', 'app_scale': 1.0, 'dataset': ds,
+                  'checksum': scenes.state_dict_checksum(sd)}
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), rays=rays, rgb=rgb,
+                            recipe=np.frombuffer(json.dumps(recipe).encode(), dtype=np.uint8))
+        coverage[name] = {'status': 'golden', 'rgb_std': float(rgb.std())}
+        print(f'{name:36s} golden: {rays.shape[0]} rays, rgb mean {rgb.mean():.4f} std {rgb.std():.4f}')
+    if not only:
+        with open(os.path.join(OUT, 'coverage.json'), 'w') as f:
+            json.dump(coverage, f, indent=1, sort_keys=True)
+    n_ok = sum(1 for v in coverage.values() if v['status'] == 'golden')
+    print(f'{n_ok} of {len(coverage)} shipped model YAMLs covered')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:] or None)

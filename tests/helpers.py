@@ -15,13 +15,26 @@ def golden_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
 
 
+def sweep_cases():
+    """One fixture per shipped model YAML the backend accepts (oracle/refgen/make_sweep.py)."""
+    return sorted('sweep/' + os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'sweep', '*.npz')))
+
+
+def sweep_coverage():
+    with open(os.path.join(GOLDEN_DIR, 'sweep', 'coverage.json')) as f:
+        return json.load(f)
+
+
 class Golden:
     def __init__(self, case):
         z = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
         self.arrays = {k: z[k] for k in z.files if k != 'recipe'}
         self.recipe = json.loads(bytes(z['recipe']).decode())
         r = self.recipe
-        self.cfg = C.model_config(r['model'], z_channels=r['z_channels'])
+        if 'model_cfg' in r:        # sweep fixtures carry the parsed YAML group (no /root/reference on the GPU box)
+            self.cfg = C.epoch_to_iter(C.to_cfg(r['model_cfg']), 4000)
+        else:
+            self.cfg = C.model_config(r['model'], z_channels=r['z_channels'])
         self.dataset = r['dataset']
         self.grid = r['grid']
         self.rays = self.arrays['rays']

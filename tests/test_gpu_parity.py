@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, golden_cases, linf
+from helpers import Golden, golden_cases, linf, sweep_cases
 from hyperreel_amd import config as C
 from hyperreel_amd import scenes
 
@@ -50,6 +50,19 @@ def test_rgb_matches_reference_golden(fns, case, precision):
     assert np.isfinite(out['rgb']).all()
     err = np.abs(out['rgb'] - g.rgb).max(-1)
     assert err.max() <= RGB_TOL, f'{case}: L-inf {err.max():.3e} at ray {int(err.argmax())} ({(err > RGB_TOL).sum()} rays over)'
+
+
+@pytest.mark.parametrize('case', sweep_cases())
+def test_every_accepted_shipped_yaml_matches_the_reference(case):
+    """One fixture per shipped conf/experiment/model/*.yaml the plan compiler accepts: the
+    reference built from that very YAML vs the HIP path built from the same parsed group."""
+    from gpu_common import make_render_fn, render_np
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    out = render_np(fn, g.rays)
+    err = np.abs(out['rgb'] - g.rgb).max(-1)
+    assert np.isfinite(out['rgb']).all()
+    assert err.max() <= RGB_TOL, f'{case}: L-inf {err.max():.3e} at ray {int(err.argmax())}'
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)

@@ -3,7 +3,7 @@ made by oracle/refgen/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import Golden, golden_cases, linf
+from helpers import Golden, golden_cases, linf, sweep_cases, sweep_coverage
 from hyperreel_oracle import HyperReelOracle
 
 
@@ -42,3 +42,21 @@ def test_torch_port_matches_reference_golden(case):
     g = Golden(case)
     out = TorchPort(g.cfg, g.dataset, g.state_dict).render(g.rays)
     assert linf(out['rgb'], g.rgb) <= 2e-5
+
+
+@pytest.mark.parametrize('case', sweep_cases())
+def test_oracle_matches_reference_on_every_accepted_shipped_yaml(case):
+    g = Golden(case)
+    out = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(g.rays)
+    assert np.isfinite(g.rgb).all() and g.rgb.std() > 0.02
+    assert linf(out['rgb'], g.rgb) <= 2e-5
+
+
+def test_sweep_coverage_matches_the_plan_compiler():
+    """coverage.json (what make_sweep.py saw) and the fixtures on disk agree; every rejected YAML
+    carries a reason."""
+    cov = sweep_coverage()
+    have = {c.split('/', 1)[1] for c in sweep_cases()}
+    assert have == {k for k, v in cov.items() if v['status'] == 'golden'}
+    assert all(v.get('reason') for v in cov.values() if v['status'] != 'golden')
+    assert len(have) >= 27
