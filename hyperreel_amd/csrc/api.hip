@@ -79,6 +79,15 @@ int layer_in(const hr_config& c, int l)
 
 int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? c.z_channels * c.preds_per_z : c.mlp_hidden; }
 
+// z_vals channels read per sample: z (z_plane, euclidean*, voxel_grid), origin xyz + radius
+// (sphere/cylinder), origin xyz + resize xyz + raw offset + radius (sphere_new/cylinder_new)
+int isect_z_channels(int t)
+{
+    if (t == HR_ISECT_SPHERE || t == HR_ISECT_CYLINDER) return 4;
+    if (t == HR_ISECT_SPHERE_NEW || t == HR_ISECT_CYLINDER_NEW) return 8;
+    return 1;
+}
+
 int validate(const hr_config& c)
 {
     if (c.ray_dim != 6 && c.ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8 (got %d)", c.ray_dim);
@@ -88,16 +97,25 @@ int validate(const hr_config& c)
     if (c.mlp_layers < 2 || c.mlp_layers > HR_MAX_LAYERS) return fail(HR_E_INVALID, "mlp_layers must be in [2,%d]", HR_MAX_LAYERS);
     if (c.mlp_in < 1 || c.mlp_in > HR_MAX_MLP_IN) return fail(HR_E_INVALID, "mlp_in must be in [1,%d]", HR_MAX_MLP_IN);
     if (c.mlp_skip_mask & 1) return fail(HR_E_INVALID, "layer 0 cannot be a skip layer");
-    if (c.z_channels < 1 || c.z_channels > HR_MAX_Z) return fail(HR_E_INVALID, "z_channels must be in [1,%d]", HR_MAX_Z);
+    if (c.z_channels < 1 || c.z_channels > HR_KERNEL_MAX_Z) return fail(HR_E_INVALID, "z_channels must be in [1,%d]", HR_KERNEL_MAX_Z);
     if (c.preds_per_z < 1 || c.preds_per_z > 64) return fail(HR_E_INVALID, "preds_per_z out of range");
-    const hr_head_field* fs[7] = {&c.f_z_vals, &c.f_isect_sigma, &c.f_offset_sigma, &c.f_point_offset,
-                                  &c.f_color_scale, &c.f_color_shift, &c.f_spatial_flow};
+    const hr_head_field* fs[9] = {&c.f_z_vals, &c.f_isect_sigma, &c.f_offset_sigma, &c.f_point_offset, &c.f_color_scale,
+                                  &c.f_color_shift, &c.f_spatial_flow, &c.f_color_scale_global, &c.f_color_shift_global};
     for (const hr_head_field* f : fs)
         if (f->offset >= 0 && f->offset + f->channels > c.preds_per_z) return fail(HR_E_INVALID, "head field exceeds preds_per_z");
     if (c.f_z_vals.offset < 0) return fail(HR_E_INVALID, "z_vals head is required");
-    if (c.isect_type == HR_ISECT_Z_PLANE ? c.f_z_vals.channels != 1 : c.f_z_vals.channels != 4)
-        return fail(HR_E_INVALID, "z_vals needs 1 channel for z_plane and 4 for sphere/cylinder");
+    if (c.isect_type < HR_ISECT_Z_PLANE || c.isect_type > HR_ISECT_VOXEL_GRID) return fail(HR_E_INVALID, "unknown isect_type %d", c.isect_type);
+    if (c.f_z_vals.channels != isect_z_channels(c.isect_type))
+        return fail(HR_E_INVALID, "z_vals needs %d channel(s) for intersect type %d (got %d)", isect_z_channels(c.isect_type),
+                    c.isect_type, c.f_z_vals.channels);
+    if (c.isect_type == HR_ISECT_VOXEL_GRID && c.z_channels % 3) return fail(HR_E_INVALID, "voxel_grid needs z_channels divisible by 3");
+    if (c.contract_type < HR_CONTRACT_IDENTITY || c.contract_type > HR_CONTRACT_AFFINE) return fail(HR_E_INVALID, "unknown contract_type");
+    if (c.contract_type == HR_CONTRACT_AFFINE)
+        for (int i = 0; i < 3; ++i)
+            if (c.c_aff_size[i] == 0.0f) return fail(HR_E_INVALID, "affine contraction with an empty box");
     if ((c.f_color_scale.offset >= 0) != (c.f_color_shift.offset >= 0)) return fail(HR_E_INVALID, "color_scale and color_shift come together");
+    if ((c.f_color_scale_global.offset >= 0) != (c.f_color_shift_global.offset >= 0))
+        return fail(HR_E_INVALID, "color_scale_global and color_shift_global come together");
     if (c.point_offset && (c.f_point_offset.offset < 0 || c.f_point_offset.channels != 3)) return fail(HR_E_INVALID, "point_offset head missing");
     if (c.advect && c.use_spatial_flow && (c.f_spatial_flow.offset < 0 || c.f_spatial_flow.channels != 3))
         return fail(HR_E_INVALID, "spatial_flow head missing");
@@ -123,11 +141,19 @@ void analyse_live_columns(hr_model* m)
         if (f.offset < 0) return;
         for (int i = first; i < first + count && f.offset + i < 64; ++i) live[f.offset + i] = true;
     };
-    if (c.isect_type == HR_ISECT_Z_PLANE) {
-        mark(c.f_z_vals, 0, 1);
-    } else {
+    int z_anchor = 0;                 // a z_vals channel that is always read
+    if (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) {
+        z_anchor = 3;
         mark(c.f_z_vals, 3, 1);
         if (c.origin_scale != 0.0f) mark(c.f_z_vals, 0, 3);
+    } else if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) {
+        z_anchor = 7;
+        mark(c.f_z_vals, 6, 2);
+        // kept contiguous up to the anchor so that offset + channel stays valid after compaction
+        if (c.resize_scale != 0.0f || c.origin_scale != 0.0f) mark(c.f_z_vals, 3, 3);
+        if (c.origin_scale != 0.0f) mark(c.f_z_vals, 0, 3);
+    } else {
+        mark(c.f_z_vals, 0, 1);
     }
     mark(c.f_isect_sigma, 0, 1);
     if (c.point_offset) {
@@ -136,6 +162,8 @@ void analyse_live_columns(hr_model* m)
     }
     mark(c.f_color_scale, 0, 3);
     mark(c.f_color_shift, 0, 3);
+    mark(c.f_color_scale_global, 0, 3);
+    mark(c.f_color_shift_global, 0, 3);
     if (c.advect && c.use_spatial_flow) mark(c.f_spatial_flow, 0, 3);
     const char* e = getenv("HR_PRUNE");
     const bool prune = !(e && e[0] == '0');
@@ -151,12 +179,14 @@ void analyse_live_columns(hr_model* m)
         if (f.offset < 0) return;
         f.offset = m->col_map.col[f.offset + anchor] - anchor;
     };
-    remap(m->kcfg.f_z_vals, c.isect_type == HR_ISECT_Z_PLANE ? 0 : 3);   // may become negative: only channel 3 is read then
+    remap(m->kcfg.f_z_vals, z_anchor);   // may become negative: only the live channels are read then
     remap(m->kcfg.f_isect_sigma, 0);
     if (c.point_offset) { remap(m->kcfg.f_point_offset, 0); remap(m->kcfg.f_offset_sigma, 0); }
     else { m->kcfg.f_point_offset.offset = -1; m->kcfg.f_offset_sigma.offset = -1; }
     remap(m->kcfg.f_color_scale, 0);
     remap(m->kcfg.f_color_shift, 0);
+    remap(m->kcfg.f_color_scale_global, 0);
+    remap(m->kcfg.f_color_shift_global, 0);
     if (c.advect && c.use_spatial_flow) remap(m->kcfg.f_spatial_flow, 0); else m->kcfg.f_spatial_flow.offset = -1;
 }
 

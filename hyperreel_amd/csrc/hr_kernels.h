@@ -2,6 +2,9 @@
 #ifndef HR_KERNELS_H
 #define HR_KERNELS_H
 
+// samples per ray the sample kernel handles (one wave per ray); hr_config.samples holds HR_MAX_Z
+#define HR_KERNEL_MAX_Z 64
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

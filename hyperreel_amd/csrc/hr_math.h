@@ -140,9 +140,11 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
 }
 
 // ---------------------------------------------------------------- contraction (nlf/contract.py)
-// inverse_contract_distance, contract.py:143-158 (identity distance_activation)
+// inverse_contract_distance: MIPNeRFContract contract.py:143-158 (identity distance_activation);
+// BBoxContract :78-79 / ZDepthContract :104-105 (d * fac)
 HR_FN float hr_inverse_contract_distance(const hr_config& c, float distance)
 {
+    if (c.contract_type == HR_CONTRACT_AFFINE) return distance * c.c_aff_fac;
     distance = (distance * 0.5f) * 2.0f;             // x/2*2, exact either way
     distance = fminf(fmaxf(distance, -2.0f), 2.0f);
     float t = 2.0f - fabsf(distance);
@@ -152,9 +154,15 @@ HR_FN float hr_inverse_contract_distance(const hr_config& c, float distance)
     return r * c.c_d0;
 }
 
-// contract_points, contract.py:178-192
+// contract_points: MIPNeRFContract contract.py:178-192; BBoxContract :84-85 / ZDepthContract :110-111
 HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, float* q)
 {
+    if (c.contract_type == HR_CONTRACT_AFFINE) {
+        q[0] = HR_DIV(px - c.c_aff_min[0], c.c_aff_size[0]);
+        q[1] = HR_DIV(py - c.c_aff_min[1], c.c_aff_size[1]);
+        q[2] = HR_DIV(pz - c.c_aff_min[2], c.c_aff_size[2]);
+        return;
+    }
     px = HR_DIV(px, c.c_r0); py = HR_DIV(py, c.c_r0); pz = HR_DIV(pz, c.c_r0);
     float dist = HR_SQRT(px * px + py * py + pz * pz);
     if (dist < 1.0f) {
@@ -184,6 +192,94 @@ HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius)
     return ((t2 < 0.0f) || (radius < 0.0f)) ? t1 : t2;
 }
 
+HR_FN float hr_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// F.normalize(p=2, eps=1e-12) of a 3-vector, in place
+HR_FN void hr_normalize3(float* v)
+{
+    float n = fmaxf(HR_SQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    v[0] = HR_DIV(v[0], n); v[1] = HR_DIV(v[1], n); v[2] = HR_DIV(v[2], n);
+}
+
+HR_FN void hr_cross3(const float* a, const float* b, float* r)
+{
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// pluecker_pos (nlf/param.py:297-307): the point of the line (o, d) closest to the origin,
+// d_hat x (o x d_hat) with d_hat = normalize(d)
+HR_FN void hr_pluecker_pos(const float* o, const float* d, float* pos)
+{
+    float dn[3] = {d[0], d[1], d[2]};
+    hr_normalize3(dn);
+    float m[3];
+    hr_cross3(o, dn, m);
+    hr_cross3(dn, m, pos);
+}
+
+// sign(d . diff) * |diff|  (primitive.py:171-173, :532-534)
+HR_FN float hr_signed_base_distance(const float* d, const float* diff)
+{
+    float dt = d[0] * diff[0] + d[1] * diff[1] + d[2] * diff[2];
+    return hr_sign(dt) * HR_SQRT(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+}
+
+// z_vals channel `ch` of a sample: head activation -> intersect activation * (1 - sigma)  (base.py:161-162)
+HR_FN float hr_zval(const hr_config& c, const float* hk, int ch, float one_m)
+{
+    return hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + ch])) * one_m;
+}
+
+// process_z_vals (base.py:128-140): anchor + scale, then back from the contracted sample space
+HR_FN float hr_process_z(const hr_config& c, float z, float scale, float anchor)
+{
+    z = z * scale + anchor;
+    if (c.contract_samples) z = hr_inverse_contract_distance(c, z);
+    return z;
+}
+
+// IntersectSphereNew / IntersectCylinderNew .intersect (primitive.py:498-545, :313-363): the ray is
+// moved into the primitive's frame, intersected, and samples whose primitive the ray misses are
+// recycled as offsets from the ray's closest point to the axis/centre.
+HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m, const float* ro, const float* rd)
+{
+    float org[3] = {0.0f, 0.0f, 0.0f};
+    if (c.origin_scale != 0.0f)
+        for (int i = 0; i < 3; ++i) org[i] = hr_zval(c, hk, i, one_m) * c.origin_scale;
+    float rs[3] = {c.resize_initial[0], c.resize_initial[1], c.resize_initial[2]};
+    if (c.resize_scale != 0.0f)
+        for (int i = 0; i < 3; ++i) rs[i] = hr_zval(c, hk, 3 + i, one_m) * c.resize_scale + c.resize_initial[i];
+    const float raw = hr_process_z(c, hr_zval(c, hk, 6, one_m), c.z_scale, c.samples[k]);
+    const float radius = hr_process_z(c, hr_zval(c, hk, 7, one_m), c.z_scale, c.samples[k]);
+    float o[3], d[3];
+    for (int i = 0; i < 3; ++i) { o[i] = (ro[i] - org[i]) * rs[i]; d[i] = rd[i] * rs[i]; }
+    const float dnorm = HR_SQRT(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);     // torch.norm(rays_d)
+    float dn[3] = {d[0], d[1], d[2]};
+    hr_normalize3(dn);
+    float t, min_radius, base_distance;
+    if (c.isect_type == HR_ISECT_SPHERE_NEW) {
+        t = hr_quadratic_t(o[0] * o[0] + o[1] * o[1] + o[2] * o[2], dn[0] * dn[0] + dn[1] * dn[1] + dn[2] * dn[2],
+                           o[0] * dn[0] + o[1] * dn[1] + o[2] * dn[2], radius);
+        float pos[3];
+        hr_pluecker_pos(o, dn, pos);                                           // also min_sphere_radius' vector
+        min_radius = HR_SQRT(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+        const float diff[3] = {pos[0] - o[0], pos[1] - o[1], pos[2] - o[2]};
+        base_distance = hr_signed_base_distance(dn, diff);
+    } else {
+        t = hr_quadratic_t(o[0] * o[0] + o[2] * o[2], dn[0] * dn[0] + dn[2] * dn[2], o[0] * dn[0] + o[2] * dn[2], radius);
+        const float oc[3] = {o[0], 0.0f, o[2]}, dc[3] = {dn[0], 0.0f, dn[2]};
+        float pos[3];
+        hr_pluecker_pos(oc, dc, pos);
+        min_radius = HR_SQRT(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+        const float diff[3] = {pos[0] - oc[0], pos[1] - oc[1], pos[2] - oc[2]};
+        base_distance = HR_DIV(hr_signed_base_distance(dc, diff), HR_SQRT(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]));
+    }
+    if (fabsf(radius) < min_radius + 4.0f * c.z_scale) t = raw + base_distance;
+    return HR_DIV(t, dnorm + 1e-5f);
+}
+
 // Pre-sort distance of sample k (Intersect.forward, intersect/base.py:142-203):
 // head activation -> z activation * (1 - sigma) -> anchors/scale -> inverse contraction
 // -> closed-form intersection -> near/far mask.  `hk` points at the P raw head values of
@@ -195,26 +291,19 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
     float one_m = 1.0f - sigma;
     float dist;
     if (c.isect_type == HR_ISECT_Z_PLANE) {
-        float z = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset])) * one_m;
-        z = z * c.z_scale + c.samples[k];                            // base.py:129
-        if (c.contract_samples) z = hr_inverse_contract_distance(c, z);
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);   // base.py:129
         dist = hr_axis_plane_t(z, ro[2], rd[2]);                     // z.py:88-95
-    } else {
+    } else if (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) {
         // origins = z[:3] * origin_scale_factor + origin_initial (primitive.py:410-412).  With the
         // shipped origin_scale_factor of 0 the three channels are multiplied by zero; they are then
         // not read at all (and hr_model_finalize drops those columns from the last Linear).
         float sx = c.origin_initial[0], sy = c.origin_initial[1], sz = c.origin_initial[2];
         if (c.origin_scale != 0.0f) {
-            const float z0 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 0])) * one_m;
-            const float z1 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 1])) * one_m;
-            const float z2 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 2])) * one_m;
-            sx = z0 * c.origin_scale + c.origin_initial[0];
-            sy = z1 * c.origin_scale + c.origin_initial[1];
-            sz = z2 * c.origin_scale + c.origin_initial[2];
+            sx = hr_zval(c, hk, 0, one_m) * c.origin_scale + c.origin_initial[0];
+            sy = hr_zval(c, hk, 1, one_m) * c.origin_scale + c.origin_initial[1];
+            sz = hr_zval(c, hk, 2, one_m) * c.origin_scale + c.origin_initial[2];
         }
-        const float z3 = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + 3])) * one_m;
-        float radius = z3 * c.z_scale + c.samples[k];
-        if (c.contract_samples) radius = hr_inverse_contract_distance(c, radius);
+        float radius = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
         float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
         float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
         if (c.isect_type == HR_ISECT_SPHERE) {
@@ -228,9 +317,33 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
             float od = ox * dx + oz * dz;
             dist = hr_quadratic_t(oo, dd, od, radius);
         }
+    } else if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) {
+        dist = hr_isect_new(c, hk, k, one_m, ro, rd);
+    } else if (c.isect_type == HR_ISECT_VOXEL_GRID) {
+        // voxel.py:72-112: samples are (Z/3, 3) axis planes; sample k is a plane orthogonal to axis k % 3
+        const int axis = k % 3;
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.voxel_scale[axis], c.samples[k]);
+        const float o = (axis == 0) ? ro[0] : (axis == 1) ? ro[1] : ro[2];
+        const float d = (axis == 0) ? rd[0] : (axis == 1) ? rd[1] : rd[2];
+        if (c.isect_outward) z = z * hr_sign(d);
+        dist = hr_axis_plane_t(z, o, d);                             // intersect_utils.py:152-179
+    } else {
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);
+        if (c.isect_type == HR_ISECT_EUCLIDEAN_UNIFIED) {            // primitive.py:162-176
+            float pos[3];
+            hr_pluecker_pos(ro, rd, pos);
+            const float diff[3] = {pos[0] - ro[0], pos[1] - ro[1], pos[2] - ro[2]};
+            dist = z + hr_signed_base_distance(rd, diff);
+        } else {                                                     // primitive.py:115-128
+            dist = z;
+            if (c.isect_min_radius > 0.0f) dist = z + (z - HR_SQRT(ro[0] * ro[0] + ro[1] * ro[1] + ro[2] * ro[2]));
+        }
     }
-    bool mask = (dist <= c.near) || (dist >= c.far);                 // base.py:194
-    return mask ? 0.0f : dist;
+    if (!c.isect_mask_off) {
+        bool mask = (dist <= c.near) || (dist >= c.far);             // base.py:194
+        dist = mask ? 0.0f : dist;
+    }
+    return dist;
 }
 
 // get_base_time, utils/flow_utils.py:10-35 (jitter off).  rintf == torch.round (half to even).
@@ -254,7 +367,7 @@ HR_FN void hr_sample_point(const hr_config& c, const float* hk, float dist_sorte
     float py = ro[1] + rd[1] * dist_sorted;
     float pz = ro[2] + rd[2] * dist_sorted;
     float dist = dist_sorted;
-    if (c.contract_type == HR_CONTRACT_MIPNERF) {
+    if (c.contract_type != HR_CONTRACT_IDENTITY) {
         float q[3];
         hr_contract_point(c, px, py, pz, q);
         float ex = q[0] - oc[0], ey = q[1] - oc[1], ez = q[2] - oc[2];

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
 
     // ---- points, contraction, advect, offset
     float oc[3] = {0.f, 0.f, 0.f};
-    if (cfg.contract_type == HR_CONTRACT_MIPNERF) hr_contract_point(cfg, ro[0], ro[1], ro[2], oc);
+    if (cfg.contract_type != HR_CONTRACT_IDENTITY) hr_contract_point(cfg, ro[0], ro[1], ro[2], oc);
     float base_t = 0.0f, time_off = 0.0f;
     if (cfg.advect) {
         base_t = hr_base_time(cfg, t_ray);
@@ -286,6 +286,13 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
         if (cfg.white_bg) {                        // tensorf_no_sample.py:236-237
             const float bg = 1.0f - acc_w;
             c0 += bg; c1 += bg; c2 += bg;
+        }
+        if (cfg.f_color_scale_global.offset >= 0) {   // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head
+            const hr_head_field& fs = cfg.f_color_scale_global;
+            const hr_head_field& fh = cfg.f_color_shift_global;
+            c0 = c0 * (hr_apply_act(fs.act, hk[fs.offset + 0]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 0]);
+            c1 = c1 * (hr_apply_act(fs.act, hk[fs.offset + 1]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 1]);
+            c2 = c2 * (hr_apply_act(fs.act, hk[fs.offset + 2]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 2]);
         }
         a.rgb[ray * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);   // eval-mode clamp, :246-247
         a.rgb[ray * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);

@@ -24,7 +24,8 @@ import numpy as np
 
 F32 = np.float32
 
-HR_MAX_Z = 64
+HR_MAX_Z = 256          # size of hr_config.samples
+HR_KERNEL_MAX_Z = 64    # what the sample kernel handles today (one wave per ray)
 HR_MAX_GROUPS = 4
 HR_MAX_LAYERS = 8
 HR_MAX_MLP_IN = 64
@@ -32,8 +33,10 @@ HR_MAX_MLP_IN = 64
 ACT = {'identity': 0, 'sigmoid': 1, 'tanh': 2}
 PARAM = {'identity': 0, 'pluecker': 1, 'two_plane': 2}
 PE = {None: 0, 'windowed': 1, 'basic': 2}
-ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2}
-CONTRACT = {'identity': 0, 'mipnerf': 1}
+ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2, 'sphere_new': 3, 'cylinder_new': 4, 'euclidean_distance': 5,
+         'euclidean_distance_unified': 6, 'voxel_grid': 7}
+ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1, 7: 1}     # z_vals channels each type reads per sample
+CONTRACT = {'identity': 0, 'mipnerf': 1, 'bbox': 2, 'z_depth': 2}   # bbox and z_depth share the affine kernel path
 DENSITY = {'relu': 0, 'softplus': 1, 'relu_abs': 2}
 SHADING = {'RGB': 0, 'SH': 1}
 
@@ -59,13 +62,16 @@ class hr_config(C.Structure):
         ('leaky_slope', C.c_float), ('z_channels', C.c_int32), ('preds_per_z', C.c_int32),
         ('f_z_vals', hr_head_field), ('f_isect_sigma', hr_head_field), ('f_offset_sigma', hr_head_field),
         ('f_point_offset', hr_head_field), ('f_color_scale', hr_head_field), ('f_color_shift', hr_head_field),
-        ('f_spatial_flow', hr_head_field),
+        ('f_spatial_flow', hr_head_field), ('f_color_scale_global', hr_head_field), ('f_color_shift_global', hr_head_field),
         ('isect_type', C.c_int32), ('isect_origin', C.c_float * 3), ('near', C.c_float), ('far', C.c_float),
         ('z_act', hr_act), ('sort', C.c_int32), ('samples', C.c_float * HR_MAX_Z), ('z_scale', C.c_float),
         ('origin_scale', C.c_float), ('origin_initial', C.c_float * 3),
+        ('resize_scale', C.c_float), ('resize_initial', C.c_float * 3), ('isect_min_radius', C.c_float),
+        ('voxel_scale', C.c_float * 3), ('isect_outward', C.c_int32), ('isect_mask_off', C.c_int32),
         ('contract_type', C.c_int32), ('contract_samples', C.c_int32),
         ('c_r0', C.c_float), ('c_r_inv_end', C.c_float), ('c_r_scale', C.c_float),
         ('c_d0', C.c_float), ('c_d_inv_end', C.c_float), ('c_d_scale', C.c_float),
+        ('c_aff_min', C.c_float * 3), ('c_aff_size', C.c_float * 3), ('c_aff_fac', C.c_float),
         ('advect', C.c_int32), ('use_spatial_flow', C.c_int32), ('flow_fac', C.c_float), ('flow_inv_fac', C.c_float),
         ('flow_kmax', C.c_float), ('flow_act', hr_act),
         ('point_offset', C.c_int32), ('offset_act', hr_act),
@@ -154,6 +160,28 @@ class _MipNerf:
         return F32((F32(out) / F32(2.0)) * F32(2.0))
 
 
+class _Affine:
+    """BBoxContract (nlf/contract.py:65-87) and ZDepthContract (:90-111): p -> (p - lo) / size,
+    contract_distance(d) = d / fac, inverse = d * fac."""
+
+    def __init__(self, c, ds):
+        if c['type'] == 'bbox':
+            lo = np.asarray(c.get('bbox_min', [-1.0, -1.0, -1.0]), F32)
+            hi = np.asarray(c.get('bbox_max', [1.0, 1.0, 1.0]), F32)
+            self.lo, self.size = lo, (hi - lo).astype(F32)
+            self.fac = F32(np.mean(np.abs(hi - lo), dtype=F32))
+        else:
+            if c.get('use_dataset_bounds', False):
+                r1 = c.get('contract_end_radius', ds['depth_range'][1])
+            else:
+                r1 = c.get('contract_end_radius', float('inf'))
+            self.fac = F32(r1 / 2.0)
+            self.lo, self.size = np.zeros(3, F32), np.full(3, self.fac, F32)
+
+    def contract_distance(self, distance):
+        return F32(F32(distance) / self.fac)
+
+
 # --------------------------------------------------------------------------- the compiler
 MLP_PRECISION = {'fp32': 0, 'bf16x3': 1}
 
@@ -167,7 +195,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
         raise NotImplementedError(f"embedding type {cfg['embedding']['type']}")
     hc = hr_config()
     for name in ('f_z_vals', 'f_isect_sigma', 'f_offset_sigma', 'f_point_offset', 'f_color_scale',
-                 'f_color_shift', 'f_spatial_flow'):
+                 'f_color_shift', 'f_spatial_flow', 'f_color_scale_global', 'f_color_shift_global'):
         setattr(hc, name, _absent_field())
     stages = list(cfg['embedding']['embeddings'].values())
     types = [s['type'] for s in stages]
@@ -261,8 +289,8 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     hc.mlp_skip_mask = mask
     hc.leaky_slope = 0.01
     Z = int(pred['z_channels'])
-    if Z > HR_MAX_Z:
-        raise NotImplementedError(f'z_channels {Z} > {HR_MAX_Z}')
+    if Z > HR_KERNEL_MAX_Z:
+        raise NotImplementedError(f'z_channels {Z} > {HR_KERNEL_MAX_Z}')
     hc.z_channels = Z
     heads = {}
     off = 0
@@ -275,11 +303,26 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     if 'z_vals' not in heads:
         raise NotImplementedError('model without a z_vals head')
     hc.f_z_vals = heads['z_vals']
-    if 'color_scale' in heads and 'color_shift' in heads:
+    # ExtractFieldsEmbedding (embedding/point.py:236-244): the colour net only sees the listed fields
+    seen = set(stages[types.index('extract_fields')]['fields']) if 'extract_fields' in types else None
+    has = lambda k: k in heads and (seen is None or k in seen)
+    if has('color_scale'):                           # tensorf_no_sample.py:222-225 (color_shift is read unguarded)
+        if not has('color_shift'):
+            raise ValueError('color_scale without color_shift')
         hc.f_color_scale, hc.f_color_shift = heads['color_scale'], heads['color_shift']
-    for k in ('color_transform', 'color_scale_global', 'color_shift_global', 'color_transform_global', 'weights_shift'):
-        if k in heads:
-            raise NotImplementedError(f"head '{k}' is outside the hot-path scope")
+    elif has('color_transform'):
+        raise NotImplementedError("head 'color_transform' is outside the hot-path scope")
+    if has('color_scale_global'):                    # tensorf_no_sample.py:240-241
+        if not has('color_shift_global'):
+            raise ValueError('color_scale_global without color_shift_global')
+        hc.f_color_scale_global, hc.f_color_shift_global = heads['color_scale_global'], heads['color_shift_global']
+    elif has('color_transform_global'):
+        raise NotImplementedError("head 'color_transform_global' is outside the hot-path scope")
+    for k in ('f_color_scale', 'f_color_shift', 'f_color_scale_global', 'f_color_shift_global'):
+        if getattr(hc, k).offset >= 0 and getattr(hc, k).channels != 3:
+            raise ValueError(f'{k[2:]} needs 3 channels')
+    if has('weights_shift'):
+        raise NotImplementedError("head 'weights_shift' is outside the hot-path scope")
 
     # ---- ray_intersect --------------------------------------------------------------
     st = stages[types.index('ray_intersect')]
@@ -290,12 +333,18 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     if t not in ISECT:
         raise NotImplementedError(f"intersect '{t}' is outside the hot-path scope (SURVEY 8f-1)")
     hc.isect_type = ISECT[t]
-    for k in ('weight_fn', 'sort_outputs', 'mask', 'dropout', 'normalize', 'residual_z', 'residual_distance', 'clamp',
-              'use_local_prediction', 'flip_axes', 'use_disparity', 'z_scale', 'num_samples_for_scale'):
+    if hc.f_z_vals.channels != ISECT_Z_CHANNELS[hc.isect_type]:
+        # the reference reshapes z_vals to (B, Z, n) and fails (or silently mis-strides) otherwise
+        raise ValueError(f"intersect '{t}' needs {ISECT_Z_CHANNELS[hc.isect_type]} z_vals channels, "
+                         f"the head has {hc.f_z_vals.channels}")
+    for k in ('weight_fn', 'sort_outputs', 'dropout', 'normalize', 'residual_z', 'residual_distance', 'clamp',
+              'use_local_prediction', 'flip_axes', 'use_disparity', 'max_axis'):
         if ic.get(k):
             raise NotImplementedError(f'intersect.{k}')
     if ic.get('num_repeat', 1) != 1:
         raise NotImplementedError('intersect.num_repeat')
+    if 'mask' in ic:                              # base.py:104-108,197-198; inference runs at iter 1e7
+        hc.isect_mask_off = int(10_000_000 > ic['mask'].get('stop_iters', float('inf')))
     udb = ic.get('use_dataset_bounds', False)
     org = ic.get('origin', [0.0, 0.0, 0.0])
     for k in range(3):
@@ -319,7 +368,12 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
             raise NotImplementedError('contract.stop_iters')
         hc.contract_type = CONTRACT[ct]
         hc.contract_samples = int(bool(ic['contract'].get('contract_samples', False)))
-        if ct == 'mipnerf':
+        if ct in ('bbox', 'z_depth'):
+            contract = _Affine(ic['contract'], dataset)
+            for k in range(3):
+                hc.c_aff_min[k], hc.c_aff_size[k] = float(contract.lo[k]), float(contract.size[k])
+            hc.c_aff_fac = float(contract.fac)
+        elif ct == 'mipnerf':
             contract = _MipNerf(ic['contract'], dataset)
             hc.c_r0 = float(contract.r0)
             inv_end = contract.r0 / contract.r1
@@ -331,12 +385,38 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
             hc.c_d_scale = float(1.0 / (1.0 - inv_end))
         elif hc.contract_samples:
             hc.contract_samples = 0          # IdentityContract.inverse_contract_distance is the identity
-    if t == 'z_plane':                        # z.py:25-39
+    cdist = contract.contract_distance if (hc.contract_samples and contract is not None) else (lambda v: F32(v))
+    if t == 'voxel_grid':                     # voxel.py:19-70: Z/3 axis planes per axis, sample k -> axis k % 3
+        if Z % 3:
+            raise ValueError('voxel_grid needs z_channels divisible by 3')
+        nz = Z // 3
+        fac = ic.get('fac', 1.0)
+        if udb:
+            if 'bbox_min' not in dataset and not ('initial' in ic and 'end' in ic):
+                raise ValueError('voxel_grid with use_dataset_bounds reads dataset.bbox_min / bbox_max')
+            initial = ic['initial'] if 'initial' in ic else (np.asarray(dataset['bbox_min'], F32) * F32(fac))
+            end = ic['end'] if 'end' in ic else (np.asarray(dataset['bbox_max'], F32) * F32(fac))
+        else:
+            initial, end = ic.get('initial', [0.0, 0.0, 0.0]), ic.get('end', [1.0, 1.0, 1.0])
+        cols = [torch_linspace_f32(cdist(F32(initial[d])), cdist(F32(end[d])), nz) for d in range(3)]
+        for j in range(nz):
+            for d in range(3):
+                hc.samples[3 * j + d] = float(cols[d][j])
+        for d in range(3):
+            if 'z_scale' in ic:
+                zs = F32(ic['z_scale'][d])
+            else:
+                zs = np.abs(cols[d][1] - cols[d][0]) if nz > 1 else F32(1.0)
+            hc.voxel_scale[d] = float(zs) if zs != 0 else 1.0
+        hc.z_scale = 1.0
+        hc.isect_outward = int(bool(ic.get('outward_facing', False)))
+        samples = None
+    elif t == 'z_plane':                      # z.py:25-39
         if udb:
             initial, end = F32(-dataset['near']), F32(-dataset['far'])
         else:
             initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
-    else:                                     # primitive.py:185-215 / 370-400
+    elif t in ('sphere', 'cylinder'):         # primitive.py:185-215 / 370-400
         if udb:
             initial = F32(ic['initial']) if 'initial' in ic else F32(dataset['near'] * 1.5)
             end = F32(ic['end']) if 'end' in ic else F32(dataset['far'] * 1.5)
@@ -346,12 +426,45 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
         oi = ic.get('origin_initial', [1.0, 1.0, 1.0])
         for k in range(3):
             hc.origin_initial[k] = float(oi[k])
-    if hc.contract_samples and contract is not None:
-        initial, end = contract.contract_distance(initial), contract.contract_distance(end)
-    samples = torch_linspace_f32(initial, end, Z)
-    for k in range(Z):
-        hc.samples[k] = float(samples[k])
-    hc.z_scale = float(np.abs(samples[1] - samples[0])) if Z > 1 else 1.0
+    elif t in ('sphere_new', 'cylinder_new'):   # primitive.py:256-303 / 441-488
+        if udb:
+            if ic['outward_facing']:
+                initial = F32(ic['initial']) if 'initial' in ic else F32(dataset['near'] * 1.5)
+            else:
+                initial = F32(ic['initial']) if 'initial' in ic else F32(-dataset['far'] * 1.5)
+            end = F32(ic['end']) if 'end' in ic else F32(dataset['far'] * 1.5)
+        else:
+            initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
+        hc.origin_scale = float(ic.get('origin_scale_factor', 0.0))
+        hc.resize_scale = float(ic.get('resize_scale_factor', 0.0))
+        ri = ic.get('resize_initial', [1.0, 1.0, 1.0])
+        for k in range(3):
+            hc.resize_initial[k] = float(ri[k])
+    elif t == 'euclidean_distance_unified':   # primitive.py:131-160
+        if udb:
+            initial = F32(ic['initial']) if 'initial' in ic else F32(-dataset['far'])
+            end = F32(ic['end']) if 'end' in ic else F32(dataset['far'])
+        else:
+            initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
+    else:                                     # euclidean_distance, primitive.py:76-113
+        initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 2.0))
+        hc.isect_min_radius = float(ic.get('min_radius', 0.0))
+    if t != 'voxel_grid':
+        samples = torch_linspace_f32(cdist(initial), cdist(end), Z)
+        for k in range(Z):
+            hc.samples[k] = float(samples[k])
+        if Z > 1:
+            if 'z_scale' in ic:
+                zs = F32(ic['z_scale'])
+            elif 'num_samples_for_scale' in ic and t == 'z_plane':       # z.py:63-65
+                zs = np.abs(samples[1] - samples[0]) * F32(Z / float(ic['num_samples_for_scale']))
+            else:
+                zs = np.abs(samples[1] - samples[0])
+        else:
+            zs = F32(ic.get('z_scale', 1.0))
+        if t == 'euclidean_distance' and zs == 0:
+            zs = F32(1.0)
+        hc.z_scale = float(zs)
 
     # ---- advect / offset --------------------------------------------------------------
     if 'advect_points' in types:
@@ -454,18 +567,27 @@ def live_head_columns(hc):
             for i in range(first, first + count):
                 live[f.offset + i] = True
 
-    if hc.isect_type == ISECT['z_plane']:
-        mark(hc.f_z_vals, 0, 1)
-    else:
+    t = hc.isect_type
+    if t in (ISECT['sphere'], ISECT['cylinder']):
         mark(hc.f_z_vals, 3, 1)
         if hc.origin_scale != 0.0:
             mark(hc.f_z_vals, 0, 3)
+    elif t in (ISECT['sphere_new'], ISECT['cylinder_new']):
+        mark(hc.f_z_vals, 6, 2)
+        if hc.resize_scale != 0.0 or hc.origin_scale != 0.0:   # kept contiguous up to channel 7
+            mark(hc.f_z_vals, 3, 3)
+        if hc.origin_scale != 0.0:
+            mark(hc.f_z_vals, 0, 3)
+    else:
+        mark(hc.f_z_vals, 0, 1)
     mark(hc.f_isect_sigma, 0, 1)
     if hc.point_offset:
         mark(hc.f_point_offset, 0, 3)
         mark(hc.f_offset_sigma, 0, 1)
     mark(hc.f_color_scale, 0, 3)
     mark(hc.f_color_shift, 0, 3)
+    mark(hc.f_color_scale_global, 0, 3)
+    mark(hc.f_color_shift_global, 0, 3)
     if hc.advect and hc.use_spatial_flow:
         mark(hc.f_spatial_flow, 0, 3)
     return live

@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 2
+#define HR_ABI_VERSION 3
 
-#define HR_MAX_Z 64          /* samples per ray (z_channels) supported by the sample kernel */
+#define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
+#define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
 #define HR_MAX_GROUPS 4      /* ray-parameterisation groups feeding the MLP (`params:` in the YAML) */
 #define HR_MAX_LAYERS 8      /* Linear layers of the sample-prediction MLP */
 #define HR_MAX_MLP_IN 64     /* MLP input features after positional encoding */
@@ -75,8 +76,16 @@ typedef struct hr_head_field {
     hr_act act;
 } hr_head_field;
 
-enum { HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2 };
-enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1 };
+/* nlf/intersect: z.py:15-97 (z_plane), primitive.py:366-438 (sphere), :181-253 (cylinder), :441-545
+ * (sphere_new), :256-363 (cylinder_new), :76-128 (euclidean_distance), :131-176
+ * (euclidean_distance_unified), voxel.py:19-112 (voxel_grid) */
+enum {
+    HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2, HR_ISECT_SPHERE_NEW = 3,
+    HR_ISECT_CYLINDER_NEW = 4, HR_ISECT_EUCLIDEAN = 5, HR_ISECT_EUCLIDEAN_UNIFIED = 6, HR_ISECT_VOXEL_GRID = 7
+};
+/* nlf/contract.py: IdentityContract (:53-62), MIPNeRFContract (:113-192); BBoxContract (:65-87) and
+ * ZDepthContract (:90-111) are both the affine map p -> (p - c_aff_min) / c_aff_size, d -> d / c_aff_fac */
+enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1, HR_CONTRACT_AFFINE = 2 };
 enum { HR_DENSITY_RELU = 0, HR_DENSITY_SOFTPLUS = 1, HR_DENSITY_RELU_ABS = 2 };
 enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
 /* arithmetic of the MLP GEMMs: exact fp32 MFMA, or three bf16 MFMA products of the hi/lo
@@ -106,6 +115,8 @@ typedef struct hr_config {
     hr_head_field f_color_scale;
     hr_head_field f_color_shift;
     hr_head_field f_spatial_flow;
+    hr_head_field f_color_scale_global;  /* scale_shift_color_one, utils/tensorf_utils.py:275-281 (sample 0's values) */
+    hr_head_field f_color_shift_global;
     /* ---- intersect (nlf/intersect/base.py:142-259, z.py, primitive.py) */
     int32_t isect_type;                  /* HR_ISECT_* */
     float isect_origin[3];
@@ -115,12 +126,20 @@ typedef struct hr_config {
     float samples[HR_MAX_Z];             /* anchor samples (contracted space when contract_samples) */
     float z_scale;
     float origin_scale;                  /* sphere/cylinder: origins = z[:3]*origin_scale + origin_initial */
-    float origin_initial[3];
+    float origin_initial[3];             /*   (*_new: origins = z[:3]*origin_scale, primitive.py:490-492) */
+    float resize_scale;                  /* *_new: resize = z[3:6]*resize_scale + resize_initial (:494-496) */
+    float resize_initial[3];
+    float isect_min_radius;              /* euclidean_distance: min_radius (> 0 adds z - |o|) */
+    float voxel_scale[3];                /* voxel_grid: per-axis z_scale; samples[] is (Z/3, 3) row-major */
+    int32_t isect_outward;               /* voxel_grid: outward_facing (planes mirrored by sign(d)) */
+    int32_t isect_mask_off;              /* mask.stop_iters passed: no near/far masking (base.py:197-198) */
     /* ---- contraction (nlf/contract.py:113-192) */
     int32_t contract_type;               /* HR_CONTRACT_* */
     int32_t contract_samples;
     float c_r0, c_r_inv_end, c_r_scale;  /* points:   start radius,   r0/r1, 1/(1-r0/r1) */
     float c_d0, c_d_inv_end, c_d_scale;  /* distance: start distance, d0/d1, 1/(1-d0/d1) */
+    float c_aff_min[3], c_aff_size[3];   /* affine: bbox_min, bbox_max - bbox_min (z_depth: 0, fac) */
+    float c_aff_fac;                     /* affine: inverse_contract_distance(d) = d * fac */
     /* ---- advect (nlf/embedding/point.py:780-831, utils/flow_utils.py:10-35) */
     int32_t advect;
     int32_t use_spatial_flow;

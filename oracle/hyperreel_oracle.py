@@ -177,14 +177,72 @@ class IdentityContract:
         return points, distance
 
 
+class _AffineContract:
+    """Shared shape of BBoxContract / ZDepthContract: BaseContract.contract_points_and_distance
+    (contract.py:43-50) contracts the ray origin and the points and re-measures the distance."""
+    contract_samples = False
+
+    def contract_points_and_distance(self, rays_o, points, distance):
+        o_c = self.contract_points(rays_o)
+        p_c = self.contract_points(points)
+        diff = p_c - o_c[..., None, :]
+        return p_c, np.sqrt(np.sum(diff * diff, axis=-1, keepdims=True, dtype=F32))
+
+
+class BBoxContract(_AffineContract):
+    """nlf/contract.py:65-87 (the dataset is never read, whatever use_dataset_bounds says)."""
+
+    def __init__(self, cfg, dataset=None):
+        self.contract_samples = bool(cfg.get('contract_samples', False))
+        self.bbox_min = _f(cfg.get('bbox_min', [-1.0, -1.0, -1.0]))
+        self.bbox_max = _f(cfg.get('bbox_max', [1.0, 1.0, 1.0]))
+        self.fac = F32(np.mean(np.abs(self.bbox_max - self.bbox_min), dtype=F32))
+
+    def inverse_contract_distance(self, d):
+        return (d * self.fac).astype(F32)
+
+    def contract_distance(self, d):
+        return (_f(d) / self.fac).astype(F32)
+
+    def contract_points(self, p):
+        return ((p - self.bbox_min) / (self.bbox_max - self.bbox_min)).astype(F32)
+
+
+class ZDepthContract(_AffineContract):
+    """nlf/contract.py:90-111."""
+
+    def __init__(self, cfg, dataset):
+        self.contract_samples = bool(cfg.get('contract_samples', False))
+        if cfg.get('use_dataset_bounds', False):
+            r1 = cfg.get('contract_end_radius', dataset['depth_range'][1])
+        else:
+            r1 = cfg.get('contract_end_radius', float('inf'))
+        self.fac = r1 / 2.0                               # python float
+
+    def inverse_contract_distance(self, d):
+        return (d * F32(self.fac)).astype(F32)
+
+    def contract_distance(self, d):
+        return (_f(d) / F32(self.fac)).astype(F32)
+
+    def contract_points(self, p):
+        return (p / F32(self.fac)).astype(F32)
+
+
 def make_contract(cfg, dataset):
     if cfg is None:
         return IdentityContract()
     t = cfg['type']
+    if 'stop_iters' in cfg:
+        raise NotImplementedError('contract.stop_iters')
     if t == 'mipnerf':
         return MipNerfContract(cfg, dataset)
     if t == 'identity':
         return IdentityContract(cfg, dataset)
+    if t == 'bbox':
+        return BBoxContract(cfg, dataset)
+    if t == 'z_depth':
+        return ZDepthContract(cfg, dataset)
     raise NotImplementedError(f'contract {t} is outside the hot-path scope')
 
 
@@ -225,6 +283,34 @@ def intersect_cylinder(rays, radius):
     o = np.stack([rays[..., 0], rays[..., 2]], -1)
     d = np.stack([rays[..., 3], rays[..., 5]], -1)
     return _quadratic(o, d, radius)
+
+
+def _normalize(v):
+    """F.normalize(p=2, dim=-1, eps=1e-12)."""
+    n = np.sqrt(np.sum(v * v, -1, keepdims=True, dtype=F32))
+    return (v / np.maximum(n, F32(1e-12))).astype(F32)
+
+
+def _norm(v):
+    return np.sqrt(np.sum(v * v, -1, dtype=F32))
+
+
+def pluecker_pos(o, d):                                # nlf/param.py:297-307: closest point of the line to 0
+    d = _normalize(d)
+    m = np.cross(o, d).astype(F32)
+    return np.cross(d, m).astype(F32)
+
+
+def _xz(v):                                            # [x, 0, z]
+    return np.stack([v[..., 0], np.zeros_like(v[..., 1]), v[..., 2]], -1)
+
+
+def pluecker_pos_cylinder(o, d):                       # nlf/param.py:310-322
+    return pluecker_pos(_xz(o), _xz(d))
+
+
+def _signed_base_distance(d, diff):                    # sign(d . diff) * |diff|
+    return (np.sign(np.sum(d * diff, -1, dtype=F32)) * _norm(diff)).astype(F32)
 
 
 # --------------------------------------------------------------------------- grid_sample
@@ -418,13 +504,21 @@ class HyperReelOracle:
         self.use_sigma = c.get('use_sigma', False)
         self.in_density_field = c.get('in_density_field', 'sigma')
         self.sort = c.get('sort', False)
-        for k in ('weight_fn', 'sort_outputs', 'mask', 'dropout', 'normalize', 'residual_z',
-                  'residual_distance', 'clamp', 'use_local_prediction', 'num_repeat', 'flip_axes'):
+        for k in ('weight_fn', 'sort_outputs', 'dropout', 'normalize', 'residual_z',
+                  'residual_distance', 'clamp', 'use_local_prediction', 'flip_axes', 'max_axis'):
             if c.get(k):
                 raise NotImplementedError(f'intersect option {k} is outside the hot-path scope')
+        if c.get('num_repeat', 1) != 1:
+            raise NotImplementedError('intersect option num_repeat')
         if c.get('use_disparity', False):
             raise NotImplementedError('use_disparity')
+        # base.py:104-108,197-198: the near/far mask is dropped once cur_iter > mask.stop_iters (inference: 1e7)
+        stop = c['mask'].get('stop_iters', float('inf')) if 'mask' in c else float('inf')
+        self.mask_on = not (10_000_000 > stop)
         t = self.isect_type
+        if t == 'voxel_grid':                           # voxel.py:19-70: Z/3 planes per axis
+            self._setup_voxel_grid(c, udb)
+            return
         if t == 'z_plane':                              # z.py:25-71
             if udb:
                 initial, end = F32(-ds['near']), F32(-ds['far'])
@@ -438,6 +532,27 @@ class HyperReelOracle:
                 initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 1.0))
             self.origin_scale = F32(c.get('origin_scale_factor', 0.0))
             self.origin_initial = _f(c.get('origin_initial', [1.0, 1.0, 1.0]))
+        elif t in ('sphere_new', 'cylinder_new'):       # primitive.py:256-303, 441-488
+            if udb:
+                if c['outward_facing']:
+                    initial = F32(c['initial']) if 'initial' in c else F32(ds['near'] * 1.5)
+                else:
+                    initial = F32(c['initial']) if 'initial' in c else F32(-ds['far'] * 1.5)
+                end = F32(c['end']) if 'end' in c else F32(ds['far'] * 1.5)
+            else:
+                initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 1.0))
+            self.origin_scale = F32(c.get('origin_scale_factor', 0.0))
+            self.resize_scale = F32(c.get('resize_scale_factor', 0.0))
+            self.resize_initial = _f(c.get('resize_initial', [1.0, 1.0, 1.0]))
+        elif t == 'euclidean_distance_unified':         # primitive.py:131-160
+            if udb:
+                initial = F32(c['initial']) if 'initial' in c else F32(-ds['far'])
+                end = F32(c['end']) if 'end' in c else F32(ds['far'])
+            else:
+                initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 1.0))
+        elif t == 'euclidean_distance':                 # primitive.py:76-113 (use_dataset_bounds is not read)
+            initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 2.0))
+            self.min_radius = float(c.get('min_radius', 0.0))
         else:
             raise NotImplementedError(f'intersect {t} is outside the hot-path scope (SURVEY 8f-1)')
         if self.contract.contract_samples:
@@ -445,9 +560,39 @@ class HyperReelOracle:
             end = self.contract.contract_distance(end)
         self.samples = torch_linspace(initial, end, Z)
         if Z > 1:
-            self.z_scale = F32(c['z_scale']) if 'z_scale' in c else np.abs(self.samples[1] - self.samples[0])
+            if 'z_scale' in c:
+                self.z_scale = F32(c['z_scale'])
+            elif 'num_samples_for_scale' in c and t == 'z_plane':        # z.py:63-65
+                self.z_scale = np.abs(self.samples[1] - self.samples[0]) * F32(Z / float(c['num_samples_for_scale']))
+            else:
+                self.z_scale = np.abs(self.samples[1] - self.samples[0])
         else:
             self.z_scale = F32(c.get('z_scale', 1.0))
+        if t == 'euclidean_distance' and self.z_scale == 0.0:
+            self.z_scale = F32(1.0)
+
+    def _setup_voxel_grid(self, c, udb):
+        if self.Z % 3:
+            raise ValueError('voxel_grid needs z_channels divisible by 3')
+        nz = self.Z // 3
+        fac = c.get('fac', 1.0)
+        if udb:                                         # voxel.py:27-29: dataset bbox * fac
+            initial = _f(c['initial']) if 'initial' in c else (_f(self.ds['bbox_min']) * F32(fac)).astype(F32)
+            end = _f(c['end']) if 'end' in c else (_f(self.ds['bbox_max']) * F32(fac)).astype(F32)
+        else:
+            initial, end = _f(c.get('initial', [0.0, 0.0, 0.0])), _f(c.get('end', [1.0, 1.0, 1.0]))
+        if self.contract.contract_samples:
+            initial = self.contract.contract_distance(initial)
+            end = self.contract.contract_distance(end)
+        self.voxel_samples = np.stack([torch_linspace(initial[d], end[d], nz) for d in range(3)], -1)   # (Z/3, 3)
+        if 'z_scale' in c:
+            zs = _f(c['z_scale'])
+        elif nz > 1:
+            zs = np.abs(self.voxel_samples[1] - self.voxel_samples[0])
+        else:
+            zs = np.ones(3, F32)
+        self.voxel_scale = np.where(zs == 0, F32(1.0), zs).astype(F32)
+        self.outward_facing = bool(c.get('outward_facing', False))
 
     def _process_scalar_z(self, z):                     # base.py:128-140
         z = z * self.z_scale + self.samples[None]
@@ -464,16 +609,63 @@ class HyperReelOracle:
         else:
             sigma = np.zeros((B, self.Z), F32)
         zv = self.z_act(zv.reshape(B, self.Z, -1)) * (F32(1) - sigma[..., None])
-        if self.isect_type == 'z_plane':
+        t = self.isect_type
+        if t == 'z_plane':
             z = self._process_scalar_z(zv.reshape(B, self.Z))
             dists = intersect_axis_plane(r[:, None, :], z, 2)                 # z.py:88-95
-        else:
+        elif t in ('sphere', 'cylinder'):
             origins = zv[..., :3] * self.origin_scale + self.origin_initial[None, None]
             radii = self._process_scalar_z(zv[..., 3])
             rr = np.concatenate([r[:, None, 0:3] * origins, r[:, None, 3:6] * origins], -1)
-            dists = intersect_sphere(rr, radii) if self.isect_type == 'sphere' else intersect_cylinder(rr, radii)
-        mask = (dists <= F32(self.near)) | (dists >= F32(self.far))             # base.py:194
-        dists = np.where(mask, F32(0), dists)
+            dists = intersect_sphere(rr, radii) if t == 'sphere' else intersect_cylinder(rr, radii)
+        elif t in ('sphere_new', 'cylinder_new'):       # primitive.py:305-363, 490-545
+            origins = zv[..., :3] * self.origin_scale
+            resize = zv[..., 3:6] * self.resize_scale + self.resize_initial[None, None]
+            raw_offsets = self._process_scalar_z(zv[..., 6])
+            radii = self._process_scalar_z(zv[..., 7])
+            ro = ((r[:, None, 0:3] - origins) * resize).astype(F32)
+            rd = (r[:, None, 3:6] * resize).astype(F32)
+            rn = _normalize(rd)
+            rr = np.concatenate([ro, rn], -1)
+            if t == 'sphere_new':
+                tt = intersect_sphere(rr, radii)
+                base_pos = pluecker_pos(ro, rn)
+                min_radius = _norm(base_pos)             # min_sphere_radius, intersect_utils.py:27-33
+                base_distance = _signed_base_distance(rn, base_pos - ro)
+            else:
+                tt = intersect_cylinder(rr, radii)
+                base_pos = pluecker_pos_cylinder(ro, rn)
+                min_radius = _norm(base_pos)             # min_cylinder_radius, intersect_utils.py:35-43
+                o_c, d_c = _xz(ro), _xz(rn)
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    base_distance = (_signed_base_distance(d_c, base_pos - o_c) / _norm(d_c)).astype(F32)
+            recycle = np.abs(radii) < min_radius + F32(4) * self.z_scale       # samples on missed primitives
+            tt = np.where(recycle, raw_offsets + base_distance, tt)
+            dists = (tt / (_norm(rd) + F32(1e-5))).astype(F32)
+        elif t == 'euclidean_distance_unified':         # primitive.py:162-176
+            z = self._process_scalar_z(zv.reshape(B, self.Z))
+            diff = pluecker_pos(r[:, :3], r[:, 3:6]) - r[:, :3]
+            dists = (z + _signed_base_distance(r[:, 3:6], diff)[:, None]).astype(F32)
+        elif t == 'euclidean_distance':                 # primitive.py:115-128
+            z = self._process_scalar_z(zv.reshape(B, self.Z))
+            if self.min_radius > 0:
+                z = (z + (z - _norm(r[:, :3])[:, None])).astype(F32)
+            dists = z
+        elif t == 'voxel_grid':                         # voxel.py:72-112, intersect_utils.py:152-179
+            nz = self.Z // 3
+            z = zv.reshape(B, nz, 3) * self.voxel_scale[None, None] + self.voxel_samples[None]     # base.py:129
+            z = z.reshape(B, -1)
+            if self.contract.contract_samples:
+                z = self.contract.inverse_contract_distance(z)
+            z = z.astype(F32).reshape(B, nz, 3)
+            if self.outward_facing:
+                z = z * np.sign(r[:, None, 3:6])
+            dists = ((z - r[:, None, 0:3]) / _safe_dir(r[:, None, 3:6])).astype(F32).reshape(B, self.Z)
+        else:
+            raise NotImplementedError(t)
+        if self.mask_on:
+            mask = (dists <= F32(self.near)) | (dists >= F32(self.far))         # base.py:194
+            dists = np.where(mask, F32(0), dists)
         if self.sort:
             dists = np.sort(dists, axis=1)                                    # only dists is permuted
         dists = dists[..., None]
@@ -541,8 +733,8 @@ class HyperReelOracle:
                     x['base_times'] = np.repeat(rays[:, None, -1:], self.Z, 1)
                 if 'viewdirs' in eo and 'viewdirs' not in x:
                     x['viewdirs'] = np.repeat(rays[:, None, 3:6], self.Z, 1)
-            elif typ == 'extract_fields':
-                pass                                     # we keep everything for diagnostics
+            elif typ == 'extract_fields':               # point.py:236-244: the colour net only sees these
+                x['_extracted'] = set(ecfg['fields'])
             else:
                 raise NotImplementedError(f'embedding {typ} is outside the hot-path scope')
         return x
@@ -655,11 +847,19 @@ class HyperReelOracle:
                 sh = eval_sh_bases_deg2(viewdirs[app])[:, None]
                 col = np.maximum(np.sum(sh * feat.reshape(-1, 3, 9), -1, dtype=F32) + F32(0.5), F32(0))
             rgb[app] = col
-        if 'color_scale' in x:                           # tensorf_utils.py:267-273
+        seen = x.get('_extracted')
+        has = lambda k: k in x and (seen is None or k in seen)
+        if has('color_scale'):                           # tensorf_utils.py:267-273
             rgb = rgb * (x['color_scale'] + F32(1.0)) + x['color_shift']
+        elif has('color_transform'):
+            raise NotImplementedError('per-sample color_transform')
         rgb_map = np.sum(weight[..., None] * rgb, -2, dtype=F32)
         if self.white_bg:
             rgb_map = rgb_map + (F32(1.0) - weight.sum(-1, dtype=F32)[:, None])
+        if has('color_scale_global'):                    # scale_shift_color_one, tensorf_utils.py:275-281: sample 0's head
+            rgb_map = rgb_map * (x['color_scale_global'][:, 0, :] + F32(1.0)) + x['color_shift_global'][:, 0, :]
+        elif has('color_transform_global'):
+            raise NotImplementedError('color_transform_global')
         rgb_map = np.clip(rgb_map, F32(0), F32(1)).astype(F32)
         return {'rgb': rgb_map, 'sigma': sigma, 'alpha': alpha, 'render_weights': weight,
                 'valid': valid, 'rgb_samples': rgb.astype(F32)}
@@ -674,6 +874,8 @@ class HyperReelOracle:
             c = self.color(x)
             x.update(c)
             for k, v in x.items():
+                if not isinstance(v, np.ndarray):
+                    continue
                 if keep == 'all' or k in keep:
                     outs.setdefault(k, []).append(v)
         return {k: np.concatenate(v, 0) for k, v in outs.items()}

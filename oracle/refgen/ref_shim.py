@@ -141,7 +141,8 @@ def load_model_cfg(name, overrides=None, iters_per_epoch=4000):
 
 def make_system(dataset):
     """Stub of the INRSystem attributes the hot-path constructors read."""
-    td = SimpleNamespace(**dataset)
+    td = SimpleNamespace(**{k: (torch.tensor(v, dtype=torch.float32) if k in ('bbox_min', 'bbox_max') else v)
+                            for k, v in dataset.items()})
     return SimpleNamespace(
         dm=SimpleNamespace(train_dataset=td),
         cfg=to_attr({'dataset': {'collection': dataset.get('collection', 'synthetic'),

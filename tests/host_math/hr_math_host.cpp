@@ -32,7 +32,7 @@ void hm_embed(const hr_config* c, const float* rays, const float* head, int n, f
         for (int k = 0; k < Z; ++k) d[k] = hr_sample_distance(*c, h + k * P, k, ro, rd);
         if (c->sort) std::sort(d.begin(), d.end());
         float oc[3] = {0, 0, 0};
-        if (c->contract_type == HR_CONTRACT_MIPNERF) hr_contract_point(*c, ro[0], ro[1], ro[2], oc);
+        if (c->contract_type != HR_CONTRACT_IDENTITY) hr_contract_point(*c, ro[0], ro[1], ro[2], oc);
         float t = r[c->ray_dim - 1], base_t = 0.f, toff = 0.f;
         if (c->advect) { base_t = hr_base_time(*c, t); toff = t - base_t; }
         base_t_out[i] = base_t;

@@ -73,8 +73,11 @@ def test_compile_config_matches_oracle_constants(name):
 def test_out_of_scope_keys_raise():
     ds = C.dataset_scalars('donerf')
     cfg = C.model_config('donerf_sphere')
-    cfg.embedding.embeddings.ray_intersect_0.intersect.type = 'voxel_grid'
-    with pytest.raises(NotImplementedError, match='voxel_grid'):
+    cfg.embedding.embeddings.ray_intersect_0.intersect.type = 'deformable_voxel_grid'
+    with pytest.raises(NotImplementedError, match='deformable_voxel_grid'):
+        plan.compile_config(cfg, ds, [8, 8, 8])
+    cfg.embedding.embeddings.ray_intersect_0.intersect.type = 'voxel_grid'     # needs a 1-channel z_vals head
+    with pytest.raises(ValueError, match='z_vals channels'):
         plan.compile_config(cfg, ds, [8, 8, 8])
     cfg = C.model_config('donerf_sphere')
     cfg.color.net.shadingMode = 'MLP_Fea'

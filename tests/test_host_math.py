@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import Golden, golden_cases, linf
+from helpers import Golden, golden_cases, linf, sweep_cases
 from hyperreel_amd import plan
 from hyperreel_oracle import HyperReelOracle, eval_sh_bases_deg2, grid_sample_2d
 
@@ -45,7 +45,7 @@ def test_config_struct_layout_matches_c(hm):
 SMALL = [c for c in golden_cases() if c.endswith('_small') or c.startswith('config1')]
 
 
-@pytest.mark.parametrize('case', SMALL)
+@pytest.mark.parametrize('case', SMALL + sweep_cases())
 def test_features_and_embedding_match_oracle(hm, case):
     g = Golden(case)
     hc = plan.compile_config(g.cfg, g.dataset, g.grid)
