@@ -79,7 +79,7 @@ int layer_in(const hr_config& c, int l)
 
 int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? c.z_channels * c.preds_per_z : c.mlp_hidden; }
 
-// z_vals channels read per sample: z (z_plane, euclidean*, voxel_grid), origin xyz + radius
+// z_vals channels read per sample: z (z_plane, euclidean_distance_unified, voxel_grid), origin xyz + radius
 // (sphere/cylinder), origin xyz + resize xyz + raw offset + radius (sphere_new/cylinder_new)
 int isect_z_channels(int t)
 {

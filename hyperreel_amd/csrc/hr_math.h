@@ -327,17 +327,12 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
         const float d = (axis == 0) ? rd[0] : (axis == 1) ? rd[1] : rd[2];
         if (c.isect_outward) z = z * hr_sign(d);
         dist = hr_axis_plane_t(z, o, d);                             // intersect_utils.py:152-179
-    } else {
+    } else {                                                         // euclidean_distance_unified, primitive.py:162-176
         float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);
-        if (c.isect_type == HR_ISECT_EUCLIDEAN_UNIFIED) {            // primitive.py:162-176
-            float pos[3];
-            hr_pluecker_pos(ro, rd, pos);
-            const float diff[3] = {pos[0] - ro[0], pos[1] - ro[1], pos[2] - ro[2]};
-            dist = z + hr_signed_base_distance(rd, diff);
-        } else {                                                     // primitive.py:115-128
-            dist = z;
-            if (c.isect_min_radius > 0.0f) dist = z + (z - HR_SQRT(ro[0] * ro[0] + ro[1] * ro[1] + ro[2] * ro[2]));
-        }
+        float pos[3];
+        hr_pluecker_pos(ro, rd, pos);
+        const float diff[3] = {pos[0] - ro[0], pos[1] - ro[1], pos[2] - ro[2]};
+        dist = z + hr_signed_base_distance(rd, diff);
     }
     if (!c.isect_mask_off) {
         bool mask = (dist <= c.near) || (dist >= c.far);             // base.py:194

@@ -33,9 +33,9 @@ HR_MAX_MLP_IN = 64
 ACT = {'identity': 0, 'sigmoid': 1, 'tanh': 2}
 PARAM = {'identity': 0, 'pluecker': 1, 'two_plane': 2}
 PE = {None: 0, 'windowed': 1, 'basic': 2}
-ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2, 'sphere_new': 3, 'cylinder_new': 4, 'euclidean_distance': 5,
-         'euclidean_distance_unified': 6, 'voxel_grid': 7}
-ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1, 7: 1}     # z_vals channels each type reads per sample
+ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2, 'sphere_new': 3, 'cylinder_new': 4, 'euclidean_distance_unified': 5,
+         'voxel_grid': 6}
+ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1}     # z_vals channels each type reads per sample
 CONTRACT = {'identity': 0, 'mipnerf': 1, 'bbox': 2, 'z_depth': 2}   # bbox and z_depth share the affine kernel path
 DENSITY = {'relu': 0, 'softplus': 1, 'relu_abs': 2}
 SHADING = {'RGB': 0, 'SH': 1}
@@ -66,7 +66,7 @@ class hr_config(C.Structure):
         ('isect_type', C.c_int32), ('isect_origin', C.c_float * 3), ('near', C.c_float), ('far', C.c_float),
         ('z_act', hr_act), ('sort', C.c_int32), ('samples', C.c_float * HR_MAX_Z), ('z_scale', C.c_float),
         ('origin_scale', C.c_float), ('origin_initial', C.c_float * 3),
-        ('resize_scale', C.c_float), ('resize_initial', C.c_float * 3), ('isect_min_radius', C.c_float),
+        ('resize_scale', C.c_float), ('resize_initial', C.c_float * 3),
         ('voxel_scale', C.c_float * 3), ('isect_outward', C.c_int32), ('isect_mask_off', C.c_int32),
         ('contract_type', C.c_int32), ('contract_samples', C.c_int32),
         ('c_r0', C.c_float), ('c_r_inv_end', C.c_float), ('c_r_scale', C.c_float),
@@ -440,15 +440,12 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
         ri = ic.get('resize_initial', [1.0, 1.0, 1.0])
         for k in range(3):
             hc.resize_initial[k] = float(ri[k])
-    elif t == 'euclidean_distance_unified':   # primitive.py:131-160
+    else:                                     # euclidean_distance_unified, primitive.py:131-160
         if udb:
             initial = F32(ic['initial']) if 'initial' in ic else F32(-dataset['far'])
             end = F32(ic['end']) if 'end' in ic else F32(dataset['far'])
         else:
             initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
-    else:                                     # euclidean_distance, primitive.py:76-113
-        initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 2.0))
-        hc.isect_min_radius = float(ic.get('min_radius', 0.0))
     if t != 'voxel_grid':
         samples = torch_linspace_f32(cdist(initial), cdist(end), Z)
         for k in range(Z):
@@ -462,8 +459,6 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
                 zs = np.abs(samples[1] - samples[0])
         else:
             zs = F32(ic.get('z_scale', 1.0))
-        if t == 'euclidean_distance' and zs == 0:
-            zs = F32(1.0)
         hc.z_scale = float(zs)
 
     # ---- advect / offset --------------------------------------------------------------

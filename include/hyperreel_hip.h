@@ -77,11 +77,12 @@ typedef struct hr_head_field {
 } hr_head_field;
 
 /* nlf/intersect: z.py:15-97 (z_plane), primitive.py:366-438 (sphere), :181-253 (cylinder), :441-545
- * (sphere_new), :256-363 (cylinder_new), :76-128 (euclidean_distance), :131-176
- * (euclidean_distance_unified), voxel.py:19-112 (voxel_grid) */
+ * (sphere_new), :256-363 (cylinder_new), :131-176 (euclidean_distance_unified), voxel.py:19-112
+ * (voxel_grid).  `plane` and `euclidean_distance` cannot run in the reference itself (their scalar
+ * z_scale breaks Intersect.process_z_vals, base.py:129), so there is nothing to be compatible with. */
 enum {
     HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2, HR_ISECT_SPHERE_NEW = 3,
-    HR_ISECT_CYLINDER_NEW = 4, HR_ISECT_EUCLIDEAN = 5, HR_ISECT_EUCLIDEAN_UNIFIED = 6, HR_ISECT_VOXEL_GRID = 7
+    HR_ISECT_CYLINDER_NEW = 4, HR_ISECT_EUCLIDEAN_UNIFIED = 5, HR_ISECT_VOXEL_GRID = 6
 };
 /* nlf/contract.py: IdentityContract (:53-62), MIPNeRFContract (:113-192); BBoxContract (:65-87) and
  * ZDepthContract (:90-111) are both the affine map p -> (p - c_aff_min) / c_aff_size, d -> d / c_aff_fac */
@@ -129,7 +130,6 @@ typedef struct hr_config {
     float origin_initial[3];             /*   (*_new: origins = z[:3]*origin_scale, primitive.py:490-492) */
     float resize_scale;                  /* *_new: resize = z[3:6]*resize_scale + resize_initial (:494-496) */
     float resize_initial[3];
-    float isect_min_radius;              /* euclidean_distance: min_radius (> 0 adds z - |o|) */
     float voxel_scale[3];                /* voxel_grid: per-axis z_scale; samples[] is (Z/3, 3) row-major */
     int32_t isect_outward;               /* voxel_grid: outward_facing (planes mirrored by sign(d)) */
     int32_t isect_mask_off;              /* mask.stop_iters passed: no near/far masking (base.py:197-198) */

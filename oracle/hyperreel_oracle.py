@@ -550,11 +550,9 @@ class HyperReelOracle:
                 end = F32(c['end']) if 'end' in c else F32(ds['far'])
             else:
                 initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 1.0))
-        elif t == 'euclidean_distance':                 # primitive.py:76-113 (use_dataset_bounds is not read)
-            initial, end = F32(c.get('initial', 0.0)), F32(c.get('end', 2.0))
-            self.min_radius = float(c.get('min_radius', 0.0))
         else:
-            raise NotImplementedError(f'intersect {t} is outside the hot-path scope (SURVEY 8f-1)')
+            raise NotImplementedError(f'intersect {t} is outside the hot-path scope (SURVEY 8f-1; `plane` and '
+                                      f'`euclidean_distance` cannot run in the reference: scalar z_scale, base.py:129)')
         if self.contract.contract_samples:
             initial = self.contract.contract_distance(initial)
             end = self.contract.contract_distance(end)
@@ -568,8 +566,6 @@ class HyperReelOracle:
                 self.z_scale = np.abs(self.samples[1] - self.samples[0])
         else:
             self.z_scale = F32(c.get('z_scale', 1.0))
-        if t == 'euclidean_distance' and self.z_scale == 0.0:
-            self.z_scale = F32(1.0)
 
     def _setup_voxel_grid(self, c, udb):
         if self.Z % 3:
@@ -646,11 +642,6 @@ class HyperReelOracle:
             z = self._process_scalar_z(zv.reshape(B, self.Z))
             diff = pluecker_pos(r[:, :3], r[:, 3:6]) - r[:, :3]
             dists = (z + _signed_base_distance(r[:, 3:6], diff)[:, None]).astype(F32)
-        elif t == 'euclidean_distance':                 # primitive.py:115-128
-            z = self._process_scalar_z(zv.reshape(B, self.Z))
-            if self.min_radius > 0:
-                z = (z + (z - _norm(r[:, :3])[:, None])).astype(F32)
-            dists = z
         elif t == 'voxel_grid':                         # voxel.py:72-112, intersect_utils.py:152-179
             nz = self.Z // 3
             z = zv.reshape(B, nz, 3) * self.voxel_scale[None, None] + self.voxel_samples[None]     # base.py:129

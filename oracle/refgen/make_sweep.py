@@ -54,11 +54,68 @@ def sweep_rays(cfg, seed):
     z_plane = isect.intersect.type == 'z_plane'
     if z_plane:
         r = scenes.random_rays(88, seed, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
+    elif isect.intersect.type in ('sphere_new', 'cylinder_new'):
+        # half of the rays start well off-centre so that they MISS the inner primitives and take the
+        # sample-recycling branch (primitive.py:536-541)
+        r = np.concatenate([scenes.random_rays(44, seed, video), scenes.random_rays(44, seed + 1000, video, pos_std=1.2)], 0)
     else:
         r = scenes.random_rays(88, seed, video)
     ray_dim = r.shape[1]
     sp = special_rays(ray_dim == 8, z_plane)
     return np.ascontiguousarray(np.concatenate([r, sp], 0), np.float32)
+
+
+# Options the reference implements but no shipped YAML selects: a shipped YAML plus an edit, run through the
+# reference like the others.  (name, base YAML, edit applied to both the reference's and our config)
+def _isect(cfg):
+    return [e for e in cfg.embedding.embeddings.values() if e.get('type') == 'ray_intersect'][0].intersect
+
+
+def _pred(cfg):
+    return [e for e in cfg.embedding.embeddings.values() if e.get('type') == 'ray_prediction'][0]
+
+
+def _v_cylinder_new(cfg):
+    ic = _isect(cfg)
+    ic.type = 'cylinder_new'
+    ic.origin_scale_factor = 0.3
+    ic.resize_scale_factor = 0.25
+    _pred(cfg).outputs.z_vals.channels = 8
+
+
+def _v_sphere_new_origins_only(cfg):          # origins live, resize dead: head-column compaction with a gap
+    ic = _isect(cfg)
+    ic.origin_scale_factor = 0.4
+    ic.resize_scale_factor = 0.0
+
+
+def _v_z_depth(cfg):
+    ic = _isect(cfg)
+    ic.contract = {'type': 'z_depth', 'contract_samples': True, 'contract_end_radius': 6.0}
+
+
+def _v_voxel_outward(cfg):
+    ic = _isect(cfg)
+    ic.outward_facing = True
+    ic.use_dataset_bounds = False
+    ic.initial = [0.1, 0.15, 0.2]
+    ic.end = [1.9, 1.7, 1.8]
+    ic.z_scale = [0.05, 0.04, 0.06]
+
+
+def _v_mask_off_unsorted(cfg):
+    ic = _isect(cfg)
+    ic.mask = {'stop_iters': 5}
+    ic.sort = False
+
+
+VARIANTS = [
+    ('variant_cylinder_new', 'bom_cylinder', _v_cylinder_new),
+    ('variant_sphere_new_origins_only', 'immersive_sphere_new', _v_sphere_new_origins_only),
+    ('variant_z_depth_contract', 'llff_z_plane', _v_z_depth),
+    ('variant_voxel_outward', 'donerf_voxel', _v_voxel_outward),
+    ('variant_mask_off_unsorted', 'donerf_sphere', _v_mask_off_unsorted),
+]
 
 
 def main(only=None, force=False):
@@ -67,16 +124,20 @@ def main(only=None, force=False):
     os.makedirs(OUT, exist_ok=True)
     coverage = {}
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(f'{ref_shim.REF}/conf/experiment/model/*.yaml'))
-    for i, name in enumerate(names):
+    jobs = [(n, n, None) for n in names] + VARIANTS
+    for i, (name, base, edit) in enumerate(jobs):
         if only and name not in only:
             continue
-        path = f'{ref_shim.REF}/conf/experiment/model/{name}.yaml'
-        ds = dataset_for(name)
+        path = f'{ref_shim.REF}/conf/experiment/model/{base}.yaml'
+        ds = dataset_for(base)
         raw = C.load_model_yaml(path)
         if raw is None:
             coverage[name] = {'status': 'rejected', 'reason': 'the shipped YAML is empty'}
             continue
         raw.color.net.grid_size = C.to_cfg({'start': list(GRID), 'end': list(GRID)})
+        if edit:
+            edit(raw)
+            raw = C.to_cfg(C.to_plain(raw))
         model_cfg = C.epoch_to_iter(C.to_cfg(C.to_plain(raw)), 4000)
         rejected = None
         try:
@@ -90,7 +151,11 @@ def main(only=None, force=False):
 
         def overrides(cfg):
             cfg.color.net.grid_size = ref_shim.to_attr({'start': list(GRID), 'end': list(GRID)})
-        ref_cfg = ref_shim.load_model_cfg(name, overrides)
+            if edit:
+                edit(cfg)
+                for k, v in list(_isect(cfg).items()):      # plain dicts written by an edit -> attr dicts
+                    _isect(cfg)[k] = ref_shim.to_attr(v)
+        ref_cfg = ref_shim.load_model_cfg(base, overrides)
         fn = ref_shim.build_reference(ref_cfg, ds)
         seed = 100 + i
         sd = scenes.make_state_dict(model_cfg, ds, GRID, seed, 'dense', 1.0)
@@ -132,8 +197,9 @@ def main(only=None, force=False):
     if not only and not force:
         with open(os.path.join(OUT, 'coverage.json'), 'w') as f:
             json.dump(coverage, f, indent=1, sort_keys=True)
-    n_ok = sum(1 for v in coverage.values() if v['status'] == 'golden')
-    print(f'{n_ok} of {len(coverage)} shipped model YAMLs covered')
+    n_ok = sum(1 for k, v in coverage.items() if v['status'] == 'golden' and not k.startswith('variant_'))
+    n_all = sum(1 for k in coverage if not k.startswith('variant_'))
+    print(f'{n_ok} of {n_all} shipped model YAMLs covered (+ {sum(1 for k in coverage if k.startswith("variant_"))} variants)')
 
 
 if __name__ == '__main__':
