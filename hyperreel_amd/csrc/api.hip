@@ -445,7 +445,14 @@ int hr_model_finalize(hr_model* m)
     HR_HIP(hipDeviceSynchronize());
     HR_HIP(hipGetLastError());
     m->finalized = true;
-    if (m->chunk == 0) return hr_model_reserve(m, 131072);   // measured best among 16k..640k rays per launch
+    if (m->chunk == 0) {
+        // 131072 rays per launch measured best among 16k..640k (DoNeRF); wide heads (z_channels up to 256)
+        // are held to a 512 MiB workspace
+        const int64_t nq = ((int64_t)m->cfg.z_channels * m->p_live + 3) / 4;
+        int64_t rays = (512ll << 20) / (nq * 16);
+        rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
+        return hr_model_reserve(m, rays);
+    }
     return HR_OK;
 }
 

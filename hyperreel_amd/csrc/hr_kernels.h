@@ -2,8 +2,8 @@
 #ifndef HR_KERNELS_H
 #define HR_KERNELS_H
 
-// samples per ray the sample kernel handles (one wave per ray); hr_config.samples holds HR_MAX_Z
-#define HR_KERNEL_MAX_Z 64
+// samples per ray the sample kernel handles (a 256-thread block per ray at most)
+#define HR_KERNEL_MAX_Z 256
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -8,7 +8,8 @@
 //    raw2alpha, utils/tensorf_utils.py:242-253).
 //
 // CDNA4 mapping
-//   * the Z samples of a ray sit in adjacent lanes of ONE wavefront (ZP = 16/32/64 lanes),
+//   * the Z samples of a ray sit in adjacent lanes of ONE wavefront (ZP = 8/16/32/64 lanes; z_channels
+//     above 64 spread a ray over 2 or 4 wavefronts of the block and add LDS hand-overs),
 //     so the per-ray sort is an in-register bitonic network over DPP/bpermute shuffles,
 //     the transmittance is a wave-level segmented prefix product and the final colour a
 //     segmented butterfly sum -- no LDS round trips, no atomics, no global intermediates;
@@ -28,14 +29,27 @@
 
 #define HR_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
+// ZP > 64 (z_channels 65..256): the lanes of one ray span ZP/64 wavefronts of the block, and the steps
+// that cross a wavefront go through a 256-float LDS scratch `s_x`.  Returns the value thread
+// `src_tid` of the block holds.
+__device__ __forceinline__ float hr_block_exchange(float v, int src_tid, float* s_x)
+{
+    __syncthreads();
+    s_x[threadIdx.x] = v;
+    __syncthreads();
+    return s_x[src_tid];
+}
+
 template <int ZP>
-__device__ __forceinline__ float hr_bitonic_sort(float v, int k)
+__device__ __forceinline__ float hr_bitonic_sort(float v, int k, float* s_x)
 {
 #pragma unroll
     for (int size = 2; size <= ZP; size <<= 1) {
 #pragma unroll
         for (int j = size >> 1; j > 0; j >>= 1) {
-            const float o = __shfl_xor(v, j, 64);
+            float o;
+            if (j < 64) o = __shfl_xor(v, j, 64);
+            else o = hr_block_exchange(v, (int)threadIdx.x ^ j, s_x);
             const bool up = ((k & size) == 0);
             const bool lower = ((k & j) == 0);
             const float mn = fminf(v, o), mx = fmaxf(v, o);
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     const int HS = a.nq * 4 + 4;                   // LDS row stride of a ray's head (+4: conflict-free float4 fills)
     float* s_head = lds;                           // [RPB][HS]
     float* s_M = lds + RPB * HS;                   // [RPB][3][CA]
+    float* s_x = s_M + RPB * 3 * CA;               // [256] cross-wave scratch, ZP > 64 only
+    constexpr int ZW = (ZP < 64) ? ZP : 64;        // lanes of a ray inside one wavefront
+    constexpr int WPR = (ZP + 63) / 64;            // wavefronts per ray
 
     const int tid = threadIdx.x;
     const int rib = tid / ZP;
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     // ---- distances: intersect + mask, then sort along the ray (base.py:152-210)
     float dist = __builtin_inff();
     if (lane_ok) dist = hr_sample_distance(cfg, hk, k, ro, rd);
-    if (cfg.sort) dist = hr_bitonic_sort<ZP>(dist, k);
+    if (cfg.sort) dist = hr_bitonic_sort<ZP>(dist, k, s_x);
 
     // ---- points, contraction, advect, offset
     float oc[3] = {0.f, 0.f, 0.f};
@@ -223,7 +240,9 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     if (lane_ok) hr_sample_point(cfg, hk, dist, ro, rd, oc, time_off, p, &dist_c);
 
     // deltas (tensorf_no_sample.py:137-144)
-    const float dist_next = __shfl_down(dist_c, 1, 64);
+    float dist_next;
+    if constexpr (ZP > 64) dist_next = hr_block_exchange(dist_c, min(tid + 1, 255), s_x);
+    else dist_next = __shfl_down(dist_c, 1, 64);
     const float delta = (k == Z - 1) ? 1e10f : (dist_next - dist_c);
 
     // ---- feature gather
@@ -245,13 +264,23 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     const float sigma = valid ? hr_density(cfg, sig_feat) : 0.0f;
     const float alpha = lane_ok ? (1.0f - HR_EXP(-sigma * (delta * cfg.distance_scale))) : 0.0f;
     float inc = lane_ok ? ((1.0f - alpha) + 1e-10f) : 1.0f;
+    const int kw = k & (ZW - 1);                   // position inside this wavefront's part of the ray
 #pragma unroll
-    for (int d = 1; d < ZP; d <<= 1) {
+    for (int d = 1; d < ZW; d <<= 1) {
         const float o = __shfl_up(inc, d, 64);
-        if (k >= d) inc = inc * o;
+        if (kw >= d) inc = inc * o;
+    }
+    float before = 1.0f;                           // product over the ray's earlier wavefronts
+    if constexpr (ZP > 64) {
+        __syncthreads();
+        if ((tid & 63) == 63) s_x[tid >> 6] = inc;
+        __syncthreads();
+        const int w = tid >> 6, w0 = (w / WPR) * WPR;
+        for (int i = w0; i < w; ++i) before = before * s_x[i];
+        inc = inc * before;
     }
     float T = __shfl_up(inc, 1, 64);
-    if (k == 0) T = 1.0f;
+    if (kw == 0) T = before;                       // == 1 for the ray's first sample
     const float weight = alpha * T;
 
     // ---- colour decode (+ per-sample scale/shift) and front-to-back sum
@@ -276,11 +305,24 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
     }
     float acc_w = lane_ok ? weight : 0.0f;
 #pragma unroll
-    for (int d = ZP >> 1; d > 0; d >>= 1) {
+    for (int d = ZW >> 1; d > 0; d >>= 1) {
         c0 += __shfl_xor(c0, d, 64);
         c1 += __shfl_xor(c1, d, 64);
         c2 += __shfl_xor(c2, d, 64);
         acc_w += __shfl_xor(acc_w, d, 64);
+    }
+    if constexpr (ZP > 64) {                       // add the ray's wavefronts in order
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            float* o = s_x + 4 * (tid >> 6);
+            o[0] = c0; o[1] = c1; o[2] = c2; o[3] = acc_w;
+        }
+        __syncthreads();
+        const int w0 = ((tid >> 6) / WPR) * WPR;
+        c0 = s_x[4 * w0 + 0]; c1 = s_x[4 * w0 + 1]; c2 = s_x[4 * w0 + 2]; acc_w = s_x[4 * w0 + 3];
+        for (int i = 1; i < WPR; ++i) {
+            c0 += s_x[4 * (w0 + i) + 0]; c1 += s_x[4 * (w0 + i) + 1]; c2 += s_x[4 * (w0 + i) + 2]; acc_w += s_x[4 * (w0 + i) + 3];
+        }
     }
     if (ray_ok && k == 0) {
         if (cfg.white_bg) {                        // tensorf_no_sample.py:236-237
@@ -316,7 +358,7 @@ __global__ __launch_bounds__(256) void hr_sample_kernel(const hr_config cfg, con
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP)
 {
     const int RPB = 256 / ZP;
-    return ((size_t)RPB * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total) * sizeof(float);
+    return ((size_t)RPB * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total + (ZP > 64 ? 256 : 0)) * sizeof(float);
 }
 
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream)
@@ -336,6 +378,8 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
         case 16: hipLaunchKernelGGL(hr_sample_kernel<16>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
         case 32: hipLaunchKernelGGL(hr_sample_kernel<32>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
         case 64: hipLaunchKernelGGL(hr_sample_kernel<64>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
-        default: break;  // Z > 64 is rejected by hr_model_create
+        case 128: hipLaunchKernelGGL(hr_sample_kernel<128>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
+        case 256: hipLaunchKernelGGL(hr_sample_kernel<256>, dim3(blocks), dim3(256), lds, stream, cfg, args2); break;
+        default: break;  // Z > 256 is rejected by hr_model_create
     }
 }

@@ -25,7 +25,7 @@ import numpy as np
 F32 = np.float32
 
 HR_MAX_Z = 256          # size of hr_config.samples
-HR_KERNEL_MAX_Z = 64    # what the sample kernel handles today (one wave per ray)
+HR_KERNEL_MAX_Z = 256   # what the sample kernel handles (a 256-thread block per ray at most)
 HR_MAX_GROUPS = 4
 HR_MAX_LAYERS = 8
 HR_MAX_MLP_IN = 64

@@ -260,6 +260,11 @@ VARIANTS = {
     # Z that is not a power of two: lanes beyond Z idle, sort pads with +inf
     'z24_sphere': lambda: _variant('donerf_sphere', lambda c: None, Z=24),
     'z7_zplane': lambda: _variant('technicolor_z_plane', lambda c: None, Z=7),
+    # more than 64 samples per ray: a ray spans 2 or 4 wavefronts (LDS hand-overs in sort / scan / sum)
+    'z96_sphere': lambda: _variant('donerf_sphere', lambda c: None, Z=96),
+    'z128_zplane': lambda: _variant('technicolor_z_plane', lambda c: None, Z=128),
+    'z200_cylinder': lambda: _variant('donerf_cylinder', lambda c: None, Z=200),
+    'z256_video_sphere': lambda: _variant('immersive_sphere', lambda c: None, Z=256),
     # sphere origins actually driven by the network (origin_scale_factor != 0): no column pruning
     'sphere_origin_scale': lambda: _variant('donerf_sphere', lambda c: _emb(c).ray_intersect_0.intersect.update(origin_scale_factor=0.05)),
     # hidden width 128: exact fp32-MFMA kernel (the split kernel needs 256)
@@ -292,7 +297,7 @@ def test_config_variants_match_oracle(variant):
     from gpu_common import make_render_fn, render_np
     from hyperreel_oracle import HyperReelOracle
     cfg = VARIANTS[variant]()
-    base = 'immersive' if 'video_rgb' in variant else ('neural_3d' if 'video_odd' in variant else
+    base = 'immersive' if ('video_rgb' in variant or 'video_sphere' in variant) else ('neural_3d' if 'video_odd' in variant else
                                                         ('technicolor' if 'zplane' in variant else 'donerf'))
     ds = C.dataset_scalars(base)
     grid = [33, 27, 30]
