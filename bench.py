@@ -40,7 +40,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) 
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak
 
 
-def algorithmic_bytes_per_ray(cfg, video):
+def algorithmic_bytes_per_ray(cfg, video, texel_bytes=4):
     """4*R_in + 12 + Z*(G_d + G_a), G = sum_i C_i * T * 4 bytes,
     T = 6 texels/channel (static VM: 4 plane + 2 line) or 8 (video: 4 space + 4 time)."""
     pred = cfg['embedding']['embeddings']['ray_prediction_0']
@@ -50,7 +50,7 @@ def algorithmic_bytes_per_ray(cfg, video):
     nd, na = list(n['n_lamb_sigma']), list(n['n_lamb_sh'])
     if video:  # plane pairs without density components are skipped altogether
         na = [a if d > 0 else 0 for a, d in zip(na, nd)]
-    G = (sum(nd) + sum(na)) * T * 4
+    G = (sum(nd) + sum(na)) * T * texel_bytes          # 'fp16 grids: halve the G terms' 
     return 4 * (8 if video else 6) + 12 + Z * G
 
 
@@ -116,6 +116,9 @@ def main():
     ap.add_argument('--torch-gpu', action='store_true', help='also time the PyTorch-ROCm port of the reference algorithm on this GPU')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'fp32'],
                     help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
+                    help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -137,7 +140,11 @@ def main():
     video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
-    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision)
+    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision, grid_dtype=args.grid_dtype)
+    texel_bytes = 2 if args.grid_dtype == 'fp16' else 4
+    # checker-side weights: with float16 texels the reference algorithm is run on the same rounded grids
+    sd_ref = sd if texel_bytes == 4 else {k: (v.astype(np.float16).astype(np.float32) if ('_plane' in k or '_line' in k) else v)
+                                          for k, v in sd.items()}
     fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     # tile of this rank: the same camera, panned by the tile index (weak scaling)
     rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
@@ -153,8 +160,29 @@ def main():
     model.native()
     gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if world > 1 else None
 
+    # One frame = hr_render's kernel launches.  They are captured once into a hipGraph and replayed per
+    # step (the library neither allocates nor synchronises inside hr_render), so a slow host thread
+    # cannot starve the GPU between launches; --no-graph enqueues them eagerly from Python instead.
+    graph = None
+    if not args.no_graph:
+        model.render(rays)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.render(rays)                       # warm the side stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rgb_static = model.render(rays)['rgb']
+
     def step():
-        rgb = model.render(rays)['rgb']
+        if graph is not None:
+            graph.replay()
+            rgb = rgb_static
+        else:
+            rgb = model.render(rays)['rgb']
         if world > 1:
             dist.all_gather_into_tensor(gathered.view(-1), rgb.view(-1))
         return rgb
@@ -223,7 +251,7 @@ def main():
         smp_ms = time_stage(run_samples, reps)
         nl = len(offs)
         flops = mlp_flops_per_ray(cfg) * B
-        byts = algorithmic_bytes_per_ray(cfg, video) * B
+        byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
         split = model._hc.mlp_precision == 1
         peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
         r_mlp = {'kernel': 'hr_mlp_bf16x3_kernel' if split else 'hr_mlp_kernel', 'bound': 'mfma',
@@ -237,14 +265,14 @@ def main():
         r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
-                 'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video)} B/ray x {min(chunk, B)} rays'}
+                 'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays'}
         # HBM-side traffic per launch: measured separately with rocprofv3 --pmc (never inside a timed
         # run) and committed under profiles/; attached only when the workload matches the profiled one
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
             w = tr['workload']
             if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
-                    and (w['mlp_precision'] == 'bf16x3') == split):
+                    and (w['mlp_precision'] == 'bf16x3') == split and texel_bytes == 4):
                 r_mlp['traffic'] = tr[r_mlp['kernel']]['traffic_bytes'] if r_mlp['kernel'] in tr else None
                 r_smp['traffic'] = tr['hr_sample_kernel']['traffic_bytes']
                 r_mlp['traffic_unit'] = r_smp['traffic_unit'] = 'bytes per launch (profiles/r01_traffic.json)'
@@ -257,13 +285,15 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd, rays_np, min(args.cpu_sample, B))
+        v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd_ref, rays_np, min(args.cpu_sample, B))
         got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
         result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                   'sample': f'{len(idx)} rays of the same frame through oracle/torch_port.py (the reference\'s '
                                             f'algorithm on PyTorch CPU ops, fp32, chunk 16384) in {secs:.1f} s'}
         result['parity_vs_oracle_linf'] = float(np.abs(got - ref_rgb).max())
 
+    result['grid_dtype'] = args.grid_dtype
+    result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else 'hipGraph replay of one captured frame'
     result['mlp_gemm'] = ('bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)'
                           if model._hc.mlp_precision == 1 else 'fp32 MFMA')
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same
@@ -272,7 +302,7 @@ def main():
     if rank == 0 and world == 1 and args.torch_gpu:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         from torch_port import TorchPort
-        tp = TorchPort(cfg, ds, sd, device='cuda')
+        tp = TorchPort(cfg, ds, sd_ref, device='cuda')
         best = None
         for ck in (16384, 1048576):          # the reference's shipped ray_chunk and its demo setting
             tp.render(rays, chunk=ck)

@@ -57,7 +57,7 @@ struct hr_model {
     int k0p = 0;
     int n_out = 0;
     // packed grids
-    float* grid_a[3] = {};
+    float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
     float* grid_b[3] = {};
     HrGridPlane planes[3] = {};
     float* basis = nullptr;
@@ -126,6 +126,7 @@ int validate(const hr_config& c)
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
     if (c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_BF16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
     if (c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256) return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
+    if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
     return HR_OK;
 }
 
@@ -405,10 +406,14 @@ int hr_model_finalize(hr_model* m)
         g.app_real_off = real_off;
         app_off += 4 * g.ca4;
         real_off += na;
-        const int tex = 4 * (g.cd4 + g.ca4);
+        const int half = (c.grid_dtype == HR_GRID_FP16);
+        int tex = 4 * (g.cd4 + g.ca4);
         if (tex == 0) continue;
-        const size_t a_bytes = sizeof(float) * (size_t)g.aw * g.ah * tex;
-        const size_t b_bytes = sizeof(float) * (size_t)g.bw * g.bh * tex;
+        if (half) tex = (tex + 7) & ~7;               // whole 16-byte loads of 8 halfs
+        g.tex = tex;
+        const size_t esz = half ? 2 : sizeof(float);
+        const size_t a_bytes = esz * (size_t)g.aw * g.ah * tex;
+        const size_t b_bytes = esz * (size_t)g.bw * g.bh * tex;
         HR_HIP(hipMalloc((void**)&m->grid_a[j], a_bytes));
         HR_HIP(hipMalloc((void**)&m->grid_b[j], b_bytes));
         HR_HIP(hipMemset(m->grid_a[j], 0, a_bytes));
@@ -416,13 +421,13 @@ int hr_model_finalize(hr_model* m)
         const char* an = c.video ? "plane_space" : "plane";
         const char* bn = c.video ? "plane_time" : "line";
         snprintf(name, sizeof(name), "density_%s.%d", an, j);
-        hr_launch_interleave(m->raw[name].p, m->grid_a[j], nd, g.ah, g.aw, tex, 0, nullptr);
+        hr_launch_interleave(m->raw[name].p, m->grid_a[j], half, nd, g.ah, g.aw, tex, 0, nullptr);
         snprintf(name, sizeof(name), "app_%s.%d", an, j);
-        hr_launch_interleave(m->raw[name].p, m->grid_a[j], na, g.ah, g.aw, tex, 4 * g.cd4, nullptr);
+        hr_launch_interleave(m->raw[name].p, m->grid_a[j], half, na, g.ah, g.aw, tex, 4 * g.cd4, nullptr);
         snprintf(name, sizeof(name), "density_%s.%d", bn, j);
-        hr_launch_interleave(m->raw[name].p, m->grid_b[j], nd, g.bh, g.bw, tex, 0, nullptr);
+        hr_launch_interleave(m->raw[name].p, m->grid_b[j], half, nd, g.bh, g.bw, tex, 0, nullptr);
         snprintf(name, sizeof(name), "app_%s.%d", bn, j);
-        hr_launch_interleave(m->raw[name].p, m->grid_b[j], na, g.bh, g.bw, tex, 4 * g.cd4, nullptr);
+        hr_launch_interleave(m->raw[name].p, m->grid_b[j], half, na, g.bh, g.bw, tex, 4 * g.cd4, nullptr);
         g.a = m->grid_a[j];
         g.b = m->grid_b[j];
         m->packed_bytes += (int64_t)(a_bytes + b_bytes);

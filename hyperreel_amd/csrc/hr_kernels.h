@@ -47,8 +47,9 @@ struct HrMlpArgs {
 //   static: plane j  [H = N[mat1]][W = N[mat0]][cd4 + ca4], line j [N[vec]][cd4 + ca4]
 //   video:  space j  [H][W][cd4 + ca4],                     time j [K][N[matT0]][cd4 + ca4]
 struct HrGridPlane {
-    const float* a;     // plane (static) / space plane (video)
-    const float* b;     // line (static) / time plane (video)
+    const void* a;      // plane (static) / space plane (video): texels of `tex` floats (or halfs, HR_GRID_FP16)
+    const void* b;      // line (static) / time plane (video)
+    int tex;            // elements per texel: 4*(cd4+ca4), rounded up to a multiple of 8 for halfs (16-byte loads)
     int aw, ah;         // plane width / height in texels
     int bw, bh;         // line: bw = 1, bh = N[vec];  time plane: bw = N[matT0], bh = K
     int cd4, ca4;       // density / appearance float4 groups per texel
@@ -91,6 +92,6 @@ struct HrColMap {
 // diagnostics export of the raw head in the user's (n, Z*P) layout; pruned columns read as 0
 void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, const HrColMap& map,
                            hipStream_t stream);
-void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
+void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 
 #endif

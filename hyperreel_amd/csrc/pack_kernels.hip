@@ -17,6 +17,18 @@ __global__ void hr_interleave_kernel(const float* __restrict__ src, float* __res
     }
 }
 
+// float16 texels (HR_GRID_FP16): same layout in halfs, values rounded to nearest even once, here.
+__global__ void hr_interleave_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int C, int H, int W,
+                                          int tex, int c_off)
+{
+    const int64_t n = (int64_t)C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t yx = i / C;
+        dst[yx * tex + c_off + c] = (_Float16)src[(int64_t)c * H * W + yx];
+    }
+}
+
 // out[r][k*P + c] = head[r][k*P_live + col_map[c]] (0 where the column was pruned)
 __global__ void hr_head_export_kernel(const float* __restrict__ head, float* __restrict__ out, int64_t n_rays, int Z, int P,
                                       int P_live, int nq, HrColMap map)
@@ -72,11 +84,16 @@ void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pi
     hipLaunchKernelGGL(hr_generate_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cam, ray_dim, first_pixel, n_pixels, rays);
 }
 
-void hr_launch_interleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream)
+void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream)
 {
     const int64_t n = (int64_t)C * H * W;
     if (n <= 0) return;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(hr_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, C, H, W, tex, c_off);
+    if (half)
+        hipLaunchKernelGGL(hr_interleave_half_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
+                           reinterpret_cast<_Float16*>(dst), C, H, W, tex, c_off);
+    else
+        hipLaunchKernelGGL(hr_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
+                           reinterpret_cast<float*>(dst), C, H, W, tex, c_off);
 }

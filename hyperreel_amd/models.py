@@ -140,6 +140,7 @@ class HipLightfieldModel(nn.Module):
         self.dataset = kwargs['dataset'] if 'dataset' in kwargs else dataset_scalars_from_system(system)
         # arithmetic of the MLP GEMMs: 'auto' | 'bf16x3' | 'fp32' (see plan.compile_config)
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
+        self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
             grid = list(kwargs['grid_size'])
@@ -154,7 +155,7 @@ class HipLightfieldModel(nn.Module):
         self._native = None
         self._native_key = None
         # fail on configurations outside the supported path now, not at the first render
-        compile_config(cfg, self.dataset, grid, self.mlp_precision)
+        compile_config(cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype)
 
     # -- reference surface ---------------------------------------------------------
     def set_iter(self, i):
@@ -192,7 +193,7 @@ class HipLightfieldModel(nn.Module):
     # -- native side -------------------------------------------------------------------
     def _tensors(self):
         own = dict(self.named_parameters())
-        hc = compile_config(self.cfg, self.dataset, self.grid_size, self.mlp_precision)
+        hc = compile_config(self.cfg, self.dataset, self.grid_size, self.mlp_precision, self.grid_dtype)
         pred_idx = [i for i, e in enumerate(self.cfg['embedding']['embeddings'].values())
                     if e['type'] == 'ray_prediction'][0]
         return hc, [(abi, own[key.format(idx=pred_idx)]) for abi, key in upload_names(hc)]
@@ -200,7 +201,7 @@ class HipLightfieldModel(nn.Module):
     def _param_key(self):
         # cheap fingerprint of everything the native model was built from: in-place
         # updates bump ._version, re-allocations change data_ptr/shape
-        return (self.mlp_precision,) + tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
+        return (self.mlp_precision, self.grid_dtype) + tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
 
     def native(self):
         """Returns the hr_model handle, (re)uploading weights if any parameter changed."""
@@ -219,7 +220,8 @@ class HipLightfieldModel(nn.Module):
                 _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
                 self._native = h
                 self._native_grid = self.grid_size
-            elif self._native_grid != self.grid_size or self._hc.mlp_precision != hc.mlp_precision:
+            elif self._native_grid != self.grid_size or self._hc.mlp_precision != hc.mlp_precision \
+                    or self._hc.grid_dtype != hc.grid_dtype:
                 L.hr_model_destroy(self._native)
                 h = C.c_void_p()
                 _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')

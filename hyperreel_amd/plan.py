@@ -79,7 +79,7 @@ class hr_config(C.Structure):
         ('num_keyframes', C.c_int32), ('n_den', C.c_int32 * 3), ('n_app', C.c_int32 * 3), ('app_dim', C.c_int32),
         ('shading', C.c_int32), ('distance_scale', C.c_float), ('weight_thresh', C.c_float),
         ('density_act', C.c_int32), ('density_shift', C.c_float), ('time_scale', C.c_float), ('time_offset', C.c_float),
-        ('white_bg', C.c_int32), ('mlp_precision', C.c_int32),
+        ('white_bg', C.c_int32), ('mlp_precision', C.c_int32), ('grid_dtype', C.c_int32),
     ]
 
 
@@ -186,7 +186,10 @@ class _Affine:
 MLP_PRECISION = {'fp32': 0, 'bf16x3': 1}
 
 
-def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
+GRID_DTYPE = {'fp32': 0, 'fp16': 1}
+
+
+def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):
     """cfg: `experiment.model` group (dict/Cfg); dataset: {near, far, depth_range,
     num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes."""
     if cfg.get('param', {}).get('fn', 'identity') != 'identity':
@@ -549,6 +552,9 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto'):
     if mlp_precision == 'bf16x3' and hc.mlp_hidden != 256:
         raise NotImplementedError('bf16x3 MLP needs hidden_channels == 256')
     hc.mlp_precision = MLP_PRECISION[mlp_precision]
+    if grid_dtype not in GRID_DTYPE:
+        raise ValueError(f"grid_dtype must be one of {sorted(GRID_DTYPE)} (got {grid_dtype!r})")
+    hc.grid_dtype = GRID_DTYPE[grid_dtype]
     return hc
 
 

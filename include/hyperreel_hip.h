@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 3
+#define HR_ABI_VERSION 4
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -92,6 +92,10 @@ enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
 /* arithmetic of the MLP GEMMs: exact fp32 MFMA, or three bf16 MFMA products of the hi/lo
  * split operands with fp32 accumulation (~2^-17 relative per product; needs mlp_hidden 256) */
 enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1 };
+/* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
+ * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
+ * stays fp32 -- results equal the fp32 path run on the rounded grids) */
+enum { HR_GRID_FP32 = 0, HR_GRID_FP16 = 1 };
 
 /* Everything the kernels need that the reference derives from the model YAML and the
  * five dataset scalars (near, far, depth_range, num_keyframes, num_frames).  Derived
@@ -165,6 +169,7 @@ typedef struct hr_config {
     float time_scale, time_offset;       /* (F-1)/F and 0.5/K, tensorf_dynamic.py:58-59 */
     int32_t white_bg;
     int32_t mlp_precision;               /* HR_MLP_* */
+    int32_t grid_dtype;                  /* HR_GRID_* */
 } hr_config;
 
 /* Optional per-sample diagnostics of hr_render_fields (all device pointers, any may be

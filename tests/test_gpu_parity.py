@@ -381,3 +381,46 @@ def test_device_ray_generation_matches_ray_utils(fns):
         b = fn.model.render(torch.from_numpy(got).cuda())['rgb']
         torch.cuda.synchronize()
         assert torch.equal(a, b)
+
+
+def _round_grids_to_half(sd):
+    out = {}
+    for k, v in sd.items():
+        is_grid = ('_plane' in k or '_line' in k) and v.dtype == np.float32
+        out[k] = v.astype(np.float16).astype(np.float32) if is_grid else v
+    return out
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small', 'immersive_sphere_small',
+                                  'sweep/catacaustics_cylinder', 'sweep/donerf_voxel'])
+def test_fp16_grids_equal_fp32_path_on_rounded_grids(case):
+    """grid_dtype='fp16' (viewer path, BASELINE config 5) only changes the STORAGE of the texels: the
+    result must equal the reference algorithm run on the same grids rounded to float16."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, grid_dtype='fp16')
+    out = render_np(fn, g.rays, want=('render_weights',))
+    ref = HyperReelOracle(g.cfg, g.dataset, _round_grids_to_half(g.state_dict)).render(g.rays, keep='all')
+    assert linf(out['rgb'], ref['rgb']) <= RGB_TOL
+    assert linf(out['render_weights'], ref['render_weights']) <= 5e-5
+    # and it is a genuinely different (rounded) scene, close to the fp32 one
+    d = linf(out['rgb'], g.rgb)
+    assert 0.0 < d < 5e-3, d
+
+
+def test_fp16_grids_full_frame_psnr():
+    """800x800 / 600^3 frame: float16 texels vs float32 texels, PSNR of the image (white-noise grids at
+    full resolution are the worst case for texel rounding)."""
+    from gpu_common import make_render_fn
+    name = 'donerf_sphere'
+    cfg, ds = C.model_config(name), C.dataset_scalars(name)
+    grid = C.final_grid_size(cfg)
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=5, density='dense', app_scale=1.0)
+    rays = torch.from_numpy(scenes.benchmark_rays(name)).cuda()
+    a = make_render_fn(cfg, ds, sd)(rays)['rgb']
+    b = make_render_fn(cfg, ds, sd, grid_dtype='fp16')(rays)['rgb']
+    mse = torch.mean((a - b) ** 2).item()
+    psnr = 10.0 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 60.0, psnr
+    assert (a - b).abs().max().item() < 2e-2
