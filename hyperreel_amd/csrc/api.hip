@@ -92,11 +92,13 @@ int validate(const hr_config& c)
 {
     if (c.ray_dim != 6 && c.ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8 (got %d)", c.ray_dim);
     if (c.n_groups < 1 || c.n_groups > HR_MAX_GROUPS) return fail(HR_E_INVALID, "n_groups out of range");
-    if (c.mlp_hidden != 64 && c.mlp_hidden != 128 && c.mlp_hidden != 256)
-        return fail(HR_E_INVALID, "mlp_hidden must be 64, 128 or 256 (got %d)", c.mlp_hidden);
-    if (c.mlp_layers < 2 || c.mlp_layers > HR_MAX_LAYERS) return fail(HR_E_INVALID, "mlp_layers must be in [2,%d]", HR_MAX_LAYERS);
-    if (c.mlp_in < 1 || c.mlp_in > HR_MAX_MLP_IN) return fail(HR_E_INVALID, "mlp_in must be in [1,%d]", HR_MAX_MLP_IN);
-    if (c.mlp_skip_mask & 1) return fail(HR_E_INVALID, "layer 0 cannot be a skip layer");
+    if (c.mlp_layers != 0) {   // 0: ZeroMLP (nlf/nets/mlp.py:14-33), the head is all zeros and samples sit on their anchors
+        if (c.mlp_hidden != 64 && c.mlp_hidden != 128 && c.mlp_hidden != 256)
+            return fail(HR_E_INVALID, "mlp_hidden must be 64, 128 or 256 (got %d)", c.mlp_hidden);
+        if (c.mlp_layers < 2 || c.mlp_layers > HR_MAX_LAYERS) return fail(HR_E_INVALID, "mlp_layers must be 0 or in [2,%d]", HR_MAX_LAYERS);
+        if (c.mlp_in < 1 || c.mlp_in > HR_MAX_MLP_IN) return fail(HR_E_INVALID, "mlp_in must be in [1,%d]", HR_MAX_MLP_IN);
+        if (c.mlp_skip_mask & 1) return fail(HR_E_INVALID, "layer 0 cannot be a skip layer");
+    }
     if (c.z_channels < 1 || c.z_channels > HR_KERNEL_MAX_Z) return fail(HR_E_INVALID, "z_channels must be in [1,%d]", HR_KERNEL_MAX_Z);
     if (c.preds_per_z < 1 || c.preds_per_z > 64) return fail(HR_E_INVALID, "preds_per_z out of range");
     const hr_head_field* fs[9] = {&c.f_z_vals, &c.f_isect_sigma, &c.f_offset_sigma, &c.f_point_offset, &c.f_color_scale,
@@ -125,7 +127,8 @@ int validate(const hr_config& c)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
     if (c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_BF16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
-    if (c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256) return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
+    if (c.mlp_layers != 0 && c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256)
+        return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
     return HR_OK;
 }
@@ -472,12 +475,14 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     const size_t nq = ((size_t)m->cfg.z_channels * m->p_live + 3) / 4;
     const size_t bytes = sizeof(float) * (size_t)rays_per_chunk * nq * 4;   // HQ layout, rays_per_chunk is a multiple of 64
     HR_HIP(hipMalloc((void**)&m->head, bytes));
+    if (m->cfg.mlp_layers == 0) HR_HIP(hipMemset(m->head, 0, bytes));   // ZeroMLP: written once, only ever read
     m->chunk = rays_per_chunk;
     return HR_OK;
 }
 
 static void launch_mlp(const hr_config& c, const HrMlpArgs& a, hipStream_t st)
 {
+    if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else hr_launch_mlp(c, a, st);
 }

@@ -43,6 +43,14 @@ class _Empty(nn.Module):
     pass
 
 
+class _ZeroNet(nn.Module):
+    """ZeroMLP (nlf/nets/mlp.py:14-33): an unused nn.Linear(1, 1), kept for strict state_dict loading."""
+
+    def __init__(self):
+        super().__init__()
+        self.layer = nn.Linear(1, 1)
+
+
 class HostMLP(nn.Module):
     """Parameter container shaped like BaseMLP (nlf/nets/mlp.py:127-154)."""
 
@@ -59,7 +67,7 @@ class HostRayPrediction(nn.Module):
         super().__init__()
         self.params = nn.ModuleList([_Dummy() for _ in pred_cfg['params']])
         self.pes = nn.ModuleList([_Dummy() if 'pe' in p else _Empty() for p in pred_cfg['params'].values()])
-        self.net = HostMLP(shapes)
+        self.net = HostMLP(shapes) if shapes else _ZeroNet()
 
 
 class HostEmbedding(nn.Module):

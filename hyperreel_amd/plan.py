@@ -271,8 +271,11 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     if mlp_in > HR_MAX_MLP_IN:
         raise NotImplementedError(f'MLP input of {mlp_in} features (max {HR_MAX_MLP_IN})')
     net = pred['net']
-    if net['type'] != 'base':
-        raise NotImplementedError(f"net '{net['type']}' is outside the hot-path scope (BaseMLP only)")
+    if net['type'] not in ('base', 'zero'):
+        raise NotImplementedError(f"net '{net['type']}' is outside the hot-path scope (BaseMLP, ZeroMLP)")
+    zero_net = net['type'] == 'zero'               # nlf/nets/mlp.py:14-33: all-zero head, the other keys are ignored
+    if zero_net:
+        net = {'depth': 2, 'hidden_channels': 0}
     for k in ('pe', 'pad_to', 'is_constant', 'zero_before_channel', 'latent_dim'):
         if k in net:
             raise NotImplementedError(f'net.{k}')
@@ -281,7 +284,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     if not net.get('bias', True):
         raise NotImplementedError('bias-free MLP')
     D = int(net['depth']) - 2                       # ray.py:283-285
-    hc.mlp_layers = D + 2
+    hc.mlp_layers = 0 if zero_net else D + 2
     hc.mlp_hidden = int(net['hidden_channels'])
     mask = 0
     for s in net.get('skips', []):
@@ -547,7 +550,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     # GEMM arithmetic of the MLP: 'bf16x3' (three bf16 MFMA products of hi/lo split operands,
     # fp32 accumulate; >= 10x inside the 1e-4 RGB bar) when the kernel supports the width,
     # 'fp32' (exact fp32 MFMA) otherwise or on request.
-    if mlp_precision == 'auto':
+    if mlp_precision == 'auto' or hc.mlp_layers == 0:
         mlp_precision = 'bf16x3' if hc.mlp_hidden == 256 else 'fp32'
     if mlp_precision == 'bf16x3' and hc.mlp_hidden != 256:
         raise NotImplementedError('bf16x3 MLP needs hidden_channels == 256')

@@ -54,6 +54,8 @@ def mlp_layer_shapes(cfg):
     emb = cfg['embedding']['embeddings']
     pred = next(e for e in emb.values() if e['type'] == 'ray_prediction')
     net = pred['net']
+    if net['type'] == 'zero':                   # ZeroMLP: no Linear on the path (its unused Linear(1,1) is `net.layer`)
+        return []
     n_in = mlp_in_channels(pred)
     W = net['hidden_channels']
     D = net['depth'] - 2
@@ -98,6 +100,9 @@ def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_s
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.weight'] = _uniform(rng, (o, n_in), b)
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.bias'] = _uniform(rng, (o,), b)
 
+    if not shapes:                              # ZeroMLP carries an unused nn.Linear(1, 1) (nlf/nets/mlp.py:27)
+        sd[f'{EMB}{pred_idx}.net.layer.weight'] = _uniform(rng, (1, 1), 1.0)
+        sd[f'{EMB}{pred_idx}.net.layer.bias'] = _uniform(rng, (1,), 1.0)
     act = net.get('fea2denseAct', 'softplus')
 
     def dens(shape):

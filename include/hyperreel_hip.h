@@ -107,7 +107,7 @@ typedef struct hr_config {
     int32_t n_groups;
     hr_param_group groups[HR_MAX_GROUPS];
     int32_t mlp_in;                      /* input features (sum over groups after PE) */
-    int32_t mlp_layers;                  /* number of Linear layers (D+2) */
+    int32_t mlp_layers;                  /* number of Linear layers (D+2); 0 = ZeroMLP (nlf/nets/mlp.py:14-33) */
     int32_t mlp_hidden;                  /* W */
     int32_t mlp_skip_mask;               /* bit i set: layer i takes cat([input, x]) */
     float leaky_slope;                   /* 0.01 */

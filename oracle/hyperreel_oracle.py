@@ -408,6 +408,12 @@ class HyperReelOracle:
         if ecfg.get('ray_outputs'):
             raise NotImplementedError('ray_outputs are outside the hot-path scope')
         net = ecfg['net']
+        self.zero_net = net['type'] == 'zero'          # ZeroMLP, nlf/nets/mlp.py:14-33
+        if self.zero_net:
+            self.D, self.skips, self.layers = 0, [], []
+            return
+        if net['type'] != 'base':
+            raise NotImplementedError(f"net {net['type']} is outside the hot-path scope")
         self.D = int(net['depth']) - 2                 # ray.py:283-285
         self.skips = list(net.get('skips', []))
         self.layers = []
@@ -477,7 +483,10 @@ class HyperReelOracle:
         return x
 
     def _predict(self, rays, x):                       # ray.py:316-347
-        h = self.mlp(self._param_pe(rays))
+        if self.zero_net:
+            h = np.zeros((rays.shape[0], self.Z * sum(self.out_shapes)), F32)
+        else:
+            h = self.mlp(self._param_pe(rays))
         x['_head_raw'] = h
         h = h.reshape(rays.shape[0], self.Z, -1)
         o = 0
