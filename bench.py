@@ -37,6 +37,7 @@ from hyperreel_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
+MFMA_BF16_SUSTAINED_TFLOPS = 1889.0   # tools/mfma_peak.hip, profiles/r01_f_mfma_peak.txt
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak
 
 
@@ -262,6 +263,11 @@ def main():
                  'note': ('fp32 GEMMs evaluated as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): the matrix '
                           'cores issue 3x the algorithmic FLOPs, so frac <= 1/3 by construction') if split else
                          'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
+        if split:
+            # measured with tools/mfma_peak.hip on MI355X: back-to-back v_mfma_f32_32x32x16_bf16 on register-resident
+            # operands sustain 1.89 PFLOP/s (the chip settles at ~1.8 GHz under matrix load), not the 2.5 PFLOP/s of `peak`
+            r_mlp['sustained_mfma_peak'] = MFMA_BF16_SUSTAINED_TFLOPS
+            r_mlp['frac_of_sustained_issue'] = round(3 * flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED_TFLOPS, 4)
         r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),

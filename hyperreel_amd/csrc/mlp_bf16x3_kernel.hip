@@ -133,6 +133,32 @@ __device__ __forceinline__ void hr_accumulate3_pipe(floatx16 (&acc)[NT][MT], con
     hr_mfma3<NT, MT>(acc, w3, x1);
 }
 
+// Same contraction with a ring of R weight slots (R-1 k-steps ahead), fully unrolled so that every slot
+// index is a compile-time constant.  HR_MLP_RING selects it (A/B: tools/ab.sh "-DHR_MLP_RING=8" ...).
+template <int NKT, int NT, int MT, int R>
+__device__ __forceinline__ void hr_accumulate3_ring(floatx16 (&acc)[NT][MT], const __bf16* xh, const __bf16* xl, int stride,
+                                                    const bf16x8* wp, int kt0, int tiles_total, const int (&tile)[NT], int lane)
+{
+    HrWOps<NT> w[R];
+    HrXOps<MT> x[2];
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i)
+        if (i < NKT) hr_load_w<NT>(w[i], wp, kt0 + i, tiles_total, tile, lane);
+    hr_load_x<MT>(x[0], xh, xl, stride, 0, lane);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt + R - 1 < NKT) hr_load_w<NT>(w[(kt + R - 1) % R], wp, kt0 + kt + R - 1, tiles_total, tile, lane);
+        if (kt + 1 < NKT) hr_load_x<MT>(x[(kt + 1) & 1], xh, xl, stride, kt + 1, lane);
+        hr_mfma3<NT, MT>(acc, w[kt % R], x[kt & 1]);
+    }
+}
+
+#ifdef HR_MLP_RING
+#define HR_ACCUMULATE_HIDDEN(NKT_, NT_, MT_, ...) hr_accumulate3_ring<NKT_, NT_, MT_, HR_MLP_RING>(__VA_ARGS__)
+#else
+#define HR_ACCUMULATE_HIDDEN(NKT_, NT_, MT_, ...) hr_accumulate3_pipe<NKT_, NT_, MT_>(__VA_ARGS__)
+#endif
+
 // Input segment (k0p/16 = 1..4 k-steps): short, no ring.
 template <int NT, int MT>
 __device__ __forceinline__ void hr_accumulate3(floatx16 (&acc)[NT][MT], const __bf16* xh, const __bf16* xl, int stride, int nkt,
@@ -222,12 +248,19 @@ __global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_m
         int tile[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) tile[nt] = wave * NT + nt;
+#ifdef HR_MLP_BIAS_EARLY
+        float4 bq[NT][4];                    // this lane's bias values, fetched under the GEMM instead of after it
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[nt][g] = *reinterpret_cast<const float4*>(bias + tile[nt] * 32 + 4 * (lane >> 5) + 8 * g);
+#endif
         int kt0 = 0;
         if (l == 0 || skip) {
             hr_accumulate3<NT, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
             kt0 = k0p / 16;
         }
-        if (l > 0) hr_accumulate3_pipe<W / 16, NT, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+        if (l > 0) HR_ACCUMULATE_HIDDEN(W / 16, NT, MT, acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
         HR_STAMP();                          // 2+3l: GEMM of layer l issued
         __syncthreads();                     // all waves have finished reading Xh/Xl
         HR_STAMP();                          // 3+3l: barrier passed
@@ -237,7 +270,11 @@ __global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_m
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n0 = nbase + 8 * g;
+#ifdef HR_MLP_BIAS_EARLY
+                const float4 b = bq[nt][g];
+#else
                 const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     float v0 = acc[nt][mt][4 * g + 0] + b.x;
@@ -307,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_m
                     hr_accumulate3<2, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile_ld, lane);
                     kt0 = k0p / 16;
                 }
-                hr_accumulate3_pipe<W / 16, 2, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
+                HR_ACCUMULATE_HIDDEN(W / 16, 2, MT, acc, Xh, Xl, XS, wp, kt0, tiles_total, tile_ld, lane);
                 HR_STAMP();                      // last layer: GEMM of this pass issued
                 store_tile(tile[0], acc[0]);
                 if (tile[1] < tiles_total) store_tile(tile[1], acc[1]);
@@ -328,7 +365,7 @@ __global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_m
                 hr_accumulate3<1, MT>(acc, Xih, Xil, XSI, k0p / 16, wp, 0, tiles_total, tile, lane);
                 kt0 = k0p / 16;
             }
-            hr_accumulate3_pipe<W / 16, 1, MT>(acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
+            HR_ACCUMULATE_HIDDEN(W / 16, 1, MT, acc, Xh, Xl, XS, wp, kt0, tiles_total, tile, lane);
             HR_STAMP();
             store_tile(tile[0], acc[0]);
             HR_STAMP();
