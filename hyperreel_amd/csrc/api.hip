@@ -130,6 +130,8 @@ int validate(const hr_config& c)
     if (c.mlp_layers != 0 && c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256)
         return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
+    if (c.color_table_views < 0) return fail(HR_E_INVALID, "negative color_table_views");
+    if (c.color_table_views > 0 && c.ray_dim != 8) return fail(HR_E_INVALID, "the colour table is indexed by rays[..., -2]: needs 8-column rays");
     return HR_OK;
 }
 
@@ -268,6 +270,7 @@ int hr_model_create(const hr_config* cfg, hr_model** out)
         n_app_sum += c.n_app[j];
     }
     m->expect["basis_mat.weight"] = sizeof(float) * (size_t)c.app_dim * n_app_sum;
+    if (c.color_table_views > 0) m->expect["color_embedding"] = sizeof(float) * (size_t)c.color_table_views * 12;
     *out = m;
     return HR_OK;
 }
@@ -516,6 +519,12 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.basis = m->basis;
     a.n_basis_cols = m->n_basis_cols;
     a.ca_total = m->ca_total;
+    // the table is read in place from the uploaded copy (12 floats per camera, no re-layout)
+    a.color_table = nullptr;
+    if (m->cfg.color_table_views > 0) {
+        auto it = m->raw.find("color_embedding");
+        if (it != m->raw.end()) a.color_table = it->second.p;
+    }
     a.dbg_mode = 0;
 }
 

@@ -71,6 +71,7 @@ struct HrSampleArgs {
     const float* basis;     // (app_dim, n_basis_cols) row-major, torch layout
     int n_basis_cols;       // sum of the real appearance channels of the sampled planes
     int ca_total;           // padded appearance slots (multiple of 4) = sum 4*ca4
+    const float* color_table;  // (color_table_views, 12) per-camera [3x3 | shift], or NULL
     int dbg_mode;           // profiling only (HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 

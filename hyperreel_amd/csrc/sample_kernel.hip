@@ -376,6 +376,21 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
             c1 = c1 * (hr_apply_act(fs.act, hk[fs.offset + 1]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 1]);
             c2 = c2 * (hr_apply_act(fs.act, hk[fs.offset + 2]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 2]);
         }
+        else if (a.color_table) {                     // transform_color_one (tensorf_utils.py:308-320, point.py:588-594)
+            // camera id = round(rays[..., -2]); ids outside the table are clamped (the reference would raise)
+            int id = (int)rintf(a.rays[ray * cfg.ray_dim + cfg.ray_dim - 2]);
+            id = min(max(id, 0), cfg.color_table_views - 1);
+            const float* e = a.color_table + 12 * id;
+            float t[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t[i] = hr_apply_act(cfg.color_table_t_act, e[i]);
+            const float n0 = c0 + ((c0 * t[0] + c1 * t[1]) + c2 * t[2]);
+            const float n1 = c1 + ((c0 * t[3] + c1 * t[4]) + c2 * t[5]);
+            const float n2 = c2 + ((c0 * t[6] + c1 * t[7]) + c2 * t[8]);
+            c0 = n0 + hr_apply_act(cfg.color_table_s_act, e[9]);
+            c1 = n1 + hr_apply_act(cfg.color_table_s_act, e[10]);
+            c2 = n2 + hr_apply_act(cfg.color_table_s_act, e[11]);
+        }
         a.rgb[ray * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);   // eval-mode clamp, :246-247
         a.rgb[ray * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
         a.rgb[ray * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);

@@ -26,8 +26,14 @@ def dataset_scalars_from_system(system):
     """The five `system.dm.train_dataset` reads of the hot path."""
     td = system.dm.train_dataset
     get = (lambda k, d=None: td[k] if isinstance(td, dict) and k in td else getattr(td, k, d))
-    return {'near': get('near', 0.0), 'far': get('far', 1.0), 'depth_range': list(get('depth_range', [0.0, 1.0])),
-            'num_keyframes': get('num_keyframes', 1), 'num_frames': get('num_frames', 1)}
+    ds = {'near': get('near', 0.0), 'far': get('far', 1.0), 'depth_range': list(get('depth_range', [0.0, 1.0])),
+          'num_keyframes': get('num_keyframes', 1), 'num_frames': get('num_frames', 1)}
+    # read by single stages only: voxel_grid bounds (voxel.py:27-29), the per-camera colour table (point.py:576-577)
+    for k in ('bbox_min', 'bbox_max', 'total_images_per_frame', 'val_all'):
+        v = get(k)
+        if v is not None:
+            ds[k] = [float(t) for t in v] if k.startswith('bbox') else v
+    return ds
 
 
 class _Dummy(nn.Module):
@@ -70,12 +76,25 @@ class HostRayPrediction(nn.Module):
         self.net = HostMLP(shapes) if shapes else _ZeroNet()
 
 
+class HostColorTransform(nn.Module):
+    """ColorTransformEmbedding (nlf/embedding/point.py:558-602): one [3x3 | shift] row per camera."""
+
+    def __init__(self, num_views):
+        super().__init__()
+        self.color_embedding = nn.Parameter(torch.zeros((int(num_views), 12)))
+
+
 class HostEmbedding(nn.Module):
-    def __init__(self, cfg, shapes):
+    def __init__(self, cfg, shapes, dataset=None):
         super().__init__()
         mods = []
         for e in cfg['embedding']['embeddings'].values():
-            mods.append(HostRayPrediction(e, shapes) if e['type'] == 'ray_prediction' else _Empty())
+            if e['type'] == 'ray_prediction':
+                mods.append(HostRayPrediction(e, shapes))
+            elif e['type'] == 'color_transform':
+                mods.append(HostColorTransform((dataset or {}).get('total_images_per_frame', 1)))
+            else:
+                mods.append(_Empty())
         self.embeddings = nn.ModuleList(mods)
 
 
@@ -157,7 +176,7 @@ class HipLightfieldModel(nn.Module):
         else:
             grid = n_to_reso(net['N_voxel_init'], to_plain(net['aabb']))
         self.param = _Dummy()
-        self.embedding_model = HostEmbedding(cfg, mlp_layer_shapes(cfg))
+        self.embedding_model = HostEmbedding(cfg, mlp_layer_shapes(cfg), self.dataset)
         self.color_model = HostColorModel(net, grid, self.dataset['num_keyframes'])
         self.cur_iter = 0
         self._native = None
@@ -202,9 +221,10 @@ class HipLightfieldModel(nn.Module):
     def _tensors(self):
         own = dict(self.named_parameters())
         hc = compile_config(self.cfg, self.dataset, self.grid_size, self.mlp_precision, self.grid_dtype)
-        pred_idx = [i for i, e in enumerate(self.cfg['embedding']['embeddings'].values())
-                    if e['type'] == 'ray_prediction'][0]
-        return hc, [(abi, own[key.format(idx=pred_idx)]) for abi, key in upload_names(hc)]
+        types = [e['type'] for e in self.cfg['embedding']['embeddings'].values()]
+        pred_idx = types.index('ray_prediction')
+        ct_idx = types.index('color_transform') if 'color_transform' in types else -1
+        return hc, [(abi, own[key.format(idx=pred_idx, ct_idx=ct_idx)]) for abi, key in upload_names(hc)]
 
     def _param_key(self):
         # cheap fingerprint of everything the native model was built from: in-place

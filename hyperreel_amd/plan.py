@@ -80,6 +80,7 @@ class hr_config(C.Structure):
         ('shading', C.c_int32), ('distance_scale', C.c_float), ('weight_thresh', C.c_float),
         ('density_act', C.c_int32), ('density_shift', C.c_float), ('time_scale', C.c_float), ('time_offset', C.c_float),
         ('white_bg', C.c_int32), ('mlp_precision', C.c_int32), ('grid_dtype', C.c_int32),
+        ('color_table_views', C.c_int32), ('color_table_t_act', hr_act), ('color_table_s_act', hr_act),
     ]
 
 
@@ -202,7 +203,8 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         setattr(hc, name, _absent_field())
     stages = list(cfg['embedding']['embeddings'].values())
     types = [s['type'] for s in stages]
-    allowed = {'ray_prediction', 'ray_intersect', 'advect_points', 'point_offset', 'add_point_outputs', 'extract_fields'}
+    allowed = {'ray_prediction', 'ray_intersect', 'advect_points', 'point_offset', 'add_point_outputs', 'extract_fields',
+               'color_transform'}
     for t in types:
         if t not in allowed:
             raise NotImplementedError(f"embedding '{t}' is outside the hot-path scope")
@@ -329,6 +331,21 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
             raise ValueError(f'{k[2:]} needs 3 channels')
     if has('weights_shift'):
         raise NotImplementedError("head 'weights_shift' is outside the hot-path scope")
+    # ColorTransformEmbedding (embedding/point.py:558-602): a no-op unless dataset.val_all
+    hc.color_table_t_act, hc.color_table_s_act = _act(None), _act(None)
+    if 'color_transform' in types and dataset.get('val_all', False):
+        ct = stages[types.index('color_transform')]
+        tf, sf = ct.get('out_transform_field', 'color_transform_global'), ct.get('out_shift_field', 'color_shift_global')
+        if (tf, sf) != ('color_transform_global', 'color_shift_global'):
+            raise NotImplementedError('color_transform with renamed output fields')
+        if 'color_shift_global' in heads:
+            raise NotImplementedError('color_transform next to a color_shift_global head')
+        vis = lambda k: seen is None or k in seen
+        # tensorf_no_sample.py:240-243: a color_scale_global head takes precedence over the transform
+        if vis(tf) and vis(sf) and hc.f_color_scale_global.offset < 0:
+            hc.color_table_views = int(dataset['total_images_per_frame'])
+            hc.color_table_t_act = _act(ct.get('transform_activation'))
+            hc.color_table_s_act = _act(ct.get('shift_activation'))
 
     # ---- ray_intersect --------------------------------------------------------------
     st = stages[types.index('ray_intersect')]
@@ -537,7 +554,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     hc.density_act = DENSITY[act]
     hc.density_shift = float(n.get('density_shift', -10.0))
     hc.white_bg = int(bool(n.get('white_bg', 0)) and not bool(n.get('black_bg', 0)))
-    hc.ray_dim = 8 if (hc.video or max_col > 6 or hc.advect) else 6
+    hc.ray_dim = 8 if (hc.video or max_col > 6 or hc.advect or hc.color_table_views > 0) else 6   # camera id = rays[..., -2]
     if hc.video:
         if n.get('densityMode', 'Density') != 'Density':
             raise NotImplementedError(f"densityMode {n.get('densityMode')}")
@@ -612,4 +629,6 @@ def upload_names(hc):
             for j in range(3):
                 names.append((f'{what}_{kind}.{j}', f'color_model.net.{what}_{kind}.{j}'))
     names.append(('basis_mat.weight', 'color_model.net.basis_mat.weight'))
+    if hc.color_table_views > 0:
+        names.append(('color_embedding', 'embedding_model.embeddings.{ct_idx}.color_embedding'))
     return names

@@ -103,6 +103,10 @@ def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_s
     if not shapes:                              # ZeroMLP carries an unused nn.Linear(1, 1) (nlf/nets/mlp.py:27)
         sd[f'{EMB}{pred_idx}.net.layer.weight'] = _uniform(rng, (1, 1), 1.0)
         sd[f'{EMB}{pred_idx}.net.layer.bias'] = _uniform(rng, (1,), 1.0)
+    for i, e in enumerate(emb.values()):        # ColorTransformEmbedding table (reference init: zeros)
+        if e['type'] == 'color_transform':
+            sd[f'{EMB}{i}.color_embedding'] = rng.standard_normal((int(dataset.get('total_images_per_frame', 1)), 12),
+                                                                  dtype=np.float32)
     act = net.get('fea2denseAct', 'softplus')
 
     def dens(shape):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 4
+#define HR_ABI_VERSION 5
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -170,6 +170,12 @@ typedef struct hr_config {
     int32_t white_bg;
     int32_t mlp_precision;               /* HR_MLP_* */
     int32_t grid_dtype;                  /* HR_GRID_* */
+    /* ---- per-camera colour correction (ColorTransformEmbedding, nlf/embedding/point.py:558-602):
+     *      table row round(rays[..., -2]) = [3x3 transform | shift]; applied to the composited colour
+     *      (transform_color_one, utils/tensorf_utils.py:308-320).  0 views: stage absent, or
+     *      dataset.val_all false, in which case the reference's stage returns x unchanged. */
+    int32_t color_table_views;
+    hr_act color_table_t_act, color_table_s_act;
 } hr_config;
 
 /* Optional per-sample diagnostics of hr_render_fields (all device pointers, any may be
@@ -212,6 +218,7 @@ int hr_model_create(const hr_config* cfg, hr_model** out);
  *   density_plane_space.<j> density_plane_time.<j> (1,C,K,N)
  *   app_plane_space.<j> app_plane_time.<j>                           video net
  *   basis_mat.weight (app_dim, sum n_app)
+ *   color_embedding (color_table_views, 12)                           when color_table_views > 0
  * `ptr` may be host or device memory; the data is copied before the call returns. */
 int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes);
 

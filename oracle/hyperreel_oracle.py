@@ -733,6 +733,13 @@ class HyperReelOracle:
                     x['base_times'] = np.repeat(rays[:, None, -1:], self.Z, 1)
                 if 'viewdirs' in eo and 'viewdirs' not in x:
                     x['viewdirs'] = np.repeat(rays[:, None, 3:6], self.Z, 1)
+            elif typ == 'color_transform':              # point.py:585-596: a no-op unless dataset.val_all
+                if self.ds.get('val_all', False):
+                    tab = self.sd[f'{self.EMB}{idx}.color_embedding']
+                    ids = np.round(rays[:, -2]).astype(np.int64)
+                    row = tab[ids]
+                    x[ecfg.get('out_transform_field', 'color_transform_global')] = Act(ecfg.get('transform_activation'))(row[:, :9])
+                    x[ecfg.get('out_shift_field', 'color_shift_global')] = Act(ecfg.get('shift_activation'))(row[:, -3:])
             elif typ == 'extract_fields':               # point.py:236-244: the colour net only sees these
                 x['_extracted'] = set(ecfg['fields'])
             else:
@@ -858,8 +865,10 @@ class HyperReelOracle:
             rgb_map = rgb_map + (F32(1.0) - weight.sum(-1, dtype=F32)[:, None])
         if has('color_scale_global'):                    # scale_shift_color_one, tensorf_utils.py:275-281: sample 0's head
             rgb_map = rgb_map * (x['color_scale_global'][:, 0, :] + F32(1.0)) + x['color_shift_global'][:, 0, :]
-        elif has('color_transform_global'):
-            raise NotImplementedError('color_transform_global')
+        elif has('color_transform_global'):              # transform_color_one, tensorf_utils.py:308-320
+            T = x['color_transform_global'].reshape(B, -1, 3, 3)[:, 0]
+            sh = x['color_shift_global'].reshape(B, -1, 3)[:, 0]
+            rgb_map = np.stack([rgb_map[:, c] + np.sum(rgb_map * T[:, c, :], -1, dtype=F32) for c in range(3)], -1) + sh
         rgb_map = np.clip(rgb_map, F32(0), F32(1)).astype(F32)
         return {'rgb': rgb_map, 'sigma': sigma, 'alpha': alpha, 'render_weights': weight,
                 'valid': valid, 'rgb_samples': rgb.astype(F32)}

@@ -44,6 +44,8 @@ def dataset_for(name):
         ds = dict(DEFAULT_DS)
     if 'voxel' in name:
         ds.update(BBOX)
+    if name == 'immersive_z_plane':             # ColorTransformEmbedding reads these (point.py:576-577)
+        ds.update({'total_images_per_frame': 5, 'val_all': True})
     return ds
 
 
@@ -62,7 +64,12 @@ def sweep_rays(cfg, seed):
         r = scenes.random_rays(88, seed, video)
     ray_dim = r.shape[1]
     sp = special_rays(ray_dim == 8, z_plane)
-    return np.ascontiguousarray(np.concatenate([r, sp], 0), np.float32)
+    r = np.ascontiguousarray(np.concatenate([r, sp], 0), np.float32)
+    if any(e.get('type') == 'color_transform' for e in cfg.embedding.embeddings.values()):
+        if r.shape[1] == 6:                     # [o, d, camera id, t]
+            r = np.concatenate([r, np.zeros((r.shape[0], 2), np.float32)], -1)
+        r[:, 6] = (np.arange(r.shape[0]) % 5).astype(np.float32) + np.float32(0.2)   # round() -> 0..4
+    return np.ascontiguousarray(r, np.float32)
 
 
 # Options the reference implements but no shipped YAML selects: a shipped YAML plus an edit, run through the
