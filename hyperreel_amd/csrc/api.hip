@@ -83,7 +83,7 @@ int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? c.z_
 // (sphere/cylinder), origin xyz + resize xyz + raw offset + radius (sphere_new/cylinder_new)
 int isect_z_channels(int t)
 {
-    if (t == HR_ISECT_SPHERE || t == HR_ISECT_CYLINDER) return 4;
+    if (t == HR_ISECT_SPHERE || t == HR_ISECT_CYLINDER || t == HR_ISECT_DEFORMABLE_VOXEL_GRID) return 4;
     if (t == HR_ISECT_SPHERE_NEW || t == HR_ISECT_CYLINDER_NEW) return 8;
     return 1;
 }
@@ -106,11 +106,13 @@ int validate(const hr_config& c)
     for (const hr_head_field* f : fs)
         if (f->offset >= 0 && f->offset + f->channels > c.preds_per_z) return fail(HR_E_INVALID, "head field exceeds preds_per_z");
     if (c.f_z_vals.offset < 0) return fail(HR_E_INVALID, "z_vals head is required");
-    if (c.isect_type < HR_ISECT_Z_PLANE || c.isect_type > HR_ISECT_VOXEL_GRID) return fail(HR_E_INVALID, "unknown isect_type %d", c.isect_type);
+    if (c.isect_type < HR_ISECT_Z_PLANE || c.isect_type > HR_ISECT_DEFORMABLE_VOXEL_GRID) return fail(HR_E_INVALID, "unknown isect_type %d", c.isect_type);
     if (c.f_z_vals.channels != isect_z_channels(c.isect_type))
         return fail(HR_E_INVALID, "z_vals needs %d channel(s) for intersect type %d (got %d)", isect_z_channels(c.isect_type),
                     c.isect_type, c.f_z_vals.channels);
     if (c.isect_type == HR_ISECT_VOXEL_GRID && c.z_channels % 3) return fail(HR_E_INVALID, "voxel_grid needs z_channels divisible by 3");
+    if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID && (c.dvg_axes < 1 || c.dvg_axes > 3 || c.z_channels % c.dvg_axes))
+        return fail(HR_E_INVALID, "deformable_voxel_grid needs 1..3 start normals dividing z_channels");
     if (c.contract_type < HR_CONTRACT_IDENTITY || c.contract_type > HR_CONTRACT_AFFINE) return fail(HR_E_INVALID, "unknown contract_type");
     if (c.contract_type == HR_CONTRACT_AFFINE)
         for (int i = 0; i < 3; ++i)
@@ -152,6 +154,10 @@ void analyse_live_columns(hr_model* m)
         z_anchor = 3;
         mark(c.f_z_vals, 3, 1);
         if (c.origin_scale != 0.0f) mark(c.f_z_vals, 0, 3);
+    } else if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) {
+        z_anchor = 3;
+        mark(c.f_z_vals, 3, 1);
+        if (c.dvg_normal_scale != 0.0f) mark(c.f_z_vals, 0, 3);
     } else if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) {
         z_anchor = 7;
         mark(c.f_z_vals, 6, 2);

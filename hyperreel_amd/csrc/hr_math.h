@@ -327,6 +327,20 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
         const float d = (axis == 0) ? rd[0] : (axis == 1) ? rd[1] : rd[2];
         if (c.isect_outward) z = z * hr_sign(d);
         dist = hr_axis_plane_t(z, o, d);                             // intersect_utils.py:152-179
+    } else if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) {
+        // voxel.py:184-213: a plane per sample, normal = normalize(z[:3]*scale + start_normal[k % axes]),
+        // offset = processed z[3]; intersect_plane (intersect_utils.py:210-236)
+        const int axis = k % c.dvg_axes;
+        float n[3];
+        for (int i = 0; i < 3; ++i) n[i] = c.dvg_normals[3 * axis + i];
+        if (c.dvg_normal_scale != 0.0f)
+            for (int i = 0; i < 3; ++i) n[i] = hr_zval(c, hk, i, one_m) * c.dvg_normal_scale + c.dvg_normals[3 * axis + i];
+        hr_normalize3(n);
+        const float dplane = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
+        const float o_n = (ro[0] * n[0] + ro[1] * n[1]) + ro[2] * n[2];
+        float d_n = (rd[0] * n[0] + rd[1] * n[1]) + rd[2] * n[2];
+        d_n = (fabsf(d_n) < 1e-5f) ? 1e12f : d_n;
+        dist = HR_DIV(dplane - o_n, d_n);
     } else {                                                         // euclidean_distance_unified, primitive.py:162-176
         float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);
         float pos[3];

@@ -34,8 +34,8 @@ ACT = {'identity': 0, 'sigmoid': 1, 'tanh': 2}
 PARAM = {'identity': 0, 'pluecker': 1, 'two_plane': 2}
 PE = {None: 0, 'windowed': 1, 'basic': 2}
 ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2, 'sphere_new': 3, 'cylinder_new': 4, 'euclidean_distance_unified': 5,
-         'voxel_grid': 6}
-ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1}     # z_vals channels each type reads per sample
+         'voxel_grid': 6, 'deformable_voxel_grid': 7}
+ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1, 7: 4}     # z_vals channels each type reads per sample
 CONTRACT = {'identity': 0, 'mipnerf': 1, 'bbox': 2, 'z_depth': 2}   # bbox and z_depth share the affine kernel path
 DENSITY = {'relu': 0, 'softplus': 1, 'relu_abs': 2}
 SHADING = {'RGB': 0, 'SH': 1}
@@ -67,7 +67,8 @@ class hr_config(C.Structure):
         ('z_act', hr_act), ('sort', C.c_int32), ('samples', C.c_float * HR_MAX_Z), ('z_scale', C.c_float),
         ('origin_scale', C.c_float), ('origin_initial', C.c_float * 3),
         ('resize_scale', C.c_float), ('resize_initial', C.c_float * 3),
-        ('voxel_scale', C.c_float * 3), ('isect_outward', C.c_int32), ('isect_mask_off', C.c_int32),
+        ('voxel_scale', C.c_float * 3), ('isect_outward', C.c_int32),
+        ('dvg_axes', C.c_int32), ('dvg_normals', C.c_float * 9), ('dvg_normal_scale', C.c_float), ('isect_mask_off', C.c_int32),
         ('contract_type', C.c_int32), ('contract_samples', C.c_int32),
         ('c_r0', C.c_float), ('c_r_inv_end', C.c_float), ('c_r_scale', C.c_float),
         ('c_d0', C.c_float), ('c_d_inv_end', C.c_float), ('c_d_scale', C.c_float),
@@ -434,6 +435,33 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         hc.z_scale = 1.0
         hc.isect_outward = int(bool(ic.get('outward_facing', False)))
         samples = None
+    elif t == 'deformable_voxel_grid':        # voxel.py:115-176: one plane family per start normal
+        if udb:
+            raise NotImplementedError('deformable_voxel_grid with use_dataset_bounds (reads the dataset point cloud)')
+        normals = ic.get('start_normal', [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+        na = len(normals)
+        if not 1 <= na <= 3 or Z % na:
+            raise ValueError('deformable_voxel_grid needs 1..3 start normals dividing z_channels')
+        hc.dvg_axes = na
+        for a_ in range(na):
+            for i in range(3):
+                hc.dvg_normals[3 * a_ + i] = float(normals[a_][i])
+        hc.dvg_normal_scale = float(ic.get('normal_scale_factor', 0.1))
+        nz = Z // na
+        ini, en = ic.get('initial', [0.0, 0.0, 0.0]), ic.get('end', [1.0, 1.0, 1.0])
+        cols = [torch_linspace_f32(cdist(F32(ini[d])), cdist(F32(en[d])), nz) for d in range(na)]
+        flat = np.stack(cols, -1).reshape(-1).astype(F32)       # torch.stack(samples, -1).view(-1, 1)
+        for k in range(Z):
+            hc.samples[k] = float(flat[k])
+        if 'z_scale' in ic:
+            if na != 1:
+                raise NotImplementedError('deformable_voxel_grid.z_scale with more than one axis (the reference cannot broadcast it)')
+            zs = F32(ic['z_scale'][0])
+        else:
+            # voxel.py:171-172 takes |samples[1] - samples[0]| of the FLATTENED (Z, 1) samples
+            zs = np.abs(flat[1] - flat[0]) if nz > 1 else F32(1.0)
+        hc.z_scale = float(zs) if zs != 0 else 1.0
+        samples = None
     elif t == 'z_plane':                      # z.py:25-39
         if udb:
             initial, end = F32(-dataset['near']), F32(-dataset['far'])
@@ -469,7 +497,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
             end = F32(ic['end']) if 'end' in ic else F32(dataset['far'])
         else:
             initial, end = F32(ic.get('initial', 0.0)), F32(ic.get('end', 1.0))
-    if t != 'voxel_grid':
+    if t not in ('voxel_grid', 'deformable_voxel_grid'):
         samples = torch_linspace_f32(cdist(initial), cdist(end), Z)
         for k in range(Z):
             hc.samples[k] = float(samples[k])
@@ -592,6 +620,10 @@ def live_head_columns(hc):
     if t in (ISECT['sphere'], ISECT['cylinder']):
         mark(hc.f_z_vals, 3, 1)
         if hc.origin_scale != 0.0:
+            mark(hc.f_z_vals, 0, 3)
+    elif t == ISECT['deformable_voxel_grid']:
+        mark(hc.f_z_vals, 3, 1)
+        if hc.dvg_normal_scale != 0.0:
             mark(hc.f_z_vals, 0, 3)
     elif t in (ISECT['sphere_new'], ISECT['cylinder_new']):
         mark(hc.f_z_vals, 6, 2)

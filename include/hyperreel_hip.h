@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 5
+#define HR_ABI_VERSION 6
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -78,11 +78,12 @@ typedef struct hr_head_field {
 
 /* nlf/intersect: z.py:15-97 (z_plane), primitive.py:366-438 (sphere), :181-253 (cylinder), :441-545
  * (sphere_new), :256-363 (cylinder_new), :131-176 (euclidean_distance_unified), voxel.py:19-112
- * (voxel_grid).  `plane` and `euclidean_distance` cannot run in the reference itself (their scalar
+ * (voxel_grid), :115-215 (deformable_voxel_grid).  `plane` and `euclidean_distance` cannot run in the reference itself (their scalar
  * z_scale breaks Intersect.process_z_vals, base.py:129), so there is nothing to be compatible with. */
 enum {
     HR_ISECT_Z_PLANE = 0, HR_ISECT_SPHERE = 1, HR_ISECT_CYLINDER = 2, HR_ISECT_SPHERE_NEW = 3,
-    HR_ISECT_CYLINDER_NEW = 4, HR_ISECT_EUCLIDEAN_UNIFIED = 5, HR_ISECT_VOXEL_GRID = 6
+    HR_ISECT_CYLINDER_NEW = 4, HR_ISECT_EUCLIDEAN_UNIFIED = 5, HR_ISECT_VOXEL_GRID = 6,
+    HR_ISECT_DEFORMABLE_VOXEL_GRID = 7
 };
 /* nlf/contract.py: IdentityContract (:53-62), MIPNeRFContract (:113-192); BBoxContract (:65-87) and
  * ZDepthContract (:90-111) are both the affine map p -> (p - c_aff_min) / c_aff_size, d -> d / c_aff_fac */
@@ -136,6 +137,9 @@ typedef struct hr_config {
     float resize_initial[3];
     float voxel_scale[3];                /* voxel_grid: per-axis z_scale; samples[] is (Z/3, 3) row-major */
     int32_t isect_outward;               /* voxel_grid: outward_facing (planes mirrored by sign(d)) */
+    int32_t dvg_axes;                    /* deformable_voxel_grid: number of start normals (sample k uses normal k % axes) */
+    float dvg_normals[9];                /*   start_normal rows */
+    float dvg_normal_scale;              /*   normal = z[:3]*normal_scale_factor + start_normal, then normalised */
     int32_t isect_mask_off;              /* mask.stop_iters passed: no near/far masking (base.py:197-198) */
     /* ---- contraction (nlf/contract.py:113-192) */
     int32_t contract_type;               /* HR_CONTRACT_* */

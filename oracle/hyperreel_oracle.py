@@ -528,6 +528,23 @@ class HyperReelOracle:
         if t == 'voxel_grid':                           # voxel.py:19-70: Z/3 planes per axis
             self._setup_voxel_grid(c, udb)
             return
+        if t == 'deformable_voxel_grid':                # voxel.py:115-176
+            if udb:
+                raise NotImplementedError('deformable_voxel_grid with use_dataset_bounds')
+            self.dvg_normals = _f(c.get('start_normal', [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))
+            na = self.dvg_normals.shape[0]
+            self.dvg_scale = F32(c.get('normal_scale_factor', 0.1))
+            initial, end = _f(c.get('initial', [0.0, 0.0, 0.0])), _f(c.get('end', [1.0, 1.0, 1.0]))
+            if self.contract.contract_samples:
+                initial, end = self.contract.contract_distance(initial), self.contract.contract_distance(end)
+            nz = Z // na
+            self.samples = np.stack([torch_linspace(initial[d], end[d], nz) for d in range(na)], -1).reshape(-1)
+            if 'z_scale' in c:
+                zs = _f(c['z_scale'])[0]
+            else:
+                zs = np.abs(self.samples[1] - self.samples[0]) if nz > 1 else F32(1.0)   # on the flattened (Z,1) tensor
+            self.z_scale = F32(1.0) if zs == 0 else F32(zs)
+            return
         if t == 'z_plane':                              # z.py:25-71
             if udb:
                 initial, end = F32(-ds['near']), F32(-ds['far'])
@@ -651,6 +668,15 @@ class HyperReelOracle:
             z = self._process_scalar_z(zv.reshape(B, self.Z))
             diff = pluecker_pos(r[:, :3], r[:, 3:6]) - r[:, :3]
             dists = (z + _signed_base_distance(r[:, 3:6], diff)[:, None]).astype(F32)
+        elif t == 'deformable_voxel_grid':              # voxel.py:178-213, intersect_utils.py:210-236
+            na = self.dvg_normals.shape[0]
+            d = self._process_scalar_z(zv[..., 3])
+            normal = zv[..., :3].reshape(-1, na, 3) * self.dvg_scale + self.dvg_normals[None]
+            normal = _normalize(normal.reshape(B, -1, 3))
+            o_n = np.sum(r[:, None, :3] * normal, -1, dtype=F32)
+            d_n = np.sum(r[:, None, 3:6] * normal, -1, dtype=F32)
+            d_n = np.where(np.abs(d_n) < F32(1e-5), F32(1e12), d_n).astype(F32)
+            dists = ((d - o_n) / d_n).astype(F32)
         elif t == 'voxel_grid':                         # voxel.py:72-112, intersect_utils.py:152-179
             nz = self.Z // 3
             z = zv.reshape(B, nz, 3) * self.voxel_scale[None, None] + self.voxel_samples[None]     # base.py:129

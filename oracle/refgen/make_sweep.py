@@ -116,7 +116,19 @@ def _v_mask_off_unsorted(cfg):
     ic.sort = False
 
 
+def _v_deformable_3axes(cfg):                 # default start normals (x, y, z), 16 planes per axis
+    st = [e for e in cfg.embedding.embeddings.values() if e.get('type') == 'ray_intersect'][0]
+    st.z_channels = 48
+    _pred(cfg).z_channels = 48
+    ic = st.intersect
+    ic.pop('start_normal')
+    ic.normal_scale_factor = 0.3
+    ic.initial = [-1.0, -0.8, -0.2]
+    ic.end = [1.0, 0.9, 1.6]
+
+
 VARIANTS = [
+    ('variant_deformable_3axes', 'shiny_z_deformable', _v_deformable_3axes),
     ('variant_cylinder_new', 'bom_cylinder', _v_cylinder_new),
     ('variant_sphere_new_origins_only', 'immersive_sphere_new', _v_sphere_new_origins_only),
     ('variant_z_depth_contract', 'llff_z_plane', _v_z_depth),
@@ -154,6 +166,17 @@ def main(only=None, force=False):
             print(f'{name:36s} rejected: {e}')
             rejected = e
             if not force:
+                # record whether the reference itself can build and run this YAML at all
+                try:
+                    def ov(cfg):
+                        cfg.color.net.grid_size = ref_shim.to_attr({'start': list(GRID), 'end': list(GRID)})
+                    fn = ref_shim.build_reference(ref_shim.load_model_cfg(base, ov), ds)
+                    v = any(e.get('type') == 'advect_points' for e in raw.embedding.embeddings.values()) or raw.color.net.type == 'tensor_vm_split_time'
+                    ref_shim.run_reference(fn, torch.from_numpy(scenes.random_rays(8, 1, v)))
+                    coverage[name]['reference_runs'] = True
+                except Exception as e2:                      # noqa: BLE001 -- any failure of the reference counts
+                    coverage[name]['reference_runs'] = False
+                    coverage[name]['reference_error'] = f'{type(e2).__name__}: {str(e2).splitlines()[0][:160]}'
                 continue
 
         def overrides(cfg):
