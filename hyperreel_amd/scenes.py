@@ -49,18 +49,14 @@ def mlp_in_channels(pred_cfg):
     return total
 
 
-def mlp_layer_shapes(cfg):
-    """[(out, in)] of the D+2 Linear layers (nlf/nets/mlp.py:127-147)."""
-    emb = cfg['embedding']['embeddings']
-    pred = next(e for e in emb.values() if e['type'] == 'ray_prediction')
-    net = pred['net']
+def _stage_layer_shapes(stage, n_out):
+    net = stage['net']
     if net['type'] == 'zero':                   # ZeroMLP: no Linear on the path (its unused Linear(1,1) is `net.layer`)
         return []
-    n_in = mlp_in_channels(pred)
+    n_in = mlp_in_channels(stage)
     W = net['hidden_channels']
     D = net['depth'] - 2
     skips = list(net.get('skips', []))
-    n_out = pred['z_channels'] * sum(o['channels'] for o in pred['outputs'].values())
     shapes = []
     for i in range(D + 2):
         if i == 0:
@@ -72,6 +68,19 @@ def mlp_layer_shapes(cfg):
         else:
             shapes.append((W, W))
     return shapes
+
+
+def mlp_layer_shapes(cfg):
+    """[(out, in)] of the D+2 Linear layers of the ray_prediction net (nlf/nets/mlp.py:127-147)."""
+    emb = cfg['embedding']['embeddings']
+    pred = next(e for e in emb.values() if e['type'] == 'ray_prediction')
+    return _stage_layer_shapes(pred, pred['z_channels'] * sum(o['channels'] for o in pred['outputs'].values()))
+
+
+def point_mlp_layer_shapes(stage):
+    """Same for a point_prediction stage: out = channels * (out_z // in_z) per point (embedding/point.py:106-125)."""
+    per = int(stage.get('out_z_channels', 1)) // int(stage.get('in_z_channels', 1))
+    return _stage_layer_shapes(stage, per * sum(o['channels'] for o in stage['outputs'].values()))
 
 
 def _uniform(rng, shape, bound):
@@ -100,6 +109,15 @@ def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_s
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.weight'] = _uniform(rng, (o, n_in), b)
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.bias'] = _uniform(rng, (o,), b)
 
+    for pi, e in enumerate(emb.values()):        # point_prediction cascades: a second MLP, one row per coarse sample
+        if e['type'] != 'point_prediction':
+            continue
+        pshapes = point_mlp_layer_shapes(e)
+        for i, (o, n_in) in enumerate(pshapes):
+            mid = '.0' if i < len(pshapes) - 1 else ''
+            b = 1.0 / math.sqrt(n_in)
+            sd[f'{EMB}{pi}.net.layers.{i}{mid}.weight'] = _uniform(rng, (o, n_in), b)
+            sd[f'{EMB}{pi}.net.layers.{i}{mid}.bias'] = _uniform(rng, (o,), b)
     if not shapes:                              # ZeroMLP carries an unused nn.Linear(1, 1) (nlf/nets/mlp.py:27)
         sd[f'{EMB}{pred_idx}.net.layer.weight'] = _uniform(rng, (1, 1), 1.0)
         sd[f'{EMB}{pred_idx}.net.layer.bias'] = _uniform(rng, (1,), 1.0)

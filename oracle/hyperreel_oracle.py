@@ -373,131 +373,13 @@ def eval_sh_bases_deg2(dirs):                          # utils/sh_utils.py:94-11
     return out
 
 
-# --------------------------------------------------------------------------- the model
-class HyperReelOracle:
-    """cfg: the `experiment.model` YAML as a plain dict, AFTER the *_epoch->*_iter
-    rewrite is irrelevant here (inference).  dataset: {near, far, depth_range,
-    num_keyframes, num_frames}.  sd: {reference state_dict key: ndarray}, keys as
-    listed in SURVEY.md section 5 without the leading `render_fn.`."""
+# --------------------------------------------------------------------------- ray_intersect
+class _Isect:
+    """One `ray_intersect` stage (Intersect.__init__ + forward, nlf/intersect/base.py:52-259 and the
+    subclasses in z.py / primitive.py / voxel.py).  A model has one; point_prediction cascades two."""
 
-    EMB = 'model.embedding_model.embeddings.'
-    NET = 'model.color_model.net.'
-
-    def __init__(self, cfg, dataset, sd):
-        self.cfg = cfg
-        self.ds = dataset
-        self.sd = {k: _f(v) for k, v in sd.items() if np.asarray(v).dtype.kind == 'f'}
-        if cfg.get('param', {}).get('fn', 'identity') != 'identity':
-            raise NotImplementedError('model-level ray param other than identity')
-        self.stages = []
-        for idx, (key, ecfg) in enumerate(cfg['embedding']['embeddings'].items()):
-            self.stages.append((idx, ecfg['type'], ecfg))
-        self._setup_prediction()
-        self._setup_intersect()
-        self._setup_color()
-
-    # ---- ray_prediction -------------------------------------------------------------
-    def _setup_prediction(self):
-        (idx, _, ecfg), = [s for s in self.stages if s[1] == 'ray_prediction']
-        self.pred_idx = idx
-        self.pred_cfg = ecfg
-        self.Z = int(ecfg['z_channels'])
-        self.out_names = list(ecfg['outputs'].keys())
-        self.out_shapes = [int(ecfg['outputs'][k]['channels']) for k in self.out_names]
-        self.out_acts = [Act(ecfg['outputs'][k].get('activation')) for k in self.out_names]
-        if ecfg.get('ray_outputs'):
-            raise NotImplementedError('ray_outputs are outside the hot-path scope')
-        net = ecfg['net']
-        self.zero_net = net['type'] == 'zero'          # ZeroMLP, nlf/nets/mlp.py:14-33
-        if self.zero_net:
-            self.D, self.skips, self.layers = 0, [], []
-            return
-        if net['type'] != 'base':
-            raise NotImplementedError(f"net {net['type']} is outside the hot-path scope")
-        self.D = int(net['depth']) - 2                 # ray.py:283-285
-        self.skips = list(net.get('skips', []))
-        self.layers = []
-        pre = f'{self.EMB}{idx}.net.layers.'
-        for i in range(self.D + 2):
-            mid = '.0' if i < self.D + 1 else ''       # Sequential(Linear, act) vs bare Linear
-            self.layers.append((self.sd[f'{pre}{i}{mid}.weight'], self.sd[f'{pre}{i}{mid}.bias']))
-
-    def _param_pe(self, rays):
-        cols = []
-        for pkey, pcfg in self.pred_cfg['params'].items():
-            x = rays[:, pcfg['start']:pcfg['end']]
-            p = pcfg['param']
-            fn = p['fn']
-            if fn == 'identity':
-                y = x
-            elif fn == 'pluecker':                     # param.py:244-253
-                origin = _f(p.get('origin', [0.0, 0.0, 0.0]))
-                o = x[:, :3] - origin[None]
-                d = x[:, 3:6]
-                n = np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))
-                d = d / np.maximum(n, F32(1e-12))
-                if p.get('use_local_param', False):
-                    raise NotImplementedError
-                m = np.cross(o, d).astype(F32)
-                y = np.concatenate([d * F32(p.get('direction_multiplier', 1.0)),
-                                    m * F32(p.get('moment_multiplier', 1.0))], -1)
-            elif fn == 'two_plane':                    # param.py:87-115
-                origin = _f(p.get('origin', [0.0, 0.0, 0.0]))
-                r = np.concatenate([x[:, :3] - origin[None], x[:, 3:6]], -1)
-                if p.get('use_local_param', False):
-                    raise NotImplementedError
-                t1 = intersect_axis_plane(r, F32(p.get('near', -1.0)), 2)
-                t2 = intersect_axis_plane(r, F32(p.get('far', 0.0)), 2)
-                y = np.concatenate([r[:, :2] + r[:, 3:5] * t1[:, None],
-                                    r[:, :2] + r[:, 3:5] * t2[:, None]], -1)
-            else:
-                raise NotImplementedError(f'ray param {fn} is outside the hot-path scope')
-            y = y.astype(F32)
-            pe = pcfg.get('pe')
-            if pe is not None:                         # pe.py:210-221 / 53-66
-                if pe['type'] not in ('windowed', 'basic'):
-                    raise NotImplementedError(pe['type'])
-                n = int(pe['n_freqs'])
-                fm = pe.get('freq_multiplier', 2.0)
-                bm = F32(pe.get('base_multiplier', 1.0)) if pe['type'] == 'windowed' else F32(1.0)
-                freqs = (F32(fm) ** torch_linspace(1.0, float(n), n)).astype(F32)
-                out = [] if pe.get('exclude_identity', False) and pe['type'] == 'windowed' else [y]
-                if pe['type'] == 'windowed':
-                    for f in freqs:
-                        out += [np.sin(bm * f * y), np.cos(bm * f * y)]
-                elif n > 0:                            # BasicPE: [x, sin(all), cos(all)], channel-major
-                    cur = (freqs[None, None] * y[..., None]).reshape(y.shape[0], -1)
-                    out += [np.sin(cur), np.cos(cur)]
-                y = np.concatenate(out, -1).astype(F32)
-            cols.append(y)
-        return np.concatenate(cols, -1).astype(F32)
-
-    def mlp(self, x):                                  # mlp.py:159-172
-        inp = x
-        for i, (w, b) in enumerate(self.layers):
-            if i in self.skips:
-                x = np.concatenate([inp, x], -1)
-            x = (x @ w.T + b).astype(F32)
-            if i < self.D + 1:
-                x = np.where(x >= 0, x, x * F32(0.01)).astype(F32)
-        return x
-
-    def _predict(self, rays, x):                       # ray.py:316-347
-        if self.zero_net:
-            h = np.zeros((rays.shape[0], self.Z * sum(self.out_shapes)), F32)
-        else:
-            h = self.mlp(self._param_pe(rays))
-        x['_head_raw'] = h
-        h = h.reshape(rays.shape[0], self.Z, -1)
-        o = 0
-        for name, n, act in zip(self.out_names, self.out_shapes, self.out_acts):
-            x[name] = act(h[..., o:o + n])
-            o += n
-        return x
-
-    # ---- ray_intersect ---------------------------------------------------------------
-    def _setup_intersect(self):
-        (idx, _, ecfg), = [s for s in self.stages if s[1] == 'ray_intersect']
+    def __init__(self, ecfg, Z_expected, ds):
+        self.Z, self.ds = Z_expected, ds
         c = ecfg['intersect']
         self.isect = c
         self.isect_type = c['type']
@@ -622,7 +504,7 @@ class HyperReelOracle:
             z = self.contract.inverse_contract_distance(z)
         return z.astype(F32)
 
-    def _intersect(self, rays, x):                      # base.py:142-259
+    def __call__(self, rays, x):                        # base.py:142-259
         B = rays.shape[0]
         r = np.concatenate([rays[:, :3] - self.origin[None], rays[:, 3:6]], -1).astype(F32)
         zv = x['z_vals']                                # (B,Z,zc) already through its head activation
@@ -705,6 +587,197 @@ class HyperReelOracle:
         x['weights'] = np.ones_like(dists)
         return x
 
+
+# --------------------------------------------------------------------------- the model
+class HyperReelOracle:
+    """cfg: the `experiment.model` YAML as a plain dict, AFTER the *_epoch->*_iter
+    rewrite is irrelevant here (inference).  dataset: {near, far, depth_range,
+    num_keyframes, num_frames}.  sd: {reference state_dict key: ndarray}, keys as
+    listed in SURVEY.md section 5 without the leading `render_fn.`."""
+
+    EMB = 'model.embedding_model.embeddings.'
+    NET = 'model.color_model.net.'
+
+    def __init__(self, cfg, dataset, sd):
+        self.cfg = cfg
+        self.ds = dataset
+        self.sd = {k: _f(v) for k, v in sd.items() if np.asarray(v).dtype.kind == 'f'}
+        if cfg.get('param', {}).get('fn', 'identity') != 'identity':
+            raise NotImplementedError('model-level ray param other than identity')
+        self.stages = []
+        for idx, (key, ecfg) in enumerate(cfg['embedding']['embeddings'].items()):
+            self.stages.append((idx, ecfg['type'], ecfg))
+        self._setup_prediction()
+        # one _Isect per ray_intersect stage; the sample count of a stage is that of the prediction feeding it
+        self._isects = {}
+        Z = self.Z
+        for idx, typ, ecfg in self.stages:
+            if typ == 'point_prediction':
+                Z = int(ecfg.get('out_z_channels', 1))
+            elif typ == 'ray_intersect':
+                self._isects[idx] = _Isect(ecfg, Z, self.ds)
+        self._setup_point_prediction()
+        last = self._isects[max(self._isects)]
+        for k, v in vars(last).items():                  # single-stage view kept for tests / tools: orc.samples, orc.near ...
+            if k not in ('Z', 'ds'):
+                setattr(self, k, v)
+        self.Z_final = last.Z
+        self._setup_color()
+
+    # ---- ray_prediction -------------------------------------------------------------
+    def _setup_prediction(self):
+        (idx, _, ecfg), = [s for s in self.stages if s[1] == 'ray_prediction']
+        self.pred_idx = idx
+        self.pred_cfg = ecfg
+        self.Z = int(ecfg['z_channels'])
+        self.out_names = list(ecfg['outputs'].keys())
+        self.out_shapes = [int(ecfg['outputs'][k]['channels']) for k in self.out_names]
+        self.out_acts = [Act(ecfg['outputs'][k].get('activation')) for k in self.out_names]
+        if ecfg.get('ray_outputs'):
+            raise NotImplementedError('ray_outputs are outside the hot-path scope')
+        net = ecfg['net']
+        self.zero_net = net['type'] == 'zero'          # ZeroMLP, nlf/nets/mlp.py:14-33
+        if self.zero_net:
+            self.D, self.skips, self.layers = 0, [], []
+            return
+        if net['type'] != 'base':
+            raise NotImplementedError(f"net {net['type']} is outside the hot-path scope")
+        self.D, self.skips, self.layers = self._load_layers(idx, net)
+
+    def _load_layers(self, idx, net):
+        D = int(net['depth']) - 2                      # ray.py:283-285 / point.py:117-119
+        layers = []
+        pre = f'{self.EMB}{idx}.net.layers.'
+        for i in range(D + 2):
+            mid = '.0' if i < D + 1 else ''            # Sequential(Linear, act) vs bare Linear
+            layers.append((self.sd[f'{pre}{i}{mid}.weight'], self.sd[f'{pre}{i}{mid}.bias']))
+        return D, list(net.get('skips', [])), layers
+
+    def _param_pe(self, rays):
+        return self._param_pe_cfg(self.pred_cfg['params'], rays)
+
+    def _param_pe_cfg(self, params, rays):
+        cols = []
+        for pkey, pcfg in params.items():
+            x = rays[:, pcfg['start']:pcfg['end']]
+            p = pcfg['param']
+            fn = p['fn']
+            if fn == 'identity':
+                y = x
+            elif fn == 'pluecker':                     # param.py:244-253
+                origin = _f(p.get('origin', [0.0, 0.0, 0.0]))
+                o = x[:, :3] - origin[None]
+                d = x[:, 3:6]
+                n = np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))
+                d = d / np.maximum(n, F32(1e-12))
+                if p.get('use_local_param', False):
+                    raise NotImplementedError
+                m = np.cross(o, d).astype(F32)
+                y = np.concatenate([d * F32(p.get('direction_multiplier', 1.0)),
+                                    m * F32(p.get('moment_multiplier', 1.0))], -1)
+            elif fn == 'two_plane':                    # param.py:87-115
+                origin = _f(p.get('origin', [0.0, 0.0, 0.0]))
+                r = np.concatenate([x[:, :3] - origin[None], x[:, 3:6]], -1)
+                if p.get('use_local_param', False):
+                    raise NotImplementedError
+                t1 = intersect_axis_plane(r, F32(p.get('near', -1.0)), 2)
+                t2 = intersect_axis_plane(r, F32(p.get('far', 0.0)), 2)
+                y = np.concatenate([r[:, :2] + r[:, 3:5] * t1[:, None],
+                                    r[:, :2] + r[:, 3:5] * t2[:, None]], -1)
+            else:
+                raise NotImplementedError(f'ray param {fn} is outside the hot-path scope')
+            y = y.astype(F32)
+            pe = pcfg.get('pe')
+            if pe is not None:                         # pe.py:210-221 / 53-66
+                if pe['type'] not in ('windowed', 'basic'):
+                    raise NotImplementedError(pe['type'])
+                n = int(pe['n_freqs'])
+                fm = pe.get('freq_multiplier', 2.0)
+                bm = F32(pe.get('base_multiplier', 1.0)) if pe['type'] == 'windowed' else F32(1.0)
+                freqs = (F32(fm) ** torch_linspace(1.0, float(n), n)).astype(F32)
+                out = [] if pe.get('exclude_identity', False) and pe['type'] == 'windowed' else [y]
+                if pe['type'] == 'windowed':
+                    for f in freqs:
+                        out += [np.sin(bm * f * y), np.cos(bm * f * y)]
+                elif n > 0:                            # BasicPE: [x, sin(all), cos(all)], channel-major
+                    cur = (freqs[None, None] * y[..., None]).reshape(y.shape[0], -1)
+                    out += [np.sin(cur), np.cos(cur)]
+                y = np.concatenate(out, -1).astype(F32)
+            cols.append(y)
+        return np.concatenate(cols, -1).astype(F32)
+
+    def mlp(self, x):                                  # mlp.py:159-172
+        return self._run_mlp(x, self.D, self.skips, self.layers)
+
+    @staticmethod
+    def _run_mlp(x, D, skips, layers):
+        inp = x
+        for i, (w, b) in enumerate(layers):
+            if i in skips:
+                x = np.concatenate([inp, x], -1)
+            x = (x @ w.T + b).astype(F32)
+            if i < D + 1:
+                x = np.where(x >= 0, x, x * F32(0.01)).astype(F32)
+        return x
+
+    # ---- point_prediction (cascades) ---------------------------------------------------
+    def _setup_point_prediction(self):                 # point.py:39-135
+        self._pp = {}
+        for idx, typ, e in self.stages:
+            if typ != 'point_prediction':
+                continue
+            if e.get('filter', False):
+                raise NotImplementedError('point_prediction.filter')
+            if e.get('rays_name', 'rays') != 'rays' or e.get('points_name', 'points') != 'points':
+                raise NotImplementedError('point_prediction with renamed rays / points')
+            if e['net']['type'] != 'base':
+                raise NotImplementedError(f"point_prediction net {e['net']['type']}")
+            outs = e['outputs']
+            if any(o.get('residual', False) for o in outs.values()):
+                raise NotImplementedError('residual point_prediction outputs')
+            D, skips, layers = self._load_layers(idx, e['net'])
+            self._pp[idx] = {
+                'cfg': e, 'D': D, 'skips': skips, 'layers': layers, 'names': list(outs.keys()),
+                'shapes': [int(o['channels']) for o in outs.values()], 'acts': [Act(o.get('activation')) for o in outs.values()]}
+
+    def _point_prediction(self, idx, rays, x):         # point.py:137-203
+        pp = self._pp[idx]
+        e = pp['cfg']
+        pts = x['points']
+        B, Zi = pts.shape[:2]
+        cols = []
+        for name, n in e['inputs'].items():
+            if name == 'viewdirs':
+                cols.append(np.repeat(rays[:, None, 3:6], Zi, 1))
+            elif name == 'origins':
+                cols.append(np.repeat(rays[:, None, 0:3], Zi, 1))
+            elif name == 'times':
+                cols.append(np.repeat(rays[:, None, -1:], Zi, 1))
+            else:
+                cols.append(x[name][..., :int(n)])
+        inp = np.concatenate(cols, -1).astype(F32).reshape(B * Zi, -1)
+        h = self._run_mlp(self._param_pe_cfg(e['params'], inp), pp['D'], pp['skips'], pp['layers'])
+        x['_head_raw_points'] = h
+        h = h.reshape(B, -1, sum(pp['shapes']))
+        o = 0
+        for name, n, act in zip(pp['names'], pp['shapes'], pp['acts']):
+            x[name] = act(h[..., o:o + n])
+            o += n
+        return x
+
+    def _predict(self, rays, x):                       # ray.py:316-347
+        if self.zero_net:
+            h = np.zeros((rays.shape[0], self.Z * sum(self.out_shapes)), F32)
+        else:
+            h = self.mlp(self._param_pe(rays))
+        x['_head_raw'] = h
+        h = h.reshape(rays.shape[0], self.Z, -1)
+        o = 0
+        for name, n, act in zip(self.out_names, self.out_shapes, self.out_acts):
+            x[name] = act(h[..., o:o + n])
+            o += n
+        return x
+
     # ---- point stages ------------------------------------------------------------------
     def _advect(self, rays, x, ecfg):                   # point.py:780-831, flow_utils.py:10-35
         if ecfg.get('use_angular_flow', False):
@@ -724,8 +797,9 @@ class HyperReelOracle:
             x['spatial_flow'] = flow
             points = points + flow * toff
         x['points'] = points.astype(F32)
-        x['base_times'] = np.repeat(base_t[:, None, :], self.Z, 1)
-        x['time_offset'] = np.repeat(toff, self.Z, 1)
+        Zc = points.shape[1]
+        x['base_times'] = np.repeat(base_t[:, None, :], Zc, 1)
+        x['time_offset'] = np.repeat(toff, Zc, 1)
         return x
 
     def _point_offset(self, x, ecfg):                    # point.py:371-396
@@ -746,19 +820,22 @@ class HyperReelOracle:
             if typ == 'ray_prediction':
                 x = self._predict(rays, x)
             elif typ == 'ray_intersect':
-                x = self._intersect(rays, x)
+                x = self._isects[idx](rays, x)
+            elif typ == 'point_prediction':
+                x = self._point_prediction(idx, rays, x)
             elif typ == 'advect_points':
                 x = self._advect(rays, x, ecfg)
             elif typ == 'point_offset':
                 x = self._point_offset(x, ecfg)
             elif typ == 'add_point_outputs':             # point.py:857-869
                 eo = ecfg['extra_outputs']
+                Zc = x['points'].shape[1]
                 if 'times' in eo and 'times' not in x:
-                    x['times'] = np.repeat(rays[:, None, -1:], self.Z, 1)
+                    x['times'] = np.repeat(rays[:, None, -1:], Zc, 1)
                 if 'base_times' in eo and 'base_times' not in x:
-                    x['base_times'] = np.repeat(rays[:, None, -1:], self.Z, 1)
+                    x['base_times'] = np.repeat(rays[:, None, -1:], Zc, 1)
                 if 'viewdirs' in eo and 'viewdirs' not in x:
-                    x['viewdirs'] = np.repeat(rays[:, None, 3:6], self.Z, 1)
+                    x['viewdirs'] = np.repeat(rays[:, None, 3:6], Zc, 1)
             elif typ == 'color_transform':              # point.py:585-596: a no-op unless dataset.val_all
                 if self.ds.get('val_all', False):
                     tab = self.sd[f'{self.EMB}{idx}.color_embedding']
