@@ -67,6 +67,11 @@ struct hr_model {
     float* head = nullptr;
     int64_t chunk = 0;
     int64_t packed_bytes = 0;
+    // point_prediction cascade (hr_model_create_cascade): `this` is the fine level (point MLP, second intersect,
+    // colour); `coarse` holds the ray MLP and the first intersect and owns no grids
+    hr_model* coarse = nullptr;
+    bool is_coarse = false;
+    float* rows = nullptr;   // input rows of the point MLP for one chunk: (chunk * casc_in_z, casc_row_dim)
 };
 
 namespace {
@@ -77,7 +82,11 @@ int layer_in(const hr_config& c, int l)
     return c.mlp_hidden + (((c.mlp_skip_mask >> l) & 1) ? c.mlp_in : 0);
 }
 
-int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? c.z_channels * c.preds_per_z : c.mlp_hidden; }
+// samples whose head values one MLP row produces: all Z of a ray, or Z / casc_in_z per coarse point
+int samples_per_row(const hr_config& c) { return c.casc_in_z > 0 ? c.z_channels / c.casc_in_z : c.z_channels; }
+int rows_per_ray(const hr_config& c) { return c.casc_in_z > 0 ? c.casc_in_z : 1; }
+
+int layer_out(const hr_config& c, int l) { return (l == c.mlp_layers - 1) ? samples_per_row(c) * c.preds_per_z : c.mlp_hidden; }
 
 // z_vals channels read per sample: z (z_plane, euclidean_distance_unified, voxel_grid), origin xyz + radius
 // (sphere/cylinder), origin xyz + resize xyz + raw offset + radius (sphere_new/cylinder_new)
@@ -88,7 +97,7 @@ int isect_z_channels(int t)
     return 1;
 }
 
-int validate(const hr_config& c)
+int validate(const hr_config& c, bool coarse = false)
 {
     if (c.ray_dim != 6 && c.ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8 (got %d)", c.ray_dim);
     if (c.n_groups < 1 || c.n_groups > HR_MAX_GROUPS) return fail(HR_E_INVALID, "n_groups out of range");
@@ -124,7 +133,23 @@ int validate(const hr_config& c)
     if (c.advect && c.use_spatial_flow && (c.f_spatial_flow.offset < 0 || c.f_spatial_flow.channels != 3))
         return fail(HR_E_INVALID, "spatial_flow head missing");
     if (c.video && c.ray_dim != 8) return fail(HR_E_INVALID, "video net needs 8-column rays");
-    if (c.video && (!c.advect || c.num_keyframes < 1)) return fail(HR_E_INVALID, "video net needs the advect stage and num_keyframes >= 1");
+    if (c.video && !coarse && (!c.advect || c.num_keyframes < 1)) return fail(HR_E_INVALID, "video net needs the advect stage and num_keyframes >= 1");
+    if (c.casc_in_z < 0 || (coarse && c.casc_in_z != 0)) return fail(HR_E_INVALID, "casc_in_z is set on the fine config of a cascade only");
+    if (c.casc_in_z > 0) {
+        if (c.z_channels % c.casc_in_z) return fail(HR_E_INVALID, "z_channels must be a multiple of casc_in_z");
+        if (c.casc_n_inputs < 1 || c.casc_n_inputs > 4 || c.casc_row_dim < 1 || c.casc_row_dim > 8)
+            return fail(HR_E_INVALID, "point_prediction rows: 1..4 inputs, 1..8 columns");
+        int sum = 0;
+        for (int i = 0; i < c.casc_n_inputs; ++i) {
+            if (c.casc_input_kind[i] < HR_PIN_POINTS || c.casc_input_kind[i] > HR_PIN_TIMES || c.casc_input_dim[i] < 1 || c.casc_input_dim[i] > 3)
+                return fail(HR_E_INVALID, "bad point_prediction input %d", i);
+            sum += c.casc_input_dim[i];
+        }
+        if (sum != c.casc_row_dim) return fail(HR_E_INVALID, "casc_row_dim does not match the inputs");
+        for (int g = 0; g < c.n_groups; ++g)
+            if (c.groups[g].fn != HR_PARAM_IDENTITY || c.groups[g].end > c.casc_row_dim)
+                return fail(HR_E_INVALID, "point_prediction params must be identity groups over the row's columns");
+    }
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
@@ -235,17 +260,18 @@ int hr_sizeof_config(void) { return (int)sizeof(hr_config); }
 
 const char* hr_last_error(void) { return g_err; }
 
-int hr_model_create(const hr_config* cfg, hr_model** out)
+static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
 {
     if (!cfg || !out) return fail(HR_E_INVALID, "null argument");
     *out = nullptr;
-    int rc = validate(*cfg);
+    int rc = validate(*cfg, coarse);
     if (rc != HR_OK) return rc;
     int ndev = 0;
     HR_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(HR_E_HIP, "no HIP device");
     hr_model* m = new hr_model();
     m->cfg = *cfg;
+    m->is_coarse = coarse;
     analyse_live_columns(m);
     const hr_config& c = m->cfg;
     char name[64];
@@ -254,6 +280,10 @@ int hr_model_create(const hr_config* cfg, hr_model** out)
         m->expect[name] = sizeof(float) * (size_t)layer_out(c, l) * layer_in(c, l);
         snprintf(name, sizeof(name), "mlp.%d.bias", l);
         m->expect[name] = sizeof(float) * (size_t)layer_out(c, l);
+    }
+    if (coarse) {          // ray MLP + first intersect only: no grids
+        *out = m;
+        return HR_OK;
     }
     int n_app_sum = 0;
     for (int j = 0; j < 3; ++j) {
@@ -281,9 +311,45 @@ int hr_model_create(const hr_config* cfg, hr_model** out)
     return HR_OK;
 }
 
+int hr_model_create(const hr_config* cfg, hr_model** out)
+{
+    if (cfg && cfg->casc_in_z != 0) return fail(HR_E_INVALID, "a cascade's fine config goes through hr_model_create_cascade");
+    return create_level(cfg, false, out);
+}
+
+int hr_model_create_cascade(const hr_config* coarse, const hr_config* fine, hr_model** out)
+{
+    if (!coarse || !fine || !out) return fail(HR_E_INVALID, "null argument");
+    *out = nullptr;
+    if (fine->casc_in_z <= 0) return fail(HR_E_INVALID, "the fine config needs casc_in_z (samples of the coarse level)");
+    if (fine->casc_in_z != coarse->z_channels) return fail(HR_E_INVALID, "casc_in_z %d != coarse z_channels %d", fine->casc_in_z, coarse->z_channels);
+    if (fine->ray_dim != coarse->ray_dim) return fail(HR_E_INVALID, "both levels read the same rays: ray_dim must agree");
+    hr_model* c = nullptr;
+    int rc = create_level(coarse, true, &c);
+    if (rc != HR_OK) return rc;
+    hr_model* m = nullptr;
+    rc = create_level(fine, false, &m);
+    if (rc != HR_OK) {
+        hr_model_destroy(c);
+        return rc;
+    }
+    m->coarse = c;
+    *out = m;
+    return HR_OK;
+}
+
 int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes)
 {
     if (!m || !name) return fail(HR_E_INVALID, "null argument");
+    std::string key = name;
+    if (m->coarse) {                      // cascade: mlp.* is the coarse ray MLP, mlp1.* the point MLP of this level
+        if (key.compare(0, 4, "mlp.") == 0) {
+            m->finalized = false;
+            return hr_model_upload(m->coarse, name, ptr, bytes);
+        }
+        if (key.compare(0, 5, "mlp1.") == 0) key = "mlp." + key.substr(5);
+    }
+    name = key.c_str();
     auto it = m->expect.find(name);
     if (it == m->expect.end()) return fail(HR_E_INVALID, "unknown tensor name '%s'", name);
     if (bytes != it->second) return fail(HR_E_INVALID, "tensor '%s': expected %zu bytes, got %zu", name, it->second, bytes);
@@ -302,16 +368,22 @@ int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes
 int hr_model_finalize(hr_model* m)
 {
     if (!m) return fail(HR_E_INVALID, "null argument");
+    if (m->coarse) {
+        int rc = hr_model_finalize(m->coarse);
+        if (rc != HR_OK) return rc;
+    }
     const hr_config& c = m->cfg;
     for (auto& kv : m->expect)
-        if (m->raw.find(kv.first) == m->raw.end()) return fail(HR_E_MISSING, "tensor '%s' was never uploaded", kv.first.c_str());
+        if (m->raw.find(kv.first) == m->raw.end())
+            return fail(HR_E_MISSING, "tensor '%s%s' was never uploaded", (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? "mlp1." : "",
+                        (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? kv.first.c_str() + 4 : kv.first.c_str());
     m->packed_bytes = 0;
     char name[64];
 
     // ---- MLP: MFMA B-operand tiles (layout documented in hr_kernels.h)
     const int W = c.mlp_hidden;
     m->k0p = (c.mlp_in + 15) & ~15;
-    m->n_out = c.z_channels * m->p_live;
+    m->n_out = samples_per_row(c) * m->p_live;     // head columns of one MLP row
     const int P_user = c.preds_per_z, P_live = m->p_live;
     int live_cols[64];
     for (int i = 0, j = 0; i < P_user; ++i)
@@ -385,6 +457,12 @@ int hr_model_finalize(hr_model* m)
         HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         m->n_tiles[l] = nt;
         m->packed_bytes += (int64_t)nb * sizeof(float);
+    }
+
+    if (m->is_coarse) {      // coarse level of a cascade: no grids
+        HR_HIP(hipDeviceSynchronize());
+        m->finalized = true;
+        return HR_OK;
     }
 
     // ---- grids: channel-last texels, density | appearance interleaved per plane pair
@@ -463,10 +541,10 @@ int hr_model_finalize(hr_model* m)
     HR_HIP(hipGetLastError());
     m->finalized = true;
     if (m->chunk == 0) {
-        // 131072 rays per launch measured best among 16k..640k (DoNeRF); wide heads (z_channels up to 256)
+        // 131072 rays per launch measured best among 16k..640k (DoNeRF); wide heads (z_channels up to 256, cascades)
         // are held to a 512 MiB workspace
-        const int64_t nq = ((int64_t)m->cfg.z_channels * m->p_live + 3) / 4;
-        int64_t rays = (512ll << 20) / (nq * 16);
+        const int64_t nq = ((int64_t)m->n_out + 3) / 4;
+        int64_t rays = (512ll << 20) / (nq * 16 * rows_per_ray(m->cfg));
         rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
         return hr_model_reserve(m, rays);
     }
@@ -480,11 +558,18 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     rays_per_chunk = (rays_per_chunk + 63) & ~(int64_t)63;
     if (rays_per_chunk == m->chunk && m->head) return HR_OK;
     free_dev(m->head);
+    free_dev(m->rows);
     m->chunk = 0;
-    const size_t nq = ((size_t)m->cfg.z_channels * m->p_live + 3) / 4;
-    const size_t bytes = sizeof(float) * (size_t)rays_per_chunk * nq * 4;   // HQ layout, rays_per_chunk is a multiple of 64
+    const size_t n_rows = (size_t)rays_per_chunk * rows_per_ray(m->cfg);      // a multiple of 64
+    const size_t nq = ((size_t)samples_per_row(m->cfg) * m->p_live + 3) / 4;
+    const size_t bytes = sizeof(float) * n_rows * nq * 4;                        // HQ layout over rows
     HR_HIP(hipMalloc((void**)&m->head, bytes));
     if (m->cfg.mlp_layers == 0) HR_HIP(hipMemset(m->head, 0, bytes));   // ZeroMLP: written once, only ever read
+    if (m->coarse) {
+        int rc = hr_model_reserve(m->coarse, rays_per_chunk);
+        if (rc != HR_OK) return rc;
+        HR_HIP(hipMalloc((void**)&m->rows, sizeof(float) * n_rows * m->cfg.casc_row_dim));
+    }
     m->chunk = rays_per_chunk;
     return HR_OK;
 }
@@ -532,6 +617,43 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
         if (it != m->raw.end()) a.color_table = it->second.p;
     }
     a.dbg_mode = 0;
+    a.rows_per_ray = rows_per_ray(m->cfg);
+    a.rows_out = nullptr;
+    a.row_dim = a.n_row_inputs = 0;
+    for (int i = 0; i < 4; ++i) a.row_kind[i] = a.row_len[i] = 0;
+}
+
+// Cascade, everything before the final sample kernel: coarse MLP -> coarse intersect (emits the point MLP's input
+// rows, one per coarse sample) -> point MLP over n * casc_in_z rows.  Leaves the fine head in m->head.
+static void launch_cascade_front(hr_model* m, const float* rays, int64_t n, hipStream_t st)
+{
+    hr_model* c0 = m->coarse;
+    HrMlpArgs ma;
+    fill_mlp_args(c0, ma, rays, n);
+    launch_mlp(c0->kcfg, ma, st);
+    HrSampleArgs sa;
+    fill_sample_args(c0, sa, rays, n, nullptr);
+    sa.rows_out = m->rows;
+    sa.row_dim = m->cfg.casc_row_dim;
+    sa.n_row_inputs = m->cfg.casc_n_inputs;
+    for (int i = 0; i < 4; ++i) { sa.row_kind[i] = m->cfg.casc_input_kind[i]; sa.row_len[i] = m->cfg.casc_input_dim[i]; }
+    hr_launch_samples(c0->kcfg, sa, st);
+    hr_config kc = m->kcfg;
+    kc.ray_dim = m->cfg.casc_row_dim;            // the point MLP's "rays" are the rows
+    HrMlpArgs mb;
+    fill_mlp_args(m, mb, m->rows, n * m->cfg.casc_in_z);
+    launch_mlp(kc, mb, st);
+}
+
+static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st)
+{
+    if (m->coarse) {
+        launch_cascade_front(m, rays, n, st);
+        return;
+    }
+    HrMlpArgs ma;
+    fill_mlp_args(m, ma, rays, n);
+    launch_mlp(m->kcfg, ma, st);
 }
 
 static int check_render(const hr_model* m, const float* rays, int64_t n, const float* rgb)
@@ -557,9 +679,7 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
         const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
         const float* rays = rays_dev + r0 * c.ray_dim;
-        HrMlpArgs ma;
-        fill_mlp_args(m, ma, rays, n);
-        launch_mlp(m->kcfg, ma, st);
+        launch_front(m, rays, n, st);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
         if (fields) {
@@ -569,7 +689,7 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
             if (fields->weights_dev) sa.fields.weights_dev = fields->weights_dev + r0 * Z;
             if (fields->head_dev)
                 hr_launch_head_export(m->head, fields->head_dev + r0 * (int64_t)Z * c.preds_per_z, n, Z, c.preds_per_z, m->p_live,
-                                      (m->n_out + 3) / 4, m->col_map, st);
+                                      (m->n_out + 3) / 4, rows_per_ray(c), m->col_map, st);
         }
         hr_launch_samples(m->kcfg, sa, st);
     }
@@ -599,9 +719,7 @@ int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* strea
     int rc = check_render(m, rays_dev, n_rays, rays_dev);
     if (rc != HR_OK) return rc;
     if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
-    HrMlpArgs ma;
-    fill_mlp_args(m, ma, rays_dev, n_rays);
-    launch_mlp(m->kcfg, ma, (hipStream_t)stream);
+    launch_front(m, rays_dev, n_rays, (hipStream_t)stream);   // cascades: everything up to the fine head
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -623,6 +741,7 @@ int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsig
     int rc = check_render(m, rays_dev, n_rays, rays_dev);
     if (rc != HR_OK) return rc;
     if (n_rays > m->chunk) return fail(HR_E_INVALID, "n_rays exceeds the reserved chunk (%lld)", (long long)m->chunk);
+    if (m->coarse) return fail(HR_E_INVALID, "hr_debug_trace_mlp does not support cascades");
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays_dev, n_rays);
     ma.trace = trace_dev;
@@ -636,7 +755,8 @@ int64_t hr_model_device_bytes(const hr_model* m)
     if (!m) return 0;
     int64_t raw = 0;
     for (auto& kv : m->raw) raw += (int64_t)kv.second.bytes;
-    return raw + m->packed_bytes + (int64_t)sizeof(float) * m->chunk * m->cfg.z_channels * m->p_live;
+    return raw + m->packed_bytes + (int64_t)sizeof(float) * m->chunk * m->cfg.z_channels * m->p_live +
+           (m->rows ? (int64_t)sizeof(float) * m->chunk * m->cfg.casc_in_z * m->cfg.casc_row_dim : 0) + hr_model_device_bytes(m->coarse);
 }
 
 void hr_model_destroy(hr_model* m)
@@ -654,6 +774,8 @@ void hr_model_destroy(hr_model* m)
     }
     free_dev(m->basis);
     free_dev(m->head);
+    free_dev(m->rows);
+    hr_model_destroy(m->coarse);
     delete m;
 }
 

@@ -72,6 +72,12 @@ struct HrSampleArgs {
     int n_basis_cols;       // sum of the real appearance channels of the sampled planes
     int ca_total;           // padded appearance slots (multiple of 4) = sum 4*ca4
     const float* color_table;  // (color_table_views, 12) per-camera [3x3 | shift], or NULL
+    // point_prediction cascades (hr_model_create_cascade)
+    int rows_per_ray;       // head rows per ray: 1, or casc_in_z when the head comes from the point MLP
+                            //   (sample k reads row ray*rows_per_ray + k / M at columns (k % M) * P.., M = Z / rows_per_ray)
+    float* rows_out;        // coarse pass only: input rows of the point MLP, (n_rays * Z, row_dim); no colour is produced
+    int row_dim, n_row_inputs;
+    int row_kind[4], row_len[4];   // HR_PIN_* and columns of each input
     int dbg_mode;           // profiling only (HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 
@@ -91,7 +97,8 @@ struct HrColMap {
     int col[64];
 };
 // diagnostics export of the raw head in the user's (n, Z*P) layout; pruned columns read as 0
-void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, const HrColMap& map,
+void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, int rows_per_ray,
+                           const HrColMap& map,
                            hipStream_t stream);
 void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 

@@ -31,8 +31,9 @@ __global__ void hr_interleave_half_kernel(const float* __restrict__ src, _Float1
 
 // out[r][k*P + c] = head[r][k*P_live + col_map[c]] (0 where the column was pruned)
 __global__ void hr_head_export_kernel(const float* __restrict__ head, float* __restrict__ out, int64_t n_rays, int Z, int P,
-                                      int P_live, int nq, HrColMap map)
+                                      int P_live, int nq, int rows_per_ray, HrColMap map)
 {
+    const int M = Z / rows_per_ray;   // samples per head row (Z unless the head comes from a point MLP)
     const int n_out = Z * P;
     const int64_t total = n_rays * n_out;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -40,18 +41,19 @@ __global__ void hr_head_export_kernel(const float* __restrict__ head, float* __r
         const int n = (int)(i - r * n_out);
         const int k = n / P, c = n - k * P;
         const int cn = map.col[c];
-        out[i] = (cn >= 0) ? head[hr_head_index(r, k * P_live + cn, nq)] : 0.0f;
+        out[i] = (cn >= 0) ? head[hr_head_index(r * rows_per_ray + k / M, (k % M) * P_live + cn, nq)] : 0.0f;
     }
 }
 
-void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, const HrColMap& map,
-                           hipStream_t stream)
+void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, int rows_per_ray,
+                           const HrColMap& map, hipStream_t stream)
 {
     const int64_t total = n_rays * Z * P;
     if (total <= 0) return;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(hr_head_export_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, head, out, n_rays, Z, P, P_live, nq, map);
+    hipLaunchKernelGGL(hr_head_export_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, head, out, n_rays, Z, P, P_live, nq,
+                       rows_per_ray, map);
 }
 
 // Camera -> rays (utils/ray_utils.py:98-135, datasets/base.py:485-518): pixel centres +0.5,

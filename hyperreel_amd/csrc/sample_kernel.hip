@@ -184,9 +184,10 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
     const int Z = cfg.z_channels;
     const int P = cfg.preds_per_z;
     const int CA = a.ca_total;                   // padded appearance slots (multiple of 4)
-    const int HS = a.nq * 4 + 4;                   // LDS row stride of a ray's head (+4: conflict-free float4 fills)
-    float* s_head = lds;                           // [RPB][HS]
-    float* s_M = lds + RPB * HS;                   // [RPB][3][CA]
+    const int HS = a.nq * 4 + 4;                   // LDS row stride of a head row (+4: conflict-free float4 fills)
+    const int RPR = a.rows_per_ray;                // head rows per ray (1 unless the head comes from a point MLP)
+    float* s_head = lds;                           // [RPB * RPR][HS]
+    float* s_M = lds + RPB * RPR * HS;             // [RPB][3][CA]
     float* s_x = s_M + RPB * 3 * CA;               // [256] cross-wave scratch, ZP > 64 only
     constexpr int ZW = (ZP < 64) ? ZP : 64;        // lanes of a ray inside one wavefront
     constexpr int WPR = (ZP + 63) / 64;            // wavefronts per ray
@@ -209,12 +210,21 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
 
     // ---- stage this block's head into LDS: per feature quad the block's RPB rays are RPB x 16
     //      contiguous bytes in the HQ layout (RPB divides 64, so a block never straddles a 64-ray group)
-    {
+    if (RPR == 1) {
         const float4* src4 = reinterpret_cast<const float4*>(a.head) + ((size_t)(ray_base >> 6) * a.nq << 6) + (ray_base & 63);
         const int total = a.nq * RPB;
         for (int i = tid; i < total; i += 256) {
             const int q = i / RPB, r = i - q * RPB;
             *reinterpret_cast<float4*>(s_head + r * HS + 4 * q) = src4[((size_t)q << 6) + r];
+        }
+    } else {                                       // cascade: RPB * RPR rows of the point MLP's head, any alignment
+        const float4* src4 = reinterpret_cast<const float4*>(a.head);
+        const int NR = RPB * RPR;
+        const int64_t row0 = ray_base * RPR, n_rows = a.n_rays * RPR;
+        for (int i = tid; i < a.nq * NR; i += 256) {
+            const int q = i / NR, r = i - q * NR;
+            const int64_t row = row0 + r;
+            if (row < n_rows) *reinterpret_cast<float4*>(s_head + r * HS + 4 * q) = src4[hr_head_index(row, 4 * q, a.nq) >> 2];
         }
     }
 
@@ -260,7 +270,10 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
     }
     __syncthreads();
 
-    const float* hk = s_head + rib * HS + (lane_ok ? k : 0) * P;
+    // sample k's P head values: row k / M of the ray, columns (k % M) * P ..  (M == Z when RPR == 1)
+    const int Mz = Z / RPR;
+    const int kk = lane_ok ? k : 0;
+    const float* hk = s_head + (rib * RPR + kk / Mz) * HS + (kk % Mz) * P;
 
     // ---- distances: intersect + mask, then sort along the ray (base.py:152-210)
     float dist = __builtin_inff();
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
     const float delta = (k == Z - 1) ? 1e10f : (dist_next - dist_c);
 
     // ---- feature gather
-    const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c) && (a.dbg_mode != 1);
+    const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c) && (a.dbg_mode != 1) && (a.rows_out == nullptr);
     float sig_feat = 0.0f;
     float pre0 = 0.0f, pre1 = 0.0f, pre2 = 0.0f;
     if (valid) {
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
             c0 += s_x[4 * (w0 + i) + 0]; c1 += s_x[4 * (w0 + i) + 1]; c2 += s_x[4 * (w0 + i) + 2]; acc_w += s_x[4 * (w0 + i) + 3];
         }
     }
-    if (ray_ok && k == 0) {
+    if (ray_ok && k == 0 && a.rows_out == nullptr) {
         if (cfg.white_bg) {                        // tensorf_no_sample.py:236-237
             const float bg = 1.0f - acc_w;
             c0 += bg; c1 += bg; c2 += bg;
@@ -396,6 +409,19 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
         a.rgb[ray * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
     }
 
+    // ---- coarse pass of a cascade: emit the point MLP's input row of this (sorted) sample (point.py:142-157)
+    if (a.rows_out && lane_ok) {
+        float* row = a.rows_out + (ray * Z + k) * a.row_dim;
+        const float* r = a.rays + ray * cfg.ray_dim;
+        int c = 0;
+        for (int i = 0; i < a.n_row_inputs; ++i) {
+            const int kind = a.row_kind[i];
+            for (int j = 0; j < a.row_len[i]; ++j)
+                row[c++] = (kind == HR_PIN_POINTS) ? (j == 0 ? p[0] : j == 1 ? p[1] : p[2])
+                           : (kind == HR_PIN_VIEWDIRS) ? r[3 + j] : (kind == HR_PIN_ORIGINS) ? r[j] : r[cfg.ray_dim - 1];
+        }
+    }
+
     // ---- optional diagnostics
     if (lane_ok) {
         const int64_t s = ray * Z + k;
@@ -410,10 +436,10 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
     }
 }
 
-static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP)
+static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)
 {
     const int RPB = 256 / ZP;
-    return ((size_t)RPB * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total + (ZP > 64 ? 256 : 0)) * sizeof(float);
+    return ((size_t)RPB * rows_per_ray * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total + (ZP > 64 ? 256 : 0)) * sizeof(float);
 }
 
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream)
@@ -424,7 +450,7 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     while (ZP < Z) ZP <<= 1;
     const int RPB = 256 / ZP;
     const unsigned blocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
-    const size_t lds = hr_sample_lds_bytes(args.nq, args.ca_total, ZP);
+    const size_t lds = hr_sample_lds_bytes(args.nq, args.ca_total, ZP, args.rows_per_ray);
     static const int dbg = [] { const char* e = getenv("HR_SAMPLE_DBG"); return e ? atoi(e) : 0; }();
     HrSampleArgs args2 = args;
     args2.dbg_mode = dbg;

@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -19,6 +19,7 @@ SYMBOLS = [
     ('hr_sizeof_config', C.c_int, []),
     ('hr_last_error', C.c_char_p, []),
     ('hr_model_create', C.c_int, [C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
+    ('hr_model_create_cascade', C.c_int, [C.POINTER(hr_config), C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
     ('hr_model_upload', C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     ('hr_model_finalize', C.c_int, [C.c_void_p]),
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),

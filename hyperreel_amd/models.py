@@ -15,7 +15,7 @@ from torch import nn
 
 from . import lib as _lib
 from .config import n_to_reso, to_plain
-from .plan import compile_config, hr_fields, upload_names
+from .plan import compile_model, hr_fields, upload_names
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -91,6 +91,9 @@ class HostEmbedding(nn.Module):
         for e in cfg['embedding']['embeddings'].values():
             if e['type'] == 'ray_prediction':
                 mods.append(HostRayPrediction(e, shapes))
+            elif e['type'] == 'point_prediction':         # cascades: a second MLP, same container shape
+                from .scenes import point_mlp_layer_shapes
+                mods.append(HostRayPrediction(e, point_mlp_layer_shapes(e)))
             elif e['type'] == 'color_transform':
                 mods.append(HostColorTransform((dataset or {}).get('total_images_per_frame', 1)))
             else:
@@ -182,7 +185,11 @@ class HipLightfieldModel(nn.Module):
         self._native = None
         self._native_key = None
         # fail on configurations outside the supported path now, not at the first render
-        compile_config(cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype)
+        self._compile(grid)
+
+    def _compile(self, grid):
+        """-> (coarse hr_config or None, hr_config of the level that renders)."""
+        return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype)
 
     # -- reference surface ---------------------------------------------------------
     def set_iter(self, i):
@@ -220,11 +227,12 @@ class HipLightfieldModel(nn.Module):
     # -- native side -------------------------------------------------------------------
     def _tensors(self):
         own = dict(self.named_parameters())
-        hc = compile_config(self.cfg, self.dataset, self.grid_size, self.mlp_precision, self.grid_dtype)
+        coarse, hc = self._compile(self.grid_size)
         types = [e['type'] for e in self.cfg['embedding']['embeddings'].values()]
-        pred_idx = types.index('ray_prediction')
-        ct_idx = types.index('color_transform') if 'color_transform' in types else -1
-        return hc, [(abi, own[key.format(idx=pred_idx, ct_idx=ct_idx)]) for abi, key in upload_names(hc)]
+        idx = {'idx': types.index('ray_prediction'),
+               'pp_idx': types.index('point_prediction') if 'point_prediction' in types else -1,
+               'ct_idx': types.index('color_transform') if 'color_transform' in types else -1}
+        return coarse, hc, [(abi, own[key.format(**idx)]) for abi, key in upload_names(hc, coarse)]
 
     def _param_key(self):
         # cheap fingerprint of everything the native model was built from: in-place
@@ -236,25 +244,28 @@ class HipLightfieldModel(nn.Module):
         key = self._param_key()
         if self._native is not None and key == self._native_key:
             return self._native
-        hc, tensors = self._tensors()
+        coarse, hc, tensors = self._tensors()
         L = _lib.load()
         dev = tensors[0][1].device
         if dev.type != 'cuda':
             raise RuntimeError('HipLightfieldModel must live on a HIP device (model.cuda()); there is no CPU path')
         import ctypes as C
+        def create():
+            h = C.c_void_p()
+            if coarse is None:
+                _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
+            else:
+                _lib.check(L.hr_model_create_cascade(C.byref(coarse), C.byref(hc), C.byref(h)), 'hr_model_create_cascade')
+            self._native = h
+            self._native_grid = self.grid_size
+
         with torch.cuda.device(dev):
             if self._native is None:
-                h = C.c_void_p()
-                _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
-                self._native = h
-                self._native_grid = self.grid_size
+                create()
             elif self._native_grid != self.grid_size or self._hc.mlp_precision != hc.mlp_precision \
                     or self._hc.grid_dtype != hc.grid_dtype:
                 L.hr_model_destroy(self._native)
-                h = C.c_void_p()
-                _lib.check(L.hr_model_create(C.byref(hc), C.byref(h)), 'hr_model_create')
-                self._native = h
-                self._native_grid = self.grid_size
+                create()
             torch.cuda.current_stream().synchronize()
             for abi, t in tensors:
                 t = t.detach().contiguous().float()

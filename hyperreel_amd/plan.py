@@ -82,6 +82,8 @@ class hr_config(C.Structure):
         ('density_act', C.c_int32), ('density_shift', C.c_float), ('time_scale', C.c_float), ('time_offset', C.c_float),
         ('white_bg', C.c_int32), ('mlp_precision', C.c_int32), ('grid_dtype', C.c_int32),
         ('color_table_views', C.c_int32), ('color_table_t_act', hr_act), ('color_table_s_act', hr_act),
+        ('casc_in_z', C.c_int32), ('casc_row_dim', C.c_int32), ('casc_n_inputs', C.c_int32),
+        ('casc_input_kind', C.c_int32 * 4), ('casc_input_dim', C.c_int32 * 4),
     ]
 
 
@@ -191,7 +193,7 @@ MLP_PRECISION = {'fp32': 0, 'bf16x3': 1}
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
 
 
-def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):
+def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', _coarse=False):
     """cfg: `experiment.model` group (dict/Cfg); dataset: {near, far, depth_range,
     num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes."""
     if cfg.get('param', {}).get('fn', 'identity') != 'identity':
@@ -590,7 +592,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         hc.num_keyframes = K
         hc.time_scale = float((Fr - 1) / Fr)  # tensorf_dynamic.py:58-59
         hc.time_offset = float(0.5 / K)
-        if not hc.advect:
+        if not hc.advect and not _coarse:
             raise NotImplementedError('video net without an advect_points stage (base_times)')
     # GEMM arithmetic of the MLP: 'bf16x3' (three bf16 MFMA products of hi/lo split operands,
     # fp32 accumulate; >= 10x inside the 1e-4 RGB bar) when the kernel supports the width,
@@ -604,6 +606,82 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         raise ValueError(f"grid_dtype must be one of {sorted(GRID_DTYPE)} (got {grid_dtype!r})")
     hc.grid_dtype = GRID_DTYPE[grid_dtype]
     return hc
+
+
+PIN = {'points': 0, 'viewdirs': 1, 'origins': 2, 'times': 3}
+
+
+def is_cascade(cfg):
+    return any(e['type'] == 'point_prediction' for e in cfg['embedding']['embeddings'].values())
+
+
+def compile_cascade(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):
+    """point_prediction cascades (embedding/point.py:39-218): ray_prediction -> ray_intersect -> point_prediction
+    -> ray_intersect -> ...  Returns (coarse, fine) hr_configs for hr_model_create_cascade.  The point MLP is
+    described to `compile_config` as a ray_prediction over the columns of its input row."""
+    import copy
+    items = list(cfg['embedding']['embeddings'].items())
+    types = [e['type'] for _, e in items]
+    ip = types.index('point_prediction')
+    if types[:ip] != ['ray_prediction', 'ray_intersect'] or types[ip + 1:ip + 2] != ['ray_intersect'] \
+            or 'point_prediction' in types[ip + 1:] or 'ray_prediction' in types[ip + 1:]:
+        raise NotImplementedError(f'cascade layout {types} (expected ray_prediction, ray_intersect, point_prediction, '
+                                  f'ray_intersect, ...)')
+    pp = items[ip][1]
+    for k in ('filter',):
+        if pp.get(k):
+            raise NotImplementedError(f'point_prediction.{k}')
+    if pp.get('rays_name', 'rays') != 'rays' or pp.get('points_name', 'points') != 'points':
+        raise NotImplementedError('point_prediction with renamed rays / points')
+    if any(o.get('residual', False) for o in pp['outputs'].values()):
+        raise NotImplementedError('residual point_prediction outputs')
+    in_z, out_z = int(pp.get('in_z_channels', 1)), int(pp.get('out_z_channels', 1))
+    Z0 = int(items[0][1]['z_channels'])
+    if in_z != Z0 or out_z % in_z:
+        raise ValueError(f'point_prediction in_z_channels {in_z} / out_z_channels {out_z} vs {Z0} coarse samples')
+    kinds, dims = [], []
+    for name, n in pp['inputs'].items():
+        if name not in PIN:
+            raise NotImplementedError(f"point_prediction input '{name}'")
+        full = 1 if name == 'times' else 3
+        n = int(n)
+        if not 1 <= n <= full:
+            raise ValueError(f"point_prediction input '{name}': {n} columns")
+        # viewdirs / origins / times are appended whole whatever the declared width (point.py:147-153)
+        kinds.append(PIN[name])
+        dims.append(n if name == 'points' else full)
+    if len(kinds) > 4:
+        raise NotImplementedError('more than 4 point_prediction inputs')
+    row_dim = sum(dims)
+    if row_dim > 8:
+        raise NotImplementedError('point_prediction rows wider than 8 columns')
+    # coarse level: the first two stages; the colour net rides along unused
+    c0 = copy.deepcopy(cfg)
+    c0['embedding']['embeddings'] = type(cfg['embedding']['embeddings'])(items[:2])
+    hc0 = compile_config(c0, dataset, grid_size, mlp_precision, grid_dtype, _coarse=True)
+    # fine level: the point MLP posed as a ray_prediction over the row's columns + everything after it
+    c1 = copy.deepcopy(cfg)
+    synth = type(pp)({'type': 'ray_prediction', 'params': copy.deepcopy(pp['params']), 'net': copy.deepcopy(pp['net']),
+                      'z_channels': out_z, 'outputs': copy.deepcopy(pp['outputs'])})
+    for g in synth['params'].values():
+        if g['param'].get('fn', 'identity') != 'identity':
+            raise NotImplementedError('point_prediction params other than identity')
+        if g['end'] > row_dim:
+            raise ValueError('point_prediction param reads beyond the input row')
+    c1['embedding']['embeddings'] = type(cfg['embedding']['embeddings'])([(items[ip][0], synth)] + items[ip + 1:])
+    hc1 = compile_config(c1, dataset, grid_size, mlp_precision, grid_dtype)
+    hc1.ray_dim = hc0.ray_dim = max(hc0.ray_dim, 8 if (hc1.video or hc1.advect or hc1.color_table_views > 0) else 6)
+    hc1.casc_in_z, hc1.casc_row_dim, hc1.casc_n_inputs = in_z, row_dim, len(kinds)
+    for i, (k, d) in enumerate(zip(kinds, dims)):
+        hc1.casc_input_kind[i], hc1.casc_input_dim[i] = k, d
+    return hc0, hc1
+
+
+def compile_model(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):
+    """-> (coarse hr_config or None, hr_config of the rendering level): cascade-aware front door."""
+    if is_cascade(cfg):
+        return compile_cascade(cfg, dataset, grid_size, mlp_precision, grid_dtype)
+    return None, compile_config(cfg, dataset, grid_size, mlp_precision, grid_dtype)
 
 
 def live_head_columns(hc):
@@ -646,15 +724,23 @@ def live_head_columns(hc):
     return live
 
 
-def upload_names(hc):
-    """[(ABI tensor name, reference state_dict key suffix)] for hr_model_upload."""
+def upload_names(hc, coarse=None):
+    """[(ABI tensor name, reference state_dict key suffix)] for hr_model_upload.  Keys carry {idx} (the
+    ray_prediction stage), {pp_idx} (the point_prediction stage of a cascade) and {ct_idx} (color_transform)."""
     names = []
-    emb = 'embedding_model.embeddings.{idx}.net.layers.'
-    L = hc.mlp_layers
-    for i in range(L):
-        mid = '.0' if i < L - 1 else ''        # Sequential(Linear, act) vs bare Linear (mlp.py:149-154)
-        names.append((f'mlp.{i}.weight', f'{emb}{i}{mid}.weight'))
-        names.append((f'mlp.{i}.bias', f'{emb}{i}{mid}.bias'))
+
+    def mlp(prefix, L, where):
+        emb = 'embedding_model.embeddings.{' + where + '}.net.layers.'
+        for i in range(L):
+            mid = '.0' if i < L - 1 else ''    # Sequential(Linear, act) vs bare Linear (mlp.py:149-154)
+            names.append((f'{prefix}.{i}.weight', f'{emb}{i}{mid}.weight'))
+            names.append((f'{prefix}.{i}.bias', f'{emb}{i}{mid}.bias'))
+
+    if coarse is None:
+        mlp('mlp', hc.mlp_layers, 'idx')
+    else:                                      # hr_model_create_cascade: coarse ray MLP, then the point MLP
+        mlp('mlp', coarse.mlp_layers, 'idx')
+        mlp('mlp1', hc.mlp_layers, 'pp_idx')
     kinds = ('plane_space', 'plane_time') if hc.video else ('plane', 'line')
     for what in ('density', 'app'):
         for kind in kinds:

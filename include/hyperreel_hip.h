@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 6
+#define HR_ABI_VERSION 7
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -97,6 +97,8 @@ enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1 };
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
 enum { HR_GRID_FP32 = 0, HR_GRID_FP16 = 1 };
+/* inputs of a point_prediction row: x['points'] of the coarse intersect, rays[..., 3:6], rays[..., 0:3], rays[..., -1:] */
+enum { HR_PIN_POINTS = 0, HR_PIN_VIEWDIRS = 1, HR_PIN_ORIGINS = 2, HR_PIN_TIMES = 3 };
 
 /* Everything the kernels need that the reference derives from the model YAML and the
  * five dataset scalars (near, far, depth_range, num_keyframes, num_frames).  Derived
@@ -180,6 +182,14 @@ typedef struct hr_config {
      *      dataset.val_all false, in which case the reference's stage returns x unchanged. */
     int32_t color_table_views;
     hr_act color_table_t_act, color_table_s_act;
+    /* ---- point_prediction cascade (PointPredictionEmbedding, nlf/embedding/point.py:39-218), set only in the
+     *      FINE config of hr_model_create_cascade: the MLP of this config runs once per COARSE sample on the row
+     *      [inputs...] (groups[] index the row's columns) and emits z_channels / casc_in_z samples per row. */
+    int32_t casc_in_z;                   /* coarse samples per ray (in_z_channels); 0: not a cascade */
+    int32_t casc_row_dim;                /* columns of an input row = sum of casc_input_dim */
+    int32_t casc_n_inputs;
+    int32_t casc_input_kind[4];          /* HR_PIN_* in `inputs` order (point.py:142-156) */
+    int32_t casc_input_dim[4];           /* columns taken from each */
 } hr_config;
 
 /* Optional per-sample diagnostics of hr_render_fields (all device pointers, any may be
@@ -212,6 +222,12 @@ const char* hr_last_error(void);
  * LightfieldModel.__init__ (nlf/models/models.py:104-129) + RenderLightfield.__init__
  * (nlf/rendering.py:59-70). */
 int hr_model_create(const hr_config* cfg, hr_model** out);
+
+/* Two-level model for the reference's point_prediction cascades (the shipped ..._cascaded.yaml and
+ * ..._feedback.yaml model groups): `coarse` describes ray_prediction + the first ray_intersect (its colour-net fields are
+ * ignored), `fine` the point_prediction MLP (casc_* set), the second ray_intersect and everything after it.
+ * Tensors of the coarse MLP are uploaded as mlp.<i>.*, those of the point MLP as mlp1.<i>.*. */
+int hr_model_create_cascade(const hr_config* coarse, const hr_config* fine, hr_model** out);
 
 /* Hands over one tensor of the reference state_dict, float32, in the reference's own
  * layout (nlf/__init__.py:433-479 are the reference's loader).  `name` is the key with

@@ -160,7 +160,7 @@ def main(only=None, force=False):
         model_cfg = C.epoch_to_iter(C.to_cfg(C.to_plain(raw)), 4000)
         rejected = None
         try:
-            plan.compile_config(model_cfg, ds, GRID)
+            plan.compile_model(model_cfg, ds, GRID)
         except (NotImplementedError, ValueError) as e:
             coverage[name] = {'status': 'rejected', 'reason': str(e)}
             print(f'{name:36s} rejected: {e}')

@@ -424,3 +424,27 @@ def test_fp16_grids_full_frame_psnr():
     psnr = 10.0 * np.log10(1.0 / max(mse, 1e-20))
     assert psnr > 60.0, psnr
     assert (a - b).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('case', ['sweep/technicolor_cascaded', 'sweep/shiny_z_plane_feedback'])
+def test_cascade_intermediates_and_ragged_counts(case, precision):
+    """point_prediction cascades (coarse MLP -> coarse intersect -> per-point MLP -> fine intersect): a ray count
+    that is not a multiple of anything, both MLP precisions, intermediates of the FINE level against the oracle."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    g = Golden(case)
+    video = g.rays.shape[1] == 8
+    rays = scenes.random_rays(515, 9, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision)
+    out = render_np(fn, rays, want=('distances', 'render_weights'))
+    ref = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(rays, keep='all')
+    Z = ref['distances'].shape[1]
+    assert Z == 32
+    d_ref = ref['distances'].reshape(-1, Z)
+    assert float(np.max(np.abs(out['distances'] - d_ref) / (1 + np.abs(d_ref)))) <= 2e-5
+    assert linf(out['render_weights'], ref['render_weights']) <= 5e-5
+    assert linf(out['rgb'], ref['rgb']) <= RGB_TOL
+    # chunked internally == one shot (the chunk boundary falls inside the row buffer of the point MLP)
+    fn.model.reserve(128)
+    assert np.array_equal(render_np(fn, rays)['rgb'], out['rgb'])
