@@ -612,7 +612,7 @@ PIN = {'points': 0, 'viewdirs': 1, 'origins': 2, 'times': 3}
 
 
 def is_cascade(cfg):
-    return any(e['type'] == 'point_prediction' for e in cfg['embedding']['embeddings'].values())
+    return any(e.get('type') == 'point_prediction' for e in cfg.get('embedding', {}).get('embeddings', {}).values())
 
 
 def compile_cascade(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):

@@ -131,8 +131,10 @@ def cpu_mode():
 
 
 def load_model_cfg(name, overrides=None, iters_per_epoch=4000):
+    # OmegaConf (the reference's loader) reads `1e-4` as a float; PyYAML's default resolver does not
+    from hyperreel_amd.config import _Loader
     with open(f'{REF}/conf/experiment/model/{name}.yaml') as f:
-        cfg = to_attr(yaml.safe_load(f))
+        cfg = to_attr(yaml.load(f, Loader=_Loader))
     if overrides:
         overrides(cfg)
     epoch_to_iter(cfg, iters_per_epoch)

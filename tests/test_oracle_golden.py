@@ -59,7 +59,7 @@ def test_sweep_coverage_matches_the_plan_compiler():
     have = {c.split('/', 1)[1] for c in sweep_cases()}
     assert have == {k for k, v in cov.items() if v['status'] == 'golden'}
     assert all(v.get('reason') for v in cov.values() if v['status'] != 'golden')
-    assert len([k for k in have if not k.startswith('variant_')]) >= 44
+    assert len([k for k in have if not k.startswith('variant_')]) >= 45
     # nothing the reference can run is left out
     left = {k: v for k, v in cov.items() if v['status'] != 'golden' and v.get('reference_runs')}
     assert not left, left
