@@ -274,6 +274,19 @@ static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
     m->is_coarse = coarse;
     analyse_live_columns(m);
     const hr_config& c = m->cfg;
+    {   // LDS of the sample kernel: 256/ZP rays x head rows x (live head columns + 4) + the decode matrices
+        int ZP = 8;
+        while (ZP < c.z_channels) ZP <<= 1;
+        const size_t rpb = 256 / ZP, nq = ((size_t)samples_per_row(c) * m->p_live + 3) / 4;
+        size_t ca = 0;
+        for (int j = 0; j < 3; ++j) ca += 4 * (size_t)((c.n_app[j] + 3) / 4);
+        const size_t lds = 4 * (rpb * rows_per_ray(c) * (nq * 4 + 4) + rpb * 3 * ca + 256);
+        if (lds > 160 * 1024) {
+            delete m;
+            return fail(HR_E_INVALID, "z_channels %d x %d head columns need %zu bytes of LDS per workgroup (160 KiB available)",
+                        c.z_channels, m->p_live, lds);
+        }
+    }
     char name[64];
     for (int l = 0; l < c.mlp_layers; ++l) {
         snprintf(name, sizeof(name), "mlp.%d.weight", l);

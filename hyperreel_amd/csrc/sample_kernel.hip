@@ -454,10 +454,17 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     static const int dbg = [] { const char* e = getenv("HR_SAMPLE_DBG"); return e ? atoi(e) : 0; }();
     HrSampleArgs args2 = args;
     args2.dbg_mode = dbg;
+    // few samples x many head columns can exceed the 64 KiB a kernel gets by default (e.g. 32 rays x 8 x 64 floats)
+    const bool big_lds = lds > 64 * 1024;
 #define HR_LAUNCH_SAMPLES(Z_) \
     do { \
-        if (cfg.grid_dtype == HR_GRID_FP16) hipLaunchKernelGGL((hr_sample_kernel<Z_, true>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
-        else hipLaunchKernelGGL((hr_sample_kernel<Z_, false>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
+        if (cfg.grid_dtype == HR_GRID_FP16) { \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, true>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
+        } else { \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, false>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
+        } \
     } while (0)
     switch (ZP) {
         case 8: HR_LAUNCH_SAMPLES(8); break;
