@@ -448,3 +448,9 @@ def test_cascade_intermediates_and_ragged_counts(case, precision):
     # chunked internally == one shot (the chunk boundary falls inside the row buffer of the point MLP)
     fn.model.reserve(128)
     assert np.array_equal(render_np(fn, rays)['rgb'], out['rgb'])
+    # embed(): the fine level's head fields come back in (ray, sample, channel) order
+    emb = fn.embed(torch.from_numpy(rays).cuda())
+    assert emb['points'].shape == (rays.shape[0], 3 * Z)
+    for key in ('color_scale', 'color_shift', 'point_offset'):
+        if key in emb and key in ref:
+            assert linf(emb[key].cpu().numpy(), ref[key].reshape(rays.shape[0], -1)) <= 2e-5, key
