@@ -103,6 +103,55 @@ __device__ __forceinline__ void hr_consume_group(const HrGridPlane& g, int q, in
 
 typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 
+// Channel groups (float4) a gather pass reads from each tap before moving to the next tap, and the occupancy the
+// kernel is compiled for.  Measured (sample stage, ms per 800x800 frame; G, workgroups/CU):
+//   DoNeRF Z=32 static      (1,5) 1.18   (2,4) 1.39   (2,5: spills) 2.1   (4,4: spills) 3.2
+//   immersive Z=32 keyframe (1,5) 1.58   (2,4) 1.75
+//   neural_3d Z=64 keyframe (1,5) 4.55   (2,4) 3.95   <- 8 taps x 64 distinct lines per group overflow the L1 (hit rate 61 %)
+// so one group per pass everywhere except the 64+-sample kernels; float16 texels keep their own octet-major loop.
+template <int ZP, bool HALF>
+struct HrGatherTune {
+    static constexpr int G = (!HALF && ZP >= 64) ? 2 : 1;          // (unused by the float16 path)
+    static constexpr int MIN_BLOCKS = (!HALF && ZP >= 64) ? 4 : 5;
+};
+
+// acc[j] (+)= w * texel[q0 + j] for the first min(nb, G) channel groups of one tap; `off` is the
+// element offset of the tap's texel.  FIRST: acc = v * w, else acc = fma(v, w, acc) (ATen's bilinear order).
+template <bool HALF, int G, bool FIRST>
+__device__ __forceinline__ void hr_tap(const void* base, int off, int q0, int nb, float w, float4 (&acc)[G])
+{
+    auto put = [&](int j, const float4 v) {
+        if (FIRST) {
+            acc[j].x = v.x * w; acc[j].y = v.y * w; acc[j].z = v.z * w; acc[j].w = v.w * w;
+        } else {
+            acc[j].x = HR_FMA(v.x, w, acc[j].x); acc[j].y = HR_FMA(v.y, w, acc[j].y);
+            acc[j].z = HR_FMA(v.z, w, acc[j].z); acc[j].w = HR_FMA(v.w, w, acc[j].w);
+        }
+    };
+    if constexpr (!HALF) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off) + q0;
+        float4 v[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (j < nb) v[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (j < nb) put(j, v[j]);
+    } else {
+        const hr_half8* p = reinterpret_cast<const hr_half8*>(reinterpret_cast<const _Float16*>(base) + off) + (q0 >> 1);
+        constexpr int NO = (G + 1) / 2;
+        hr_half8 h[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+            if (2 * o < nb) h[o] = p[o];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (2 * o < nb) put(2 * o, make_float4((float)h[o][0], (float)h[o][1], (float)h[o][2], (float)h[o][3]));
+            if (2 * o + 1 < nb && 2 * o + 1 < G) put(2 * o + 1, make_float4((float)h[o][4], (float)h[o][5], (float)h[o][6], (float)h[o][7]));
+        }
+    }
+}
+
 // All channel groups of one plane pair for a sample at normalised coordinates pn: bilinear
 // plane tap x (line | time-plane) tap, density partial sum and appearance decode.
 // HALF: float16 texels, one 16-byte load brings two channel groups (half the load instructions and
@@ -111,7 +160,7 @@ typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 //  gather with LDS hand-over, 1.66 vs 1.27 ms per frame; compile-time unrolled batches of 12-16
 //  loads in flight at 4 waves/SIMD, 1.37 ms.  The gather sits at ~1.1 vector-L1 accesses per
 //  clock per CU, i.e. it is bound by the tag-lookup rate for scattered 16-byte reads.)
-template <bool HALF>
+template <bool HALF, int G>
 __device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const float (&pn)[4], const float* M, int CA,
                                                 float& sig_feat, float& pre0, float& pre1, float& pre2)
 {
@@ -138,17 +187,9 @@ __device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const floa
     const int ib00 = line ? bxp.i0 * tex : (byp.i0 * g.bw + bxp.i0) * tex;
     const int ib01 = line ? bxp.i1 * tex : (byp.i0 * g.bw + bxp.i1) * tex;
     const int ib10 = (byp.i1 * g.bw + bxp.i0) * tex, ib11 = (byp.i1 * g.bw + bxp.i1) * tex;
-    if constexpr (!HALF) {
-        const float* A = reinterpret_cast<const float*>(g.a);
-        const float* B = reinterpret_cast<const float*>(g.b);
-        auto ld = [](const float* p, int q) { return *reinterpret_cast<const float4*>(p + 4 * q); };
-        for (int q = 0; q < ng; ++q) {
-            const float4 pa = hr_bilerp4(ld(A + ia00, q), ld(A + ia01, q), ld(A + ia10, q), ld(A + ia11, q), w00, w01, w10, w11);
-            const float4 pb = line ? hr_lerp4(ld(B + ib00, q), ld(B + ib01, q), bxp.w0, bxp.w1)
-                                   : hr_bilerp4(ld(B + ib00, q), ld(B + ib01, q), ld(B + ib10, q), ld(B + ib11, q), v00, v01, v10, v11);
-            hr_consume_group(g, q, cd, pa, pb, M, CA, sig_feat, pre0, pre1, pre2);
-        }
-    } else {
+    if constexpr (HALF) {
+        // float16 texels: one 16-byte load brings two channel groups; octet-major order (all taps of an octet, then the
+        // next octet) keeps 96 VGPRs without spills and measured 0.86 vs 1.08 ms against the tap-major form below
         const _Float16* A = reinterpret_cast<const _Float16*>(g.a);
         const _Float16* B = reinterpret_cast<const _Float16*>(g.b);
         auto ld = [](const _Float16* p, int o) { return *reinterpret_cast<const hr_half8*>(p + 8 * o); };
@@ -173,11 +214,37 @@ __device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const floa
                 hr_consume_group(g, 2 * o + 1, cd, pa, pb, M, CA, sig_feat, pre0, pre1, pre2);
             }
         }
+        return;
+    }
+    // Tap-major order: per pass, up to G channel groups of ONE tap's texel are read back to back (a
+    // contiguous 64-byte run for fp32 texels, 32 bytes for fp16), then the next tap.  The accumulators carry
+    // ATen's summation order (nw, ne, sw, se).  Group-major order (all taps of one group, then the next group)
+    // touches 6-8 different cache lines per lane between two reads of the same texel and measured an L1 hit
+    // rate of only 61 % on the keyframe model with 64 samples per ray (12x the L2 requests of DoNeRF).
+    for (int q0 = 0; q0 < ng; q0 += G) {
+        const int nb = ng - q0;
+        float4 pa[G], pb[G];
+        hr_tap<HALF, G, true>(g.a, ia00, q0, nb, w00, pa);
+        hr_tap<HALF, G, false>(g.a, ia01, q0, nb, w01, pa);
+        hr_tap<HALF, G, false>(g.a, ia10, q0, nb, w10, pa);
+        hr_tap<HALF, G, false>(g.a, ia11, q0, nb, w11, pa);
+        if (line) {
+            hr_tap<HALF, G, true>(g.b, ib00, q0, nb, bxp.w0, pb);
+            hr_tap<HALF, G, false>(g.b, ib01, q0, nb, bxp.w1, pb);
+        } else {
+            hr_tap<HALF, G, true>(g.b, ib00, q0, nb, v00, pb);
+            hr_tap<HALF, G, false>(g.b, ib01, q0, nb, v01, pb);
+            hr_tap<HALF, G, false>(g.b, ib10, q0, nb, v10, pb);
+            hr_tap<HALF, G, false>(g.b, ib11, q0, nb, v11, pb);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (j < nb) hr_consume_group(g, q0 + j, cd, pa[j], pb[j], M, CA, sig_feat, pre0, pre1, pre2);
     }
 }
 
 template <int ZP, bool HALF>
-__global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
+__global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
 {
     constexpr int RPB = 256 / ZP;   // rays per block
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -310,7 +377,7 @@ __global__ __launch_bounds__(256, 5) void hr_sample_kernel(const hr_config cfg, 
         pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
         const float* M = s_M + rib * 3 * CA;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) hr_gather_plane<HALF>(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
+        for (int j = 0; j < 3; ++j) hr_gather_plane<HALF, HrGatherTune<ZP, HALF>::G>(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
     }
 
     // ---- density -> alpha -> transmittance -> weight (raw2alpha, tensorf_utils.py:242-253)
