@@ -282,6 +282,9 @@ def main():
                 r_mlp['traffic'] = tr[r_mlp['kernel']]['traffic_bytes'] if r_mlp['kernel'] in tr else None
                 r_smp['traffic'] = tr['hr_sample_kernel']['traffic_bytes']
                 r_mlp['traffic_unit'] = r_smp['traffic_unit'] = 'bytes per launch (profiles/r01_traffic.json)'
+                for r in (r_mlp, r_smp):          # what the PMC passes say actually limits the kernel
+                    if r['kernel'] in tr and 'limiter' in tr[r['kernel']]:
+                        r['limiter'] = tr[r['kernel']]['limiter']
         except (OSError, KeyError, ValueError):
             pass
         dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
