@@ -103,16 +103,17 @@ __device__ __forceinline__ void hr_consume_group(const HrGridPlane& g, int q, in
 
 typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 
-// Channel groups (float4) a gather pass reads from each tap before moving to the next tap, and the occupancy the
-// kernel is compiled for.  Measured (sample stage, ms per 800x800 frame; G, workgroups/CU):
-//   DoNeRF Z=32 static      (1,5) 1.18   (2,4) 1.39   (2,5: spills) 2.1   (4,4: spills) 3.2
-//   immersive Z=32 keyframe (1,5) 1.58   (2,4) 1.75
-//   neural_3d Z=64 keyframe (1,5) 4.55   (2,4) 3.95   <- 8 taps x 64 distinct lines per group overflow the L1 (hit rate 61 %)
-// so one group per pass everywhere except the 64+-sample kernels; float16 texels keep their own octet-major loop.
+// How the gather is compiled per kernel variant.  fp32 texels: the lanes of a quad (or pair) cooperate on one sample
+// at a time (hr_gather_plane_coop below) at 4 workgroups/CU; float16 texels: every lane gathers its own sample, one
+// 16-byte load per two channel groups, at 5 workgroups/CU.  Measured sample stage, ms per 800x800 frame:
+//                            own-sample, group-major   own-sample, 2 groups/tap   cooperative
+//   DoNeRF Z=32 static              1.18                      1.39                   1.12
+//   technicolor Z=32 keyframe       1.13                       -                     0.94
+//   immersive Z=32 keyframe         1.58                      1.75                   1.34
+//   neural_3d Z=64 keyframe         4.55 (L1 hit rate 61 %)   3.95                   2.93
 template <int ZP, bool HALF>
 struct HrGatherTune {
-    static constexpr int G = (!HALF && ZP >= 64) ? 2 : 1;          // (unused by the float16 path)
-    static constexpr int MIN_BLOCKS = (!HALF && ZP >= 64) ? 4 : 5;
+    static constexpr int MIN_BLOCKS = HALF ? 5 : 4;
 };
 
 // acc[j] (+)= w * texel[q0 + j] for the first min(nb, G) channel groups of one tap; `off` is the
@@ -243,6 +244,124 @@ __device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Quad-cooperative gather (fp32 texels).  The vector-memory address unit charges a scattered 16-byte lane access
+// about a cycle, but serves the 4 lanes of a quad reading 64 CONTIGUOUS bytes at more than twice that rate
+// (tools/gather_ubench.hip, L1-resident: 1.4 vs 3.0 lane-loads per clock per CU; L2-resident 1.0 vs 1.7).
+// So for the gather the four lanes of a quad stop working on their own samples and take one channel group each
+// of ONE sample at a time: the owner's taps are broadcast inside the quad with DPP moves, each lane loads its
+// float4 of every tap (one 64-byte run per tap and quad), forms plane x line for its group, and the four partial
+// results (density sum, three decode dot products) are summed with two DPP steps and kept by the owner.
+// The quad's lanes are consecutive samples of one ray (ZP >= 8), so they share the ray's decode matrix M.
+template <int CTRL>
+__device__ __forceinline__ float hr_dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int hr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+struct HrTaps {                 // one plane pair's taps of one sample: element offsets and weights
+    int ia[4];                  // plane: nw, ne, sw, se
+    float wa[4];
+    int ib[4];                  // line: low, high (2 used) / time plane: 4
+    float wb[4];
+};
+
+__device__ __forceinline__ HrTaps hr_make_taps(const HrGridPlane& g, const float (&pn)[4])
+{
+    HrTaps t;
+    const int tex = g.tex;
+    const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
+    const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
+    const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
+    const hr_axis_tap tx = hr_make_tap(gx, g.aw);
+    const hr_axis_tap ty = hr_make_tap(gy, g.ah);
+    t.wa[0] = tx.w0 * ty.w0; t.wa[1] = tx.w1 * ty.w0; t.wa[2] = tx.w0 * ty.w1; t.wa[3] = tx.w1 * ty.w1;
+    t.ia[0] = (ty.i0 * g.aw + tx.i0) * tex; t.ia[1] = (ty.i0 * g.aw + tx.i1) * tex;
+    t.ia[2] = (ty.i1 * g.aw + tx.i0) * tex; t.ia[3] = (ty.i1 * g.aw + tx.i1) * tex;
+    const bool line = (g.bw == 1);
+    const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
+    const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
+    if (line) {
+        t.ib[0] = bxp.i0 * tex; t.ib[1] = bxp.i1 * tex; t.ib[2] = 0; t.ib[3] = 0;
+        t.wb[0] = bxp.w0; t.wb[1] = bxp.w1; t.wb[2] = 0.0f; t.wb[3] = 0.0f;
+    } else {
+        t.ib[0] = (byp.i0 * g.bw + bxp.i0) * tex; t.ib[1] = (byp.i0 * g.bw + bxp.i1) * tex;
+        t.ib[2] = (byp.i1 * g.bw + bxp.i0) * tex; t.ib[3] = (byp.i1 * g.bw + bxp.i1) * tex;
+        t.wb[0] = bxp.w0 * byp.w0; t.wb[1] = bxp.w1 * byp.w0; t.wb[2] = bxp.w0 * byp.w1; t.wb[3] = bxp.w1 * byp.w1;
+    }
+    return t;
+}
+
+// One owner at a time.  LPS = lanes per sample: 4 (the quad serves owner lane T of the quad) or 2 (each pair serves
+// its own lane T; used for plane pairs with exactly two channel groups so that no lane idles).
+template <int LPS, int T>
+__device__ __forceinline__ void hr_gather_coop_step(const HrGridPlane& g, const HrTaps& mine, bool my_valid, const float* M, int CA,
+                                                    float& sig_feat, float& pre0, float& pre1, float& pre2)
+{
+    // quad_perm selecting the owner: [T,T,T,T] for quads, [T,T,2+T,2+T] for pairs
+    constexpr int B = (LPS == 4) ? T * 0x55 : (T | (T << 2) | ((2 + T) << 4) | ((2 + T) << 6));
+    const int j = threadIdx.x & (LPS - 1);                // this lane's channel group within a pass
+    const bool v = hr_dpp_i<B>(my_valid ? 1 : 0) != 0;
+    if (!v) return;                                       // uniform inside the quad / pair
+    const bool line = (g.bw == 1);
+    HrTaps t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t.ia[i] = hr_dpp_i<B>(mine.ia[i]);
+        t.wa[i] = hr_dpp_f<B>(mine.wa[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        t.ib[i] = hr_dpp_i<B>(mine.ib[i]);
+        t.wb[i] = hr_dpp_f<B>(mine.wb[i]);
+    }
+    if (!line) {
+#pragma unroll
+        for (int i = 2; i < 4; ++i) {
+            t.ib[i] = hr_dpp_i<B>(mine.ib[i]);
+            t.wb[i] = hr_dpp_f<B>(mine.wb[i]);
+        }
+    }
+    const int ng = g.cd4 + g.ca4, cd = g.cd4;
+    const float* A = reinterpret_cast<const float*>(g.a);
+    const float* Bp = reinterpret_cast<const float*>(g.b);
+    float s = 0.0f, p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+    for (int q = j; q < ng; q += LPS) {                   // this lane's channel group(s)
+        auto ld = [q](const float* p, int off) { return *reinterpret_cast<const float4*>(p + off + 4 * q); };
+        const float4 pa = hr_bilerp4(ld(A, t.ia[0]), ld(A, t.ia[1]), ld(A, t.ia[2]), ld(A, t.ia[3]), t.wa[0], t.wa[1], t.wa[2], t.wa[3]);
+        const float4 pb = line ? hr_lerp4(ld(Bp, t.ib[0]), ld(Bp, t.ib[1]), t.wb[0], t.wb[1])
+                               : hr_bilerp4(ld(Bp, t.ib[0]), ld(Bp, t.ib[1]), ld(Bp, t.ib[2]), ld(Bp, t.ib[3]), t.wb[0], t.wb[1], t.wb[2], t.wb[3]);
+        hr_consume_group(g, q, cd, pa, pb, M, CA, s, p0, p1, p2);
+    }
+    // sum over the cooperating lanes: neighbour, then (quads) the other pair
+    s += hr_dpp_f<0xB1>(s); p0 += hr_dpp_f<0xB1>(p0); p1 += hr_dpp_f<0xB1>(p1); p2 += hr_dpp_f<0xB1>(p2);
+    if (LPS == 4) { s += hr_dpp_f<0x4E>(s); p0 += hr_dpp_f<0x4E>(p0); p1 += hr_dpp_f<0x4E>(p1); p2 += hr_dpp_f<0x4E>(p2); }
+    if (j == T) { sig_feat += s; pre0 += p0; pre1 += p1; pre2 += p2; }
+}
+
+__device__ __forceinline__ void hr_gather_plane_coop(const HrGridPlane& g, const float (&pn)[4], bool valid, const float* M, int CA,
+                                                     float& sig_feat, float& pre0, float& pre1, float& pre2)
+{
+    const int ng = g.cd4 + g.ca4;
+    if (ng == 0) return;
+    if (ng == 1) {               // a single 16-byte group per texel: nothing to share
+        if (valid) hr_gather_plane<false, 1>(g, pn, M, CA, sig_feat, pre0, pre1, pre2);
+        return;
+    }
+    const HrTaps mine = hr_make_taps(g, pn);
+    if (ng == 2) {
+        hr_gather_coop_step<2, 0>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_coop_step<2, 1>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+    } else {
+        hr_gather_coop_step<4, 0>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_coop_step<4, 1>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_coop_step<4, 2>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_coop_step<4, 3>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
+    }
+}
+
 template <int ZP, bool HALF>
 __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
 {
@@ -369,7 +488,18 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     const bool valid = lane_ok && hr_sample_valid(cfg, p, dist_c) && (a.dbg_mode != 1) && (a.rows_out == nullptr);
     float sig_feat = 0.0f;
     float pre0 = 0.0f, pre1 = 0.0f, pre2 = 0.0f;
-    if (valid) {
+    if constexpr (!HALF) {      // all lanes take part: the quad's lanes serve each other's samples
+        float pn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) {
+            pn[0] = hr_normalize_coord(cfg, p[0], 0);
+            pn[1] = hr_normalize_coord(cfg, p[1], 1);
+            pn[2] = hr_normalize_coord(cfg, p[2], 2);
+            pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
+        }
+        const float* M = s_M + rib * 3 * CA;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hr_gather_plane_coop(a.planes[j], pn, valid, M, CA, sig_feat, pre0, pre1, pre2);
+    } else if (valid) {
         float pn[4];
         pn[0] = hr_normalize_coord(cfg, p[0], 0);
         pn[1] = hr_normalize_coord(cfg, p[1], 1);
@@ -377,7 +507,7 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
         pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
         const float* M = s_M + rib * 3 * CA;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) hr_gather_plane<HALF, HrGatherTune<ZP, HALF>::G>(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
+        for (int j = 0; j < 3; ++j) hr_gather_plane<HALF, 1>(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
     }
 
     // ---- density -> alpha -> transmittance -> weight (raw2alpha, tensorf_utils.py:242-253)
