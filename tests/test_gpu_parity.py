@@ -287,6 +287,8 @@ VARIANTS = {
         _emb(c).ray_intersect_0.intersect.update(sort=False))),
     # channel counts that are not multiples of four and differ between density and appearance
     'odd_channels': lambda: _variant('donerf_sphere', lambda c: c.color.net.update(n_lamb_sigma=[6, 3, 5], n_lamb_sh=[10, 2, 7])),
+    # plane pairs with a single 16-byte channel group (own-sample gather) next to an 8-group pair (quads, two passes)
+    'single_group_planes': lambda: _variant('donerf_sphere', lambda c: c.color.net.update(n_lamb_sigma=[3, 12, 2], n_lamb_sh=[0, 20, 0])),
     'video_odd_channels': lambda: _variant('neural_3d_z_plane', lambda c: c.color.net.update(n_lamb_sigma=[5, 0, 3], n_lamb_sh=[9, 0, 2]), Z=16),
 }
 
