@@ -130,7 +130,10 @@ def main():
             raise SystemExit('launch N>1 with torch.distributed.run (one process per GPU)')
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # HR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-gather, barrier, max-reduce) with a single
+    # rank -- the only way to exercise it on a one-GPU box
+    multi = world > 1 or os.environ.get('HR_BENCH_FORCE_DIST') == '1'
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -159,7 +162,7 @@ def main():
     if args.chunk:
         model.reserve(args.chunk)
     model.native()
-    gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if world > 1 else None
+    gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if multi else None
 
     # One frame = hr_render's kernel launches.  They are captured once into a hipGraph and replayed per
     # step (the library neither allocates nor synchronises inside hr_render), so a slow host thread
@@ -184,25 +187,25 @@ def main():
             rgb = rgb_static
         else:
             rgb = model.render(rays)['rgb']
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered.view(-1), rgb.view(-1))
         return rgb
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rgb = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -331,7 +334,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
