@@ -214,6 +214,12 @@ __global__ __launch_bounds__(64 * NW, (MT == 2) ? (NW / 2) : (NW / 4)) void hr_m
     int tri = 0;
 #define HR_STAMP() do { if (tr && lane == 0 && tri < 64) tr[tri] = __builtin_readcyclecounter(); ++tri; } while (0)
     HR_STAMP();                                              // 0: start
+#ifdef HR_MLP_DESYNC
+    // experiment: the two workgroups that share a CU in the first dispatch round are blocks b and b + 256 (XCD = b % 8,
+    // CU = (b / 8) % 32); delay the second one by HR_MLP_DESYNC x 3.4 us so that its GEMM phases meet the other's epilogues
+    if ((blockIdx.x >> 8) & 1)
+        for (int i = 0; i < HR_MLP_DESYNC; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     // ---- prologue: ray parameterisation + positional encoding (fp32), then split
     if (tid < TM) {
         const int64_t r = ray0 + tid;
@@ -378,7 +384,10 @@ template <int W, int MT, int NW>
 static void hr_launch_mlp_bf16x3_t(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream)
 {
     constexpr int TM = 32 * MT;
-    const size_t lds = (size_t)TM * 2 * ((args.k0p + 8) + (W + 8)) * sizeof(__bf16);
+    size_t lds = (size_t)TM * 2 * ((args.k0p + 8) + (W + 8)) * sizeof(__bf16);
+    // experiment knob: HR_MLP_LDS_PAD=<KB> pads the allocation (e.g. 20 forces one workgroup per CU at 64 rays)
+    static const size_t pad = [] { const char* e = getenv("HR_MLP_LDS_PAD"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+    lds += pad;
     const unsigned blocks = (unsigned)((args.n_rays + TM - 1) / TM);
     static size_t allowed = 0;
     if (lds > allowed) {
