@@ -1,6 +1,7 @@
 // Does the vector-memory address unit (TA) reward quad-coalesced 16-byte gathers?  Same instruction count and bytes:
 //   mode 0: every lane reads 16 B of ITS OWN random 64-byte texel (4 consecutive loads cover the texel)     [the sample kernel today]
 //   mode 1: the 4 lanes of a quad read the 4 x 16 B of ONE random texel (one load covers it; 4 loads = 4 texels)
+//   mode 2: the 2 lanes of a pair read 2 x 16 B (a 32-byte run) of one random texel
 // hipcc --offload-arch=gfx950 -O3 tools/gather_ubench.hip -o /tmp/gub && /tmp/gub
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,7 +14,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(const float4* __restrict__ grid, unsigned n_texels, float* out, int iters)
 {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned s = (MODE == 0 ? tid : (tid >> 2)) * 2654435761u + 12345u;
+    unsigned s = (MODE == 0 ? tid : MODE == 1 ? (tid >> 2) : (tid >> 1)) * 2654435761u + 12345u;
     float4 acc = make_float4(0, 0, 0, 0);
     for (int it = 0; it < iters; ++it) {
         // 6 "taps" of 4 loads each, like one plane pair with a 64-byte texel
@@ -24,11 +25,18 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ grid, unsign
                 const float4* p = grid + (size_t)(s % n_texels) * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const float4 v = p[q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-            } else {
+            } else if (MODE == 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     s = rnd(s);
                     const float4 v = grid[(size_t)(s % n_texels) * 4 + (tid & 3)];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            } else {          // MODE 2: the 2 lanes of a pair read 2 x 16 B of one random 32-byte half texel
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s = rnd(s);
+                    const float4 v = grid[(size_t)(s % n_texels) * 4 + (q & 2) + (tid & 1)];
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
             }
@@ -66,8 +74,8 @@ int main()
     for (unsigned kb : {16u, 1024u, 46u * 1024u}) {
         const unsigned n_texels = kb * 1024 / 64;
         printf("-- working set %u KB\n", kb);
-        run<0>(grid, n_texels, out, 16); run<1>(grid, n_texels, out, 16);
-        run<0>(grid, n_texels, out, 16); run<1>(grid, n_texels, out, 16);
+        run<0>(grid, n_texels, out, 16); run<1>(grid, n_texels, out, 16); run<2>(grid, n_texels, out, 16);
+        run<0>(grid, n_texels, out, 16); run<1>(grid, n_texels, out, 16); run<2>(grid, n_texels, out, 16);
     }
     return 0;
 }
