@@ -456,3 +456,15 @@ def test_cascade_intermediates_and_ragged_counts(case, precision):
     for key in ('color_scale', 'color_shift', 'point_offset'):
         if key in emb and key in ref:
             assert linf(emb[key].cpu().numpy(), ref[key].reshape(rays.shape[0], -1)) <= 2e-5, key
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'immersive_sphere_small', 'sweep/bom_sphere'])
+def test_dead_column_pruning_changes_nothing(case, monkeypatch):
+    """hr_model_finalize drops head columns the path never reads (origin channels scaled by zero, unread sigma heads) from
+    the last Linear; with HR_PRUNE=0 it keeps them.  Same arithmetic on the live columns -> bit-identical images."""
+    from gpu_common import make_render_fn, render_np
+    g = Golden(case)
+    pruned = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict), g.rays)['rgb']
+    monkeypatch.setenv('HR_PRUNE', '0')
+    full = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict), g.rays)['rgb']
+    assert np.array_equal(pruned, full)
