@@ -20,8 +20,14 @@ HEADERS = ['hr_kernels.h', 'hr_math.h', os.path.join('..', '..', 'include', 'hyp
 # places where fusion is wanted use __builtin_fmaf explicitly.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-math-errno', '-Wall', '-Wno-unused-function']
-if os.environ.get('HR_FAST_MATH', '1') != '0':
-    FLAGS.append('-DHR_FAST_MATH')   # 1-ulp rcp/sqrt/exp in the per-sample arithmetic (hr_math.h)
+# 1-ulp hardware exp (+ rcp inside sigmoid/tanh) for VALUES that are never compared against a threshold; divisions, square
+# roots and sin/cos keep their IEEE forms so that the reference's exact comparisons fall the same way (csrc/hr_math.h)
+if os.environ.get('HR_FAST_EXP', '1') != '0':
+    FLAGS.append('-DHR_FAST_EXP')
+if os.environ.get('HR_FAST_POST', '1') != '0':       # rcp / sqrt / tanh approximations strictly after the near/far mask
+    FLAGS.append('-DHR_FAST_POST')
+if os.environ.get('HR_FAST_MATH', '0') == '1':       # measurements only: all three approximation groups
+    FLAGS.append('-DHR_FAST_MATH')
 
 
 def hipcc():

@@ -69,6 +69,7 @@ struct hr_model {
     int64_t packed_bytes = 0;
     // point_prediction cascade (hr_model_create_cascade): `this` is the fine level (point MLP, second intersect,
     // colour); `coarse` holds the ray MLP and the first intersect and owns no grids
+    hr_config* kcfg_dev = nullptr;       // device copy of kcfg for the sample kernel (the MLP kernels take it by value)
     hr_model* coarse = nullptr;
     bool is_coarse = false;
     float* rows = nullptr;   // input rows of the point MLP for one chunk: (chunk * casc_in_z, casc_row_dim)
@@ -273,6 +274,13 @@ static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
     m->cfg = *cfg;
     m->is_coarse = coarse;
     analyse_live_columns(m);
+    {   // the kernels read the configuration from device memory
+        if (hipMalloc((void**)&m->kcfg_dev, sizeof(hr_config)) != hipSuccess) {
+            delete m;
+            return fail(HR_E_HIP, "hipMalloc of the device configuration failed");
+        }
+        (void)hipMemcpy(m->kcfg_dev, &m->kcfg, sizeof(hr_config), hipMemcpyHostToDevice);
+    }
     const hr_config& c = m->cfg;
     {   // LDS of the sample kernel: 256/ZP rays x head rows x (live head columns + 4) + the decode matrices
         int ZP = 8;
@@ -613,6 +621,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
 
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
 {
+    a.cfg_dev = m->kcfg_dev;
     a.rays = rays;
     a.head = m->head;
     a.nq = (m->n_out + 3) / 4;
@@ -788,6 +797,7 @@ void hr_model_destroy(hr_model* m)
     free_dev(m->basis);
     free_dev(m->head);
     free_dev(m->rows);
+    if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     hr_model_destroy(m->coarse);
     delete m;
 }

@@ -61,6 +61,8 @@ struct HrGridPlane {
 };
 
 struct HrSampleArgs {
+    const hr_config* cfg_dev;   // device copy of the configuration: the sample kernel indexes it per lane (samples[k] ...), and a
+                                // 2 KB by-value kernel argument indexed dynamically can end up copied to scratch by the compiler
     const float* rays;
     const float* head;      // HQ layout (hr_head_index)
     int nq;                 // ceil(Z*P / 4)

@@ -363,8 +363,11 @@ __device__ __forceinline__ void hr_gather_plane_coop(const HrGridPlane& g, const
 }
 
 template <int ZP, bool HALF>
-__global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config cfg, const HrSampleArgs a)
+__global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config* __restrict__ cfgp, const HrSampleArgs a)
 {
+    // the configuration lives in device memory (2 KB: too large to index dynamically as a by-value kernel argument
+    // without the compiler copying it to scratch); uniform reads of it become scalar loads
+    const hr_config& cfg = *cfgp;
     constexpr int RPB = 256 / ZP;   // rays per block
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Z = cfg.z_channels;
@@ -541,15 +544,15 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
             if (cfg.shading == HR_SHADING_SH) {    // SHRender, tensorf_utils.py:334-338
                 r0 = fmaxf(pre0 + 0.5f, 0.0f); r1 = fmaxf(pre1 + 0.5f, 0.0f); r2 = fmaxf(pre2 + 0.5f, 0.0f);
             } else {                               // RGBRender, tensorf_utils.py:341-343
-                r0 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre0)); r1 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre1)); r2 = HR_DIV(1.0f, 1.0f + HR_EXP(-pre2));
+                r0 = HR_RCP(1.0f + HR_EXP(-pre0)); r1 = HR_RCP(1.0f + HR_EXP(-pre1)); r2 = HR_RCP(1.0f + HR_EXP(-pre2));
             }
         }
         if (cfg.f_color_scale.offset >= 0) {       // scale_shift_color_all, tensorf_utils.py:267-273
             const hr_head_field& fs = cfg.f_color_scale;
             const hr_head_field& fh = cfg.f_color_shift;
-            r0 = r0 * (hr_apply_act(fs.act, hk[fs.offset + 0]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 0]);
-            r1 = r1 * (hr_apply_act(fs.act, hk[fs.offset + 1]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 1]);
-            r2 = r2 * (hr_apply_act(fs.act, hk[fs.offset + 2]) + 1.0f) + hr_apply_act(fh.act, hk[fh.offset + 2]);
+            r0 = r0 * (hr_apply_act_post(fs.act, hk[fs.offset + 0]) + 1.0f) + hr_apply_act_post(fh.act, hk[fh.offset + 0]);
+            r1 = r1 * (hr_apply_act_post(fs.act, hk[fs.offset + 1]) + 1.0f) + hr_apply_act_post(fh.act, hk[fh.offset + 1]);
+            r2 = r2 * (hr_apply_act_post(fs.act, hk[fs.offset + 2]) + 1.0f) + hr_apply_act_post(fh.act, hk[fh.offset + 2]);
         }
         c0 = weight * r0; c1 = weight * r1; c2 = weight * r2;
     }
@@ -657,10 +660,10 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     do { \
         if (cfg.grid_dtype == HR_GRID_FP16) { \
             if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, true>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, true>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
         } else { \
             if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, false>), dim3(blocks), dim3(256), lds, stream, cfg, args2); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, false>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
         } \
     } while (0)
     switch (ZP) {
