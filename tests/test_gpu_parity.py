@@ -468,3 +468,22 @@ def test_dead_column_pruning_changes_nothing(case, monkeypatch):
     monkeypatch.setenv('HR_PRUNE', '0')
     full = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict), g.rays)['rgb']
     assert np.array_equal(pruned, full)
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_cylinder_frame_threshold_decisions(precision):
+    """20 000 rays of the 800x800 / 600^3 cylinder frame.  With 1-ulp rcp/sqrt in the distance arithmetic one of them
+    lands on the other side of `dist <= near` (RGB off by 5e-2): everything that feeds a threshold is IEEE arithmetic."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    name = 'donerf_cylinder'
+    cfg, ds = C.model_config(name), C.dataset_scalars(name)
+    grid = C.final_grid_size(cfg)
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=7, density='dense', app_scale=1.0)
+    rays = scenes.benchmark_rays(name, 800, 800, frame=7)
+    idx = np.random.default_rng(0).choice(rays.shape[0], 20000, replace=False)
+    r = np.ascontiguousarray(rays[idx])
+    got = render_np(make_render_fn(cfg, ds, sd, mlp_precision=precision), r)['rgb']
+    ref = HyperReelOracle(cfg, ds, sd).render(r)['rgb']
+    err = np.abs(got - ref).max(-1)
+    assert err.max() <= RGB_TOL, f'{int((err > RGB_TOL).sum())} rays over, worst {err.max():.3e} at frame pixel {int(idx[err.argmax()])}'
