@@ -115,7 +115,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--torch-gpu', action='store_true', help='also time the PyTorch-ROCm port of the reference algorithm on this GPU')
-    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'fp32'],
+    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'fp32'],
                     help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
@@ -256,9 +256,10 @@ def main():
         nl = len(offs)
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
-        split = model._hc.mlp_precision == 1
+        split = model._hc.mlp_precision in (1, 2)
+        split_kernel = 'hr_mlp_f16x3_kernel' if model._hc.mlp_precision == 2 else 'hr_mlp_bf16x3_kernel'
         peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        r_mlp = {'kernel': 'hr_mlp_bf16x3_kernel' if split else 'hr_mlp_kernel', 'bound': 'mfma',
+        r_mlp = {'kernel': split_kernel if split else 'hr_mlp_kernel', 'bound': 'mfma',
                  'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
                  'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / peak, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(mlp_ms[0] / nl, 4),
@@ -281,7 +282,7 @@ def main():
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
             w = tr['workload']
             if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
-                    and (w['mlp_precision'] == 'bf16x3') == split and texel_bytes == 4):
+                    and (w['mlp_precision'] == 'bf16x3') == (model._hc.mlp_precision == 1) and texel_bytes == 4):
                 r_mlp['traffic'] = tr[r_mlp['kernel']]['traffic_bytes'] if r_mlp['kernel'] in tr else None
                 r_smp['traffic'] = tr['hr_sample_kernel']['traffic_bytes']
                 r_mlp['traffic_unit'] = r_smp['traffic_unit'] = 'bytes per launch (profiles/r01_traffic.json)'
@@ -306,8 +307,9 @@ def main():
 
     result['grid_dtype'] = args.grid_dtype
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else 'hipGraph replay of one captured frame'
-    result['mlp_gemm'] = ('bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)'
-                          if model._hc.mlp_precision == 1 else 'fp32 MFMA')
+    result['mlp_gemm'] = {1: 'bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)',
+                          2: 'f16x3 split on MFMA, fp32 accumulate (22 mantissa bits; activations must stay below 65504)',
+                          0: 'fp32 MFMA'}[int(model._hc.mlp_precision)]
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same
     #      algorithm as stock PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda';
     #      the reference itself cannot travel to the GPU box).  Reported, never part of `value`.

@@ -154,9 +154,9 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-    if (c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_BF16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
-    if (c.mlp_layers != 0 && c.mlp_precision == HR_MLP_BF16X3 && c.mlp_hidden != 256)
-        return fail(HR_E_INVALID, "the bf16x3 MLP needs mlp_hidden == 256");
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
+        return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
     if (c.color_table_views < 0) return fail(HR_E_INVALID, "negative color_table_views");
     if (c.color_table_views > 0 && c.ray_dim != 8) return fail(HR_E_INVALID, "the colour table is indexed by rays[..., -2]: needs 8-column rays");
@@ -241,6 +241,22 @@ uint16_t bf16_rne(float f)
     memcpy(&u, &f, 4);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// float -> IEEE half bits and back (round to nearest even; overflow -> inf like the hardware conversion)
+uint16_t f16_rne(float f)
+{
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+float f16_to_float(uint16_t u)
+{
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
 }
 
 float bf16_to_float(uint16_t h)
@@ -416,7 +432,8 @@ int hr_model_finalize(hr_model* m)
         const bool first = (l == 0);
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
-        const bool split = (c.mlp_precision == HR_MLP_BF16X3);
+        const bool split = (c.mlp_precision != HR_MLP_FP32);
+        const bool half = (c.mlp_precision == HR_MLP_F16X3);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -461,8 +478,8 @@ int hr_model_finalize(hr_model* m)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
                             const float v = wk(32 * t + (lane & 31), 16 * kt + 8 * (lane >> 5) + j);
-                            const uint16_t hi = bf16_rne(v);
-                            const uint16_t lo = bf16_rne(v - bf16_to_float(hi));
+                            const uint16_t hi = half ? f16_rne(v) : bf16_rne(v);
+                            const uint16_t lo = half ? f16_rne(v - f16_to_float(hi)) : bf16_rne(v - bf16_to_float(hi));
                             const size_t base = ((((size_t)kt * nt + t) * 2) * 64 + lane) * 8 + j;
                             pk[base] = hi;
                             pk[base + 64 * 8] = lo;
@@ -599,6 +616,7 @@ static void launch_mlp(const hr_config& c, const HrMlpArgs& a, hipStream_t st)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
+    else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else hr_launch_mlp(c, a, st);
 }
 
