@@ -115,7 +115,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--torch-gpu', action='store_true', help='also time the PyTorch-ROCm port of the reference algorithm on this GPU')
-    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'fp32'],
+    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16x2', 'fp32'],
                     help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
@@ -256,8 +256,8 @@ def main():
         nl = len(offs)
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
-        split = model._hc.mlp_precision in (1, 2)
-        split_kernel = 'hr_mlp_f16x3_kernel' if model._hc.mlp_precision == 2 else 'hr_mlp_bf16x3_kernel'
+        split = model._hc.mlp_precision in (1, 2, 3)
+        split_kernel = {1: 'hr_mlp_bf16x3_kernel', 2: 'hr_mlp_f16x3_kernel', 3: 'hr_mlp_f16x2_kernel'}.get(int(model._hc.mlp_precision))
         peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
         r_mlp = {'kernel': split_kernel if split else 'hr_mlp_kernel', 'bound': 'mfma',
                  'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
@@ -271,7 +271,9 @@ def main():
             # measured with tools/mfma_peak.hip on MI355X: back-to-back v_mfma_f32_32x32x16_bf16 on register-resident
             # operands sustain 1.89 PFLOP/s (the chip settles at ~1.8 GHz under matrix load), not the 2.5 PFLOP/s of `peak`
             r_mlp['sustained_mfma_peak'] = MFMA_BF16_SUSTAINED_TFLOPS
-            r_mlp['frac_of_sustained_issue'] = round(3 * flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED_TFLOPS, 4)
+            n_prod = 2 if model._hc.mlp_precision == 3 else 3
+            r_mlp['mfma_products_per_gemm'] = n_prod
+            r_mlp['frac_of_sustained_issue'] = round(n_prod * flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED_TFLOPS, 4)
         r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
@@ -309,6 +311,7 @@ def main():
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else 'hipGraph replay of one captured frame'
     result['mlp_gemm'] = {1: 'bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)',
                           2: 'f16x3 split on MFMA, fp32 accumulate (22 mantissa bits; activations must stay below 65504)',
+                          3: 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
                           0: 'fp32 MFMA'}[int(model._hc.mlp_precision)]
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same
     #      algorithm as stock PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda';

@@ -154,7 +154,7 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X3) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X2) return fail(HR_E_INVALID, "unknown mlp_precision");
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -433,7 +433,7 @@ int hr_model_finalize(hr_model* m)
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
         const bool split = (c.mlp_precision != HR_MLP_FP32);
-        const bool half = (c.mlp_precision == HR_MLP_F16X3);
+        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -617,6 +617,7 @@ static void launch_mlp(const hr_config& c, const HrMlpArgs& a, hipStream_t st)
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
+    else if (c.mlp_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
     else hr_launch_mlp(c, a, st);
 }
 

@@ -88,6 +88,7 @@ void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stre
 //   W[n = 32*nt + (lane & 31)][k = 16*kt + 8*(lane >> 5) + 0..7], part 0 = hi (bf16(w)), 1 = lo (bf16(w - hi))
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_mlp_f16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // same layouts, fp16 halves
+void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);

@@ -187,7 +187,7 @@ class _Affine:
 
 
 # --------------------------------------------------------------------------- the compiler
-MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2}
+MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3}
 
 
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
@@ -599,7 +599,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     # 'fp32' (exact fp32 MFMA) otherwise or on request.
     if mlp_precision == 'auto' or hc.mlp_layers == 0:
         mlp_precision = 'bf16x3' if hc.mlp_hidden == 256 else 'fp32'
-    if mlp_precision in ('bf16x3', 'f16x3') and hc.mlp_hidden != 256:
+    if mlp_precision in ('bf16x3', 'f16x3', 'f16x2') and hc.mlp_hidden != 256:
         raise NotImplementedError(f'{mlp_precision} MLP needs hidden_channels == 256')
     hc.mlp_precision = MLP_PRECISION[mlp_precision]
     if grid_dtype not in GRID_DTYPE:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 8
+#define HR_ABI_VERSION 9
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -92,8 +92,9 @@ enum { HR_DENSITY_RELU = 0, HR_DENSITY_SOFTPLUS = 1, HR_DENSITY_RELU_ABS = 2 };
 enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
 /* arithmetic of the MLP GEMMs: exact fp32 MFMA, or three 16-bit MFMA products of the hi/lo split operands with fp32
  * accumulation (needs mlp_hidden 256): bf16 halves (~2^-17 relative per product, fp32 range) or fp16 halves (~2^-22,
- * i.e. fp32-grade, but activations must stay below 65504) */
-enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2 };
+ * i.e. fp32-grade, but activations must stay below 65504); F16X2 additionally takes the weights as single halfs (two
+ * products, 2^-12 relative weight rounding) */
+enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
