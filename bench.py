@@ -178,7 +178,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: only this thread's calls are policed during capture (the RCCL watchdog thread of a multi-rank
+        # run may query its events meanwhile)
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             rgb_static = model.render(rays)['rgb']
 
     def step():
