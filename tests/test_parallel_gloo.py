@@ -61,3 +61,42 @@ def test_sharded_render_matches_single_process(tmp_path, n_rays):
         got = np.load(tmp_path / f'rank{r}.npy')
         assert got.shape == (n_rays, 3)
         assert np.array_equal(got, ref)       # same oracle, same rays: the gather must not change a bit
+
+
+class _FakeCameraModel:
+    """Stands in for HipLightfieldModel.render_camera on CPU: colour = a function of the pixel index."""
+
+    def __init__(self):
+        self.calls = []
+
+    def render_camera(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None):
+        lo, hi = (0, width * height) if pixel_range is None else pixel_range
+        self.calls.append((lo, hi))
+        i = torch.arange(lo, hi, dtype=torch.float32)
+        return torch.stack([i, i * 0.5, i % 7], -1)
+
+
+def _camera_worker(rank, world, port, width, height, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from hyperreel_amd.parallel import render_camera_sharded, shard_range
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    m = _FakeCameraModel()
+    full = render_camera_sharded(m, None, None, width, height)
+    assert m.calls == [shard_range(width * height, rank, world)]      # every rank renders its own pixel range only
+    np.save(os.path.join(out_dir, f'cam{rank}.npy'), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('wh', [(8, 6), (7, 5)])
+def test_camera_sharding_assembles_the_frame(tmp_path, wh):
+    world = 2
+    mp.spawn(_camera_worker, args=(world, _free_port(), wh[0], wh[1], str(tmp_path)), nprocs=world, join=True)
+    ref = _FakeCameraModel().render_camera(None, None, wh[0], wh[1]).numpy()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'cam{r}.npy'), ref)
