@@ -125,3 +125,19 @@ def test_shard_bounds():
     assert shard_bounds(10, 4) == [0, 3, 6, 8, 10]
     assert shard_bounds(640000, 8)[-1] == 640000 and shard_range(640000, 7, 8) == (560000, 640000)
     assert shard_bounds(3, 8)[-1] == 3
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: the header compiles as C99 and a C program can call the library (no GPU needed
+    for the calls made here)."""
+    import subprocess
+    from hyperreel_amd import build
+    lib = build.build()
+    exe = tmp_path / 'abi_check'
+    src = os.path.join(ROOT, 'tests', 'c_abi', 'abi_check.c')
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), src, '-o', str(exe),
+                    '-L', os.path.dirname(lib), '-lhyperreel_hip', '-Wl,-rpath,' + os.path.dirname(lib),
+                    '-Wl,-rpath,/opt/rocm/lib'], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert 'error text:' in r.stdout
