@@ -113,13 +113,17 @@ typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 //   neural_3d Z=64 keyframe         4.55 (L1 hit rate 61 %)   3.95                   2.93
 template <int ZP, bool HALF>
 struct HrGatherTune {
+#ifdef HR_SAMPLE_MIN_BLOCKS_FP32
+    static constexpr int MIN_BLOCKS = HALF ? 5 : HR_SAMPLE_MIN_BLOCKS_FP32;
+#else
     static constexpr int MIN_BLOCKS = HALF ? 5 : 4;
+#endif
 };
 
 // acc[j] (+)= w * texel[q0 + j] for the first min(nb, G) channel groups of one tap; `off` is the
-// element offset of the tap's texel.  FIRST: acc = v * w, else acc = fma(v, w, acc) (ATen's bilinear order).
+// BYTE offset of the tap's texel.  FIRST: acc = v * w, else acc = fma(v, w, acc) (ATen's bilinear order).
 template <bool HALF, int G, bool FIRST>
-__device__ __forceinline__ void hr_tap(const void* base, int off, int q0, int nb, float w, float4 (&acc)[G])
+__device__ __forceinline__ void hr_tap(const void* base, unsigned off, int q0, int nb, float w, float4 (&acc)[G])
 {
     auto put = [&](int j, const float4 v) {
         if (FIRST) {
@@ -130,7 +134,7 @@ __device__ __forceinline__ void hr_tap(const void* base, int off, int q0, int nb
         }
     };
     if constexpr (!HALF) {
-        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off) + q0;
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (size_t)(off + 16u * (unsigned)q0));
         float4 v[G];
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -139,7 +143,7 @@ __device__ __forceinline__ void hr_tap(const void* base, int off, int q0, int nb
         for (int j = 0; j < G; ++j)
             if (j < nb) put(j, v[j]);
     } else {
-        const hr_half8* p = reinterpret_cast<const hr_half8*>(reinterpret_cast<const _Float16*>(base) + off) + (q0 >> 1);
+        const hr_half8* p = reinterpret_cast<const hr_half8*>(reinterpret_cast<const char*>(base) + (size_t)(off + 16u * (unsigned)(q0 >> 1)));
         constexpr int NO = (G + 1) / 2;
         hr_half8 h[NO];
 #pragma unroll
@@ -182,18 +186,20 @@ __device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const floa
     const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
     const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
     const float v00 = bxp.w0 * byp.w0, v01 = bxp.w1 * byp.w0, v10 = bxp.w0 * byp.w1, v11 = bxp.w1 * byp.w1;
-    // element offsets of the taps' texels
-    const int ia00 = (ty.i0 * g.aw + tx.i0) * tex, ia01 = (ty.i0 * g.aw + tx.i1) * tex;
-    const int ia10 = (ty.i1 * g.aw + tx.i0) * tex, ia11 = (ty.i1 * g.aw + tx.i1) * tex;
-    const int ib00 = line ? bxp.i0 * tex : (byp.i0 * g.bw + bxp.i0) * tex;
-    const int ib01 = line ? bxp.i1 * tex : (byp.i0 * g.bw + bxp.i1) * tex;
-    const int ib10 = (byp.i1 * g.bw + bxp.i0) * tex, ib11 = (byp.i1 * g.bw + bxp.i1) * tex;
+    // BYTE offsets of the taps' texels, unsigned 32-bit: a load is then `uniform base + zero-extended VGPR offset` and
+    // needs no 64-bit address arithmetic
+    const unsigned esz = HALF ? 2u : 4u, texb = (unsigned)tex * esz;
+    const unsigned ia00 = (unsigned)(ty.i0 * g.aw + tx.i0) * texb, ia01 = (unsigned)(ty.i0 * g.aw + tx.i1) * texb;
+    const unsigned ia10 = (unsigned)(ty.i1 * g.aw + tx.i0) * texb, ia11 = (unsigned)(ty.i1 * g.aw + tx.i1) * texb;
+    const unsigned ib00 = line ? (unsigned)bxp.i0 * texb : (unsigned)(byp.i0 * g.bw + bxp.i0) * texb;
+    const unsigned ib01 = line ? (unsigned)bxp.i1 * texb : (unsigned)(byp.i0 * g.bw + bxp.i1) * texb;
+    const unsigned ib10 = (unsigned)(byp.i1 * g.bw + bxp.i0) * texb, ib11 = (unsigned)(byp.i1 * g.bw + bxp.i1) * texb;
     if constexpr (HALF) {
         // float16 texels: one 16-byte load brings two channel groups; octet-major order (all taps of an octet, then the
         // next octet) keeps 96 VGPRs without spills and measured 0.86 vs 1.08 ms against the tap-major form below
-        const _Float16* A = reinterpret_cast<const _Float16*>(g.a);
-        const _Float16* B = reinterpret_cast<const _Float16*>(g.b);
-        auto ld = [](const _Float16* p, int o) { return *reinterpret_cast<const hr_half8*>(p + 8 * o); };
+        const char* A = reinterpret_cast<const char*>(g.a);
+        const char* B = reinterpret_cast<const char*>(g.b);
+        auto ld = [](const char* p, int o) { return *reinterpret_cast<const hr_half8*>(p + (size_t)(16u * (unsigned)o)); };
         auto lo4 = [](const hr_half8 h) { return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); };
         auto hi4 = [](const hr_half8 h) { return make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]); };
         const int no = (ng + 1) >> 1;
@@ -261,34 +267,34 @@ __device__ __forceinline__ float hr_dpp_f(float v)
 template <int CTRL>
 __device__ __forceinline__ int hr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 
-struct HrTaps {                 // one plane pair's taps of one sample: element offsets and weights
-    int ia[4];                  // plane: nw, ne, sw, se
-    float wa[4];
-    int ib[4];                  // line: low, high (2 used) / time plane: 4
+struct HrTaps {                 // one plane pair's taps of one sample: BYTE offsets of the texels (unsigned 32-bit, so
+    unsigned ia[4];             //   that a load is `uniform base + zero-extended VGPR offset`: no 64-bit address
+    float wa[4];                //   arithmetic per load) and weights.  plane: nw, ne, sw, se
+    unsigned ib[4];             // line: low, high (2 used) / time plane: 4
     float wb[4];
 };
 
 __device__ __forceinline__ HrTaps hr_make_taps(const HrGridPlane& g, const float (&pn)[4])
 {
     HrTaps t;
-    const int tex = g.tex;
+    const unsigned tex = (unsigned)g.tex * 4u;            // bytes per fp32 texel
     const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
     const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
     const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
     const hr_axis_tap tx = hr_make_tap(gx, g.aw);
     const hr_axis_tap ty = hr_make_tap(gy, g.ah);
     t.wa[0] = tx.w0 * ty.w0; t.wa[1] = tx.w1 * ty.w0; t.wa[2] = tx.w0 * ty.w1; t.wa[3] = tx.w1 * ty.w1;
-    t.ia[0] = (ty.i0 * g.aw + tx.i0) * tex; t.ia[1] = (ty.i0 * g.aw + tx.i1) * tex;
-    t.ia[2] = (ty.i1 * g.aw + tx.i0) * tex; t.ia[3] = (ty.i1 * g.aw + tx.i1) * tex;
+    t.ia[0] = (unsigned)(ty.i0 * g.aw + tx.i0) * tex; t.ia[1] = (unsigned)(ty.i0 * g.aw + tx.i1) * tex;
+    t.ia[2] = (unsigned)(ty.i1 * g.aw + tx.i0) * tex; t.ia[3] = (unsigned)(ty.i1 * g.aw + tx.i1) * tex;
     const bool line = (g.bw == 1);
     const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
     const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
     if (line) {
-        t.ib[0] = bxp.i0 * tex; t.ib[1] = bxp.i1 * tex; t.ib[2] = 0; t.ib[3] = 0;
+        t.ib[0] = (unsigned)bxp.i0 * tex; t.ib[1] = (unsigned)bxp.i1 * tex; t.ib[2] = 0; t.ib[3] = 0;
         t.wb[0] = bxp.w0; t.wb[1] = bxp.w1; t.wb[2] = 0.0f; t.wb[3] = 0.0f;
     } else {
-        t.ib[0] = (byp.i0 * g.bw + bxp.i0) * tex; t.ib[1] = (byp.i0 * g.bw + bxp.i1) * tex;
-        t.ib[2] = (byp.i1 * g.bw + bxp.i0) * tex; t.ib[3] = (byp.i1 * g.bw + bxp.i1) * tex;
+        t.ib[0] = (unsigned)(byp.i0 * g.bw + bxp.i0) * tex; t.ib[1] = (unsigned)(byp.i0 * g.bw + bxp.i1) * tex;
+        t.ib[2] = (unsigned)(byp.i1 * g.bw + bxp.i0) * tex; t.ib[3] = (unsigned)(byp.i1 * g.bw + bxp.i1) * tex;
         t.wb[0] = bxp.w0 * byp.w0; t.wb[1] = bxp.w1 * byp.w0; t.wb[2] = bxp.w0 * byp.w1; t.wb[3] = bxp.w1 * byp.w1;
     }
     return t;
@@ -309,27 +315,28 @@ __device__ __forceinline__ void hr_gather_coop_step(const HrGridPlane& g, const 
     HrTaps t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        t.ia[i] = hr_dpp_i<B>(mine.ia[i]);
+        t.ia[i] = (unsigned)hr_dpp_i<B>((int)mine.ia[i]);
         t.wa[i] = hr_dpp_f<B>(mine.wa[i]);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        t.ib[i] = hr_dpp_i<B>(mine.ib[i]);
+        t.ib[i] = (unsigned)hr_dpp_i<B>((int)mine.ib[i]);
         t.wb[i] = hr_dpp_f<B>(mine.wb[i]);
     }
     if (!line) {
 #pragma unroll
         for (int i = 2; i < 4; ++i) {
-            t.ib[i] = hr_dpp_i<B>(mine.ib[i]);
+            t.ib[i] = (unsigned)hr_dpp_i<B>((int)mine.ib[i]);
             t.wb[i] = hr_dpp_f<B>(mine.wb[i]);
         }
     }
     const int ng = g.cd4 + g.ca4, cd = g.cd4;
-    const float* A = reinterpret_cast<const float*>(g.a);
-    const float* Bp = reinterpret_cast<const float*>(g.b);
+    const char* A = reinterpret_cast<const char*>(g.a);
+    const char* Bp = reinterpret_cast<const char*>(g.b);
     float s = 0.0f, p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
     for (int q = j; q < ng; q += LPS) {                   // this lane's channel group(s)
-        auto ld = [q](const float* p, int off) { return *reinterpret_cast<const float4*>(p + off + 4 * q); };
+        const unsigned qb = 16u * (unsigned)q;
+        auto ld = [qb](const char* p, unsigned off) { return *reinterpret_cast<const float4*>(p + (size_t)(off + qb)); };
         const float4 pa = hr_bilerp4(ld(A, t.ia[0]), ld(A, t.ia[1]), ld(A, t.ia[2]), ld(A, t.ia[3]), t.wa[0], t.wa[1], t.wa[2], t.wa[3]);
         const float4 pb = line ? hr_lerp4(ld(Bp, t.ib[0]), ld(Bp, t.ib[1]), t.wb[0], t.wb[1])
                                : hr_bilerp4(ld(Bp, t.ib[0]), ld(Bp, t.ib[1]), ld(Bp, t.ib[2]), ld(Bp, t.ib[3]), t.wb[0], t.wb[1], t.wb[2], t.wb[3]);
