@@ -439,12 +439,13 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
 
     // ---- decode matrix of this ray: M[c][ch] (RGB: basis_mat rows; SH: sum_j sh_j(d) * basis row c*9+j)
     {
-        float sh[9];
-        hr_sh_deg2(vd[0], vd[1], vd[2], sh);
+        float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (cfg.shading == HR_SHADING_SH) hr_sh_deg2(vd[0], vd[1], vd[2], sh);
         float* M = s_M + rib * 3 * CA;
         const int nat = a.n_basis_cols;
-        for (int e = k; e < 3 * CA; e += ZP) {
-            const int c = e / CA, pos = e - c * CA;
+        for (int c = 0; c < 3; ++c)
+        for (int pos = k; pos < CA; pos += ZP) {          // (no integer division by the runtime CA)
+            const int e = c * CA + pos;
             // padded slot -> column of basis_mat (the reference concatenates only real channels)
             int col = -1;
 #pragma unroll
@@ -467,9 +468,12 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     __syncthreads();
 
     // sample k's P head values: row k / M of the ray, columns (k % M) * P ..  (M == Z when RPR == 1)
-    const int Mz = Z / RPR;
     const int kk = lane_ok ? k : 0;
-    const float* hk = s_head + (rib * RPR + kk / Mz) * HS + (kk % Mz) * P;
+    const float* hk = s_head + rib * HS + kk * P;
+    if (RPR != 1) {                                        // cascades only: integer division by a runtime value
+        const int Mz = Z / RPR;
+        hk = s_head + (rib * RPR + kk / Mz) * HS + (kk % Mz) * P;
+    }
 
     // ---- distances: intersect + mask, then sort along the ray (base.py:152-210)
     float dist = __builtin_inff();
