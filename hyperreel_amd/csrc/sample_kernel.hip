@@ -103,9 +103,24 @@ __device__ __forceinline__ void hr_consume_group(const HrGridPlane& g, int q, in
 
 typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 
+// The three plane pairs of a VM decomposition sample the SAME three axis coordinates: plane j spans axes
+// (MAT[j][0], MAT[j][1]) and its line / time plane runs along VEC[j] (tensorf_base.py:231-232, tensorf_dynamic.py:48),
+// every axis always at that axis' grid size.  So a sample needs three 1-D taps (+ one along the keyframes), computed
+// once, instead of three per plane pair.
+struct HrAxisTaps {
+    hr_axis_tap ax[3];          // x @ grid[0], y @ grid[1], z @ grid[2]
+    hr_axis_tap t;              // keyframe axis (video) -- unused otherwise
+};
+
+template <int J> struct HrPlaneAxes {
+    static constexpr int A0 = (J == 2) ? 1 : 0;           // MAT_MODE[j][0]: 0, 0, 1
+    static constexpr int A1 = (J == 0) ? 1 : 2;           // MAT_MODE[j][1]: 1, 2, 2
+    static constexpr int V = 2 - J;                       // VEC_MODE[j] = MAT_MODE_TIME[j][0]: 2, 1, 0
+};
+
 // How the gather is compiled per kernel variant.  fp32 texels: the lanes of a quad (or pair) cooperate on one sample
-// at a time (hr_gather_plane_coop below) at 4 workgroups/CU; float16 texels: every lane gathers its own sample, one
-// 16-byte load per two channel groups, at 5 workgroups/CU.  Measured sample stage, ms per 800x800 frame:
+// at a time (hr_gather_plane_coop below); float16 texels: every lane gathers its own sample, one 16-byte load per two
+// channel groups.  Both at 4 workgroups/CU.  Measured sample stage, ms per 800x800 frame:
 //                            own-sample, group-major   own-sample, 2 groups/tap   cooperative
 //   DoNeRF Z=32 static              1.18                      1.39                   1.12
 //   technicolor Z=32 keyframe       1.13                       -                     0.94
@@ -114,9 +129,9 @@ typedef _Float16 hr_half8 __attribute__((ext_vector_type(8)));
 template <int ZP, bool HALF>
 struct HrGatherTune {
 #ifdef HR_SAMPLE_MIN_BLOCKS_FP32
-    static constexpr int MIN_BLOCKS = HALF ? 5 : HR_SAMPLE_MIN_BLOCKS_FP32;
+    static constexpr int MIN_BLOCKS = HR_SAMPLE_MIN_BLOCKS_FP32;
 #else
-    static constexpr int MIN_BLOCKS = HALF ? 5 : 4;
+    static constexpr int MIN_BLOCKS = 4;     // 110-120 VGPRs; 5 workgroups/CU (96) spills in both texel formats
 #endif
 };
 
@@ -165,26 +180,23 @@ __device__ __forceinline__ void hr_tap(const void* base, unsigned off, int q0, i
 //  gather with LDS hand-over, 1.66 vs 1.27 ms per frame; compile-time unrolled batches of 12-16
 //  loads in flight at 4 waves/SIMD, 1.37 ms.  The gather sits at ~1.1 vector-L1 accesses per
 //  clock per CU, i.e. it is bound by the tag-lookup rate for scattered 16-byte reads.)
-template <bool HALF, int G>
-__device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const float (&pn)[4], const float* M, int CA,
+template <bool HALF, int G, int J>
+__device__ __forceinline__ void hr_gather_plane(const HrGridPlane& g, const HrAxisTaps& at, const float* M, int CA,
                                                 float& sig_feat, float& pre0, float& pre1, float& pre2)
 {
     const int ng = g.cd4 + g.ca4;
     const int cd = g.cd4;
     if (ng == 0) return;
     const int tex = g.tex;
-    const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
-    const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
-    const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
-    const hr_axis_tap tx = hr_make_tap(gx, g.aw);
-    const hr_axis_tap ty = hr_make_tap(gy, g.ah);
+    const hr_axis_tap tx = at.ax[HrPlaneAxes<J>::A0];
+    const hr_axis_tap ty = at.ax[HrPlaneAxes<J>::A1];
     // ATen: nw = (x1-ix)(y1-iy), ne = (ix-x0)(y1-iy), sw = (x1-ix)(iy-y0), se = (ix-x0)(iy-y0)
     const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
     const bool line = (g.bw == 1);
     // line: grid x == 0 on a width-1 image puts weight exactly 1 on column 0 -> 2 taps along the axis;
     // time plane: x = spatial coordinate, y = keyframe time -> 4 taps
-    const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
-    const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
+    const hr_axis_tap bxp = at.ax[HrPlaneAxes<J>::V];
+    const hr_axis_tap byp = at.t;
     const float v00 = bxp.w0 * byp.w0, v01 = bxp.w1 * byp.w0, v10 = bxp.w0 * byp.w1, v11 = bxp.w1 * byp.w1;
     // BYTE offsets of the taps' texels, unsigned 32-bit: a load is then `uniform base + zero-extended VGPR offset` and
     // needs no 64-bit address arithmetic
@@ -274,21 +286,19 @@ struct HrTaps {                 // one plane pair's taps of one sample: BYTE off
     float wb[4];
 };
 
-__device__ __forceinline__ HrTaps hr_make_taps(const HrGridPlane& g, const float (&pn)[4])
+template <int J>
+__device__ __forceinline__ HrTaps hr_make_taps(const HrGridPlane& g, const HrAxisTaps& at)
 {
     HrTaps t;
     const unsigned tex = (unsigned)g.tex * 4u;            // bytes per fp32 texel
-    const float gx = (g.ax == 0) ? pn[0] : (g.ax == 1) ? pn[1] : pn[2];
-    const float gy = (g.ay == 0) ? pn[0] : (g.ay == 1) ? pn[1] : pn[2];
-    const float gb = (g.bx == 0) ? pn[0] : (g.bx == 1) ? pn[1] : pn[2];
-    const hr_axis_tap tx = hr_make_tap(gx, g.aw);
-    const hr_axis_tap ty = hr_make_tap(gy, g.ah);
+    const hr_axis_tap tx = at.ax[HrPlaneAxes<J>::A0];
+    const hr_axis_tap ty = at.ax[HrPlaneAxes<J>::A1];
     t.wa[0] = tx.w0 * ty.w0; t.wa[1] = tx.w1 * ty.w0; t.wa[2] = tx.w0 * ty.w1; t.wa[3] = tx.w1 * ty.w1;
     t.ia[0] = (unsigned)(ty.i0 * g.aw + tx.i0) * tex; t.ia[1] = (unsigned)(ty.i0 * g.aw + tx.i1) * tex;
     t.ia[2] = (unsigned)(ty.i1 * g.aw + tx.i0) * tex; t.ia[3] = (unsigned)(ty.i1 * g.aw + tx.i1) * tex;
     const bool line = (g.bw == 1);
-    const hr_axis_tap bxp = hr_make_tap(gb, line ? g.bh : g.bw);
-    const hr_axis_tap byp = hr_make_tap(pn[3], g.bh);
+    const hr_axis_tap bxp = at.ax[HrPlaneAxes<J>::V];
+    const hr_axis_tap byp = at.t;
     if (line) {
         t.ib[0] = (unsigned)bxp.i0 * tex; t.ib[1] = (unsigned)bxp.i1 * tex; t.ib[2] = 0; t.ib[3] = 0;
         t.wb[0] = bxp.w0; t.wb[1] = bxp.w1; t.wb[2] = 0.0f; t.wb[3] = 0.0f;
@@ -348,16 +358,17 @@ __device__ __forceinline__ void hr_gather_coop_step(const HrGridPlane& g, const 
     if (j == T) { sig_feat += s; pre0 += p0; pre1 += p1; pre2 += p2; }
 }
 
-__device__ __forceinline__ void hr_gather_plane_coop(const HrGridPlane& g, const float (&pn)[4], bool valid, const float* M, int CA,
+template <int J>
+__device__ __forceinline__ void hr_gather_plane_coop(const HrGridPlane& g, const HrAxisTaps& at, bool valid, const float* M, int CA,
                                                      float& sig_feat, float& pre0, float& pre1, float& pre2)
 {
     const int ng = g.cd4 + g.ca4;
     if (ng == 0) return;
     if (ng == 1) {               // a single 16-byte group per texel: nothing to share
-        if (valid) hr_gather_plane<false, 1>(g, pn, M, CA, sig_feat, pre0, pre1, pre2);
+        if (valid) hr_gather_plane<false, 1, J>(g, at, M, CA, sig_feat, pre0, pre1, pre2);
         return;
     }
-    const HrTaps mine = hr_make_taps(g, pn);
+    const HrTaps mine = hr_make_taps<J>(g, at);
     if (ng == 2) {
         hr_gather_coop_step<2, 0>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
         hr_gather_coop_step<2, 1>(g, mine, valid, M, CA, sig_feat, pre0, pre1, pre2);
@@ -511,8 +522,14 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
             pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
         }
         const float* M = s_M + rib * 3 * CA;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) hr_gather_plane_coop(a.planes[j], pn, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        HrAxisTaps at;
+        at.ax[0] = hr_make_tap(pn[0], cfg.grid[0]);
+        at.ax[1] = hr_make_tap(pn[1], cfg.grid[1]);
+        at.ax[2] = hr_make_tap(pn[2], cfg.grid[2]);
+        at.t = hr_make_tap(pn[3], cfg.video ? cfg.num_keyframes : 2);
+        hr_gather_plane_coop<0>(a.planes[0], at, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_plane_coop<1>(a.planes[1], at, valid, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_plane_coop<2>(a.planes[2], at, valid, M, CA, sig_feat, pre0, pre1, pre2);
     } else if (valid) {
         float pn[4];
         pn[0] = hr_normalize_coord(cfg, p[0], 0);
@@ -520,8 +537,14 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
         pn[2] = hr_normalize_coord(cfg, p[2], 2);
         pn[3] = cfg.video ? hr_normalize_time(cfg, base_t) : 0.0f;
         const float* M = s_M + rib * 3 * CA;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) hr_gather_plane<HALF, 1>(a.planes[j], pn, M, CA, sig_feat, pre0, pre1, pre2);
+        HrAxisTaps at;
+        at.ax[0] = hr_make_tap(pn[0], cfg.grid[0]);
+        at.ax[1] = hr_make_tap(pn[1], cfg.grid[1]);
+        at.ax[2] = hr_make_tap(pn[2], cfg.grid[2]);
+        at.t = hr_make_tap(pn[3], cfg.video ? cfg.num_keyframes : 2);
+        hr_gather_plane<HALF, 1, 0>(a.planes[0], at, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_plane<HALF, 1, 1>(a.planes[1], at, M, CA, sig_feat, pre0, pre1, pre2);
+        hr_gather_plane<HALF, 1, 2>(a.planes[2], at, M, CA, sig_feat, pre0, pre1, pre2);
     }
 
     // ---- density -> alpha -> transmittance -> weight (raw2alpha, tensorf_utils.py:242-253)
