@@ -73,4 +73,15 @@ void hm_normalize(const hr_config* c, const float* p, int n, float* out)
 
 float hm_normalize_time(const hr_config* c, float t) { return hr_normalize_time(*c, t); }
 
+// contraction of points / inverse contraction of distances (nlf/contract.py)
+void hm_contract_points(const hr_config* c, const float* p, int n, float* out)
+{
+    for (int i = 0; i < n; ++i) hr_contract_point(*c, p[3 * i], p[3 * i + 1], p[3 * i + 2], out + 3 * i);
+}
+
+void hm_inverse_contract_distance(const hr_config* c, const float* d, int n, float* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = hr_inverse_contract_distance(*c, d[i]);
+}
+
 }  // extern "C"

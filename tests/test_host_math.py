@@ -96,3 +96,44 @@ def test_taps_sh_density_normalize(hm):
     sh = np.zeros((64, 9), np.float32)
     hm.hm_sh(fp(np.ascontiguousarray(d)), 64, fp(sh))
     assert np.max(np.abs(sh - eval_sh_bases_deg2(d))) <= 1e-6
+
+
+def test_contraction_properties(hm):
+    """Size-independent properties of the mip-NeRF-360 contraction (nlf/contract.py:113-192) as the kernels compute it:
+    points land strictly inside radius 2 and keep their direction, the inner ball is only rescaled, and
+    inverse_contract_distance undoes contract_distance on the anchors' range."""
+    from hyperreel_amd import config as Cfg
+    cfg, ds = Cfg.model_config('donerf_sphere'), Cfg.dataset_scalars('donerf')
+    hc = plan.compile_config(cfg, ds, [8, 8, 8])
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((4000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    r = np.exp(rng.uniform(np.log(1e-3), np.log(1e6), (4000, 1))).astype(np.float32)
+    p = np.ascontiguousarray(d * r)
+    q = np.zeros_like(p)
+    hm.hm_contract_points(C.byref(hc), fp(p), p.shape[0], fp(q))
+    qn = np.linalg.norm(q, axis=-1)
+    # radius r1 maps to exactly 2; beyond the end radius the linear-in-disparity shell overshoots, bounded by r -> inf
+    contract = plan._MipNerf(cfg.embedding.embeddings.ray_intersect_0.intersect.contract, ds)
+    r0, r1 = float(contract.r0), float(contract.r1)
+    assert np.all(np.isfinite(q))
+    assert np.all(qn[r[:, 0] <= r1] <= 2.0 + 1e-6)
+    assert np.all(qn <= 2.0 + r0 / (r1 - r0) + 1e-5)
+    cosang = np.sum(q * d, -1) / np.maximum(qn, 1e-30)
+    assert np.min(cosang) > 1.0 - 1e-5                                   # direction preserved
+    inner = r[:, 0] < hc.c_r0 * 0.999
+    assert np.allclose(q[inner], p[inner] / np.float32(hc.c_r0), rtol=1e-6, atol=0)
+    order = np.argsort(r[:, 0])
+    assert np.all(np.diff(qn[order]) >= -1e-6)                           # monotone in the radius
+    # distances: contract (host, plan._MipNerf) then inverse-contract (kernel arithmetic)
+    d1 = float(contract.d1)                                              # beyond it inverse_contract clamps (contract.py:147)
+    dist = np.exp(rng.uniform(np.log(1e-2), np.log(0.98 * d1), 2000)).astype(np.float32)
+    cd = np.asarray([contract.contract_distance(v) for v in dist], np.float32)
+    back = np.zeros_like(cd)
+    hm.hm_inverse_contract_distance(C.byref(hc), fp(cd), cd.size, fp(back))
+    assert np.max(np.abs(back - dist) / dist) < 2e-4                     # the outer shell compresses: ~1/d^2 conditioning
+    assert np.all(np.abs(cd) <= 2.0)
+    far = np.full(8, 1e4, np.float32)                                    # past the end distance: saturates at d1
+    cf = np.asarray([contract.contract_distance(v) for v in far], np.float32)
+    hm.hm_inverse_contract_distance(C.byref(hc), fp(cf), cf.size, fp(far))
+    assert np.allclose(far, d1, rtol=1e-5)
