@@ -497,3 +497,29 @@ def test_f16x2_mode_stays_inside_the_bar(fns, case):
     g, fn = fns(case, 'f16x2')
     err = np.abs(render_np(fn, g.rays)['rgb'] - g.rgb).max()
     assert err <= RGB_TOL, f'{case}: {err:.3e}'
+
+
+@pytest.mark.parametrize('model', ['donerf_sphere', 'neural_3d_z_plane'])
+def test_full_frame_compositing_invariants(model):
+    """Whole 800x800 frames at the shipped grid size, properties that need no oracle: the sorted distances of a ray
+    ascend (masked samples are exactly 0 and come first), compositing weights are in [0,1] and sum to at most 1,
+    sigma >= 0, and the colour is the weighted sum bounded by sum(w) * max possible colour."""
+    from gpu_common import make_render_fn
+    cfg, ds = C.model_config(model), C.dataset_scalars(model)
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    rays = torch.from_numpy(scenes.benchmark_rays(model, 800, 800, frame=7)).cuda()
+    fn = make_render_fn(cfg, ds, sd)
+    Z = int(cfg.embedding.embeddings.ray_prediction_0.z_channels)
+    for lo in range(0, rays.shape[0], 160000):                    # (B, Z) diagnostics in slices
+        out = fn.model.render(rays[lo:lo + 160000], want=('distances', 'render_weights', 'sigma'))
+        d, w, sg = out['distances'], out['render_weights'], out['sigma']
+        assert d.shape[1] == Z and torch.isfinite(d).all() and torch.isfinite(w).all()
+        assert (sg >= 0).all()
+        assert (w >= 0).all() and (w <= 1.0 + 1e-6).all()
+        assert float(w.sum(-1).max()) <= 1.0 + 1e-5
+        assert (d >= 0).all()
+        # the reference sorts the pre-contraction distances; the contraction is monotone, so the final ones ascend too
+        assert (d[:, 1:] >= d[:, :-1] - 1e-6).all()
+        zero = d == 0
+        assert (zero[:, 1:] <= zero[:, :-1]).all()                # zeros form a prefix
+        assert (w[zero] == 0).all()                               # a masked sample has no density (distances > 0 test)
