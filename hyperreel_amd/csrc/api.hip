@@ -306,9 +306,9 @@ static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
         for (int j = 0; j < 3; ++j) ca += 4 * (size_t)((c.n_app[j] + 3) / 4);
         const size_t lds = 4 * (rpb * rows_per_ray(c) * (nq * 4 + 4) + rpb * 3 * ca + 256);
         if (lds > 160 * 1024) {
-            delete m;
-            return fail(HR_E_INVALID, "z_channels %d x %d head columns need %zu bytes of LDS per workgroup (160 KiB available)",
-                        c.z_channels, m->p_live, lds);
+            const int z = c.z_channels, pl = m->p_live;
+            hr_model_destroy(m);                      // also releases the device configuration
+            return fail(HR_E_INVALID, "z_channels %d x %d head columns need %zu bytes of LDS per workgroup (160 KiB available)", z, pl, lds);
         }
     }
     char name[64];
