@@ -141,3 +141,30 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert 'error text:' in r.stdout
+
+
+def test_cascade_creation_contract():
+    """hr_model_create_cascade validates the pair before touching the device: usable without a GPU."""
+    import ctypes as CT
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import Golden
+    from hyperreel_amd import lib
+    L = lib.load()
+    g = Golden('sweep/technicolor_cascaded')
+    coarse, fine = plan.compile_cascade(g.cfg, g.dataset, g.grid)
+    assert fine.casc_in_z == coarse.z_channels == 8 and fine.z_channels == 32 and fine.casc_row_dim == 7
+    h = CT.c_void_p()
+    # a cascade's fine config is refused by the single-level constructor
+    assert L.hr_model_create(CT.byref(fine), CT.byref(h)) == -1 and b'hr_model_create_cascade' in L.hr_last_error()
+    bad = plan.hr_config.from_buffer_copy(fine)
+    bad.casc_in_z = 4
+    assert L.hr_model_create_cascade(CT.byref(coarse), CT.byref(bad), CT.byref(h)) == -1
+    assert b'casc_in_z' in L.hr_last_error()
+    bad = plan.hr_config.from_buffer_copy(fine)
+    bad.ray_dim = 6
+    assert L.hr_model_create_cascade(CT.byref(coarse), CT.byref(bad), CT.byref(h)) == -1
+    rc = L.hr_model_create_cascade(CT.byref(coarse), CT.byref(fine), CT.byref(h))
+    assert rc in (0, -3)                                   # created (GPU present) or "no HIP device"
+    if rc == 0:
+        L.hr_model_destroy(h)
