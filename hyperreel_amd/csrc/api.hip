@@ -755,6 +755,15 @@ int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel,
     return HR_OK;
 }
 
+int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t w, float* dst_dev, int32_t h2, int32_t w2, void* stream)
+{
+    if (channels < 0 || h < 1 || w < 1 || h2 < 1 || w2 < 1) return fail(HR_E_INVALID, "bad plane shape");
+    if (channels > 0 && (!src_dev || !dst_dev)) return fail(HR_E_INVALID, "null plane");
+    hr_launch_upsample_plane(src_dev, channels, h, w, dst_dev, h2, w2, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream)
 {
     int rc = check_render(m, rays_dev, n_rays, rays_dev);

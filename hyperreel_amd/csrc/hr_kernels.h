@@ -104,6 +104,7 @@ struct HrColMap {
 void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z, int P, int P_live, int nq, int rows_per_ray,
                            const HrColMap& map,
                            hipStream_t stream);
+void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst, int H2, int W2, hipStream_t stream);
 void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 
 #endif

@@ -86,6 +86,39 @@ void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pi
     hipLaunchKernelGGL(hr_generate_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cam, ray_dim, first_pixel, n_pixels, rays);
 }
 
+// upsample_bilinear2d with align_corners=True, ATen's arithmetic (UpSample.h area_pixel_compute_scale / _source_index,
+// UpSampleBilinear2d): scale = (in - 1) / (out - 1) in fp32 (0 when out == 1), src = scale * dst_index,
+// i0 = (int)src, i1 = i0 + (i0 < in - 1), l1 = src - i0, l0 = 1 - l1,
+// out = l0h * (l0w * v00 + l1w * v01) + l1h * (l0w * v10 + l1w * v11).
+__global__ void hr_upsample_plane_kernel(const float* __restrict__ src, int C, int H, int W, float* __restrict__ dst, int H2, int W2)
+{
+    const float sh = (H2 > 1) ? (float)(H - 1) / (float)(H2 - 1) : 0.0f;
+    const float sw = (W2 > 1) ? (float)(W - 1) / (float)(W2 - 1) : 0.0f;
+    const int64_t n = (int64_t)C * H2 * W2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x2 = (int)(i % W2);
+        const int y2 = (int)((i / W2) % H2);
+        const int c = (int)(i / ((int64_t)W2 * H2));
+        const float fy = sh * (float)y2, fx = sw * (float)x2;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
+        const float l1h = fy - (float)y0, l0h = 1.0f - l1h;
+        const float l1w = fx - (float)x0, l0w = 1.0f - l1w;
+        const float* p = src + ((int64_t)c * H + y0) * W + x0;
+        const float v00 = p[0], v01 = p[xp], v10 = p[(int64_t)yp * W], v11 = p[(int64_t)yp * W + xp];
+        dst[i] = l0h * (l0w * v00 + l1w * v01) + l1h * (l0w * v10 + l1w * v11);
+    }
+}
+
+void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst, int H2, int W2, hipStream_t stream)
+{
+    const int64_t n = (int64_t)C * H2 * W2;
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(hr_upsample_plane_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, C, H, W, dst, H2, W2);
+}
+
 void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream)
 {
     const int64_t n = (int64_t)C * H * W;

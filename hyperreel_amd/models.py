@@ -149,6 +149,47 @@ class HostTensorVM(nn.Module):
     def set_iter(self, i):
         self.cur_iter = i
 
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """TensorVMSplit.upsample_volume_grid (nlf/nets/tensorf_base.py:1152-1188) /
+        TensorVMKeyframeTime.upsample_volume_grid (nlf/nets/tensorf_dynamic.py:395-441): every plane and line is
+        resized bilinearly (align_corners=True) to the new grid by hr_upsample_plane; planes of a video net whose density
+        plane has no components are re-created as zeros, as in the reference.  Parameters must live on the HIP device."""
+        import ctypes as C
+        L = _lib.load()
+        N = [int(v) for v in res_target]
+
+        def resize(p, h2, w2):
+            src = p.data.contiguous().float()
+            if src.device.type != 'cuda':
+                raise RuntimeError('upsample_volume_grid runs on the HIP device; there is no CPU path')
+            _, c, h, w = src.shape
+            dst = torch.empty((1, c, h2, w2), dtype=torch.float32, device=src.device)
+            with torch.cuda.device(src.device):
+                _lib.check(L.hr_upsample_plane(C.c_void_p(src.data_ptr()), c, h, w, C.c_void_p(dst.data_ptr()), h2, w2,
+                                               C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)), 'hr_upsample_plane')
+            return nn.Parameter(dst)
+
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            if self.video:
+                t0 = MAT_MODE_TIME[i][0]
+                empty = self.density_plane_space[i].shape[1] == 0
+                for space, time in ((self.app_plane_space, self.app_plane_time), (self.density_plane_space, self.density_plane_time)):
+                    if empty:
+                        space[i] = nn.Parameter(space[i].data.new_zeros(1, space[i].shape[1], N[m1], N[m0]))
+                        time[i] = nn.Parameter(time[i].data.new_zeros(1, time[i].shape[1], self.num_keyframes, N[t0]))
+                    else:
+                        space[i] = resize(space[i], N[m1], N[m0])
+                        time[i] = resize(time[i], self.num_keyframes, N[t0])
+            else:
+                for plane, line in ((self.app_plane, self.app_line), (self.density_plane, self.density_line)):
+                    if plane[i].shape[1] > 0:
+                        plane[i] = resize(plane[i], N[m1], N[m0])
+                    if line[i].shape[1] > 0:
+                        line[i] = resize(line[i], N[VEC_MODE[i]], 1)
+        self.gridSize = torch.tensor(N, dtype=torch.long, device=self.gridSize.device)
+
 
 class HostColorModel(nn.Module):
     def __init__(self, net_cfg, grid_size, num_keyframes):
@@ -186,6 +227,12 @@ class HipLightfieldModel(nn.Module):
         self._native_key = None
         # fail on configurations outside the supported path now, not at the first render
         self._compile(grid)
+
+    def upsample_volume_grid(self, res_target):
+        """Grows the feature grids like the reference's training loop does (nlf/__init__.py upsampling hooks ->
+        color_model.net.upsample_volume_grid); the native model is rebuilt for the new size at the next render."""
+        self.color_model.net.upsample_volume_grid(res_target)
+        self._native_key = None
 
     def _compile(self, grid):
         """-> (coarse hr_config or None, hr_config of the level that renders)."""

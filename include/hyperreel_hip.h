@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 9
+#define HR_ABI_VERSION 10
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -266,6 +266,12 @@ int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel,
 /* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
  * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
  * must not exceed the reserved chunk size. */
+/* Grid management: F.interpolate(plane, size=(h2, w2), mode='bilinear', align_corners=True) of one
+ * (1, C, H, W) float32 plane or line, as TensorVMSplit.up_sampling_VM / TensorVMKeyframeTime.up_sampling_VM apply it
+ * when the reference grows its grids (nlf/nets/tensorf_base.py:1152-1176, tensorf_dynamic.py:395-427).  Both buffers
+ * are device memory in the reference layout; no model is involved. */
+int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t w, float* dst_dev, int32_t h2, int32_t w2, void* stream);
+
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream);
 int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 

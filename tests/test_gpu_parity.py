@@ -523,3 +523,30 @@ def test_full_frame_compositing_invariants(model):
         zero = d == 0
         assert (zero[:, 1:] <= zero[:, :-1]).all()                # zeros form a prefix
         assert (w[zero] == 0).all()                               # a masked sample has no density (distances > 0 test)
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'immersive_sphere_small'])
+def test_upsample_volume_grid_matches_interpolate(fns, case):
+    """hr_upsample_plane == F.interpolate(mode='bilinear', align_corners=True) on every plane and line, and the model
+    renders at the new size like a reference model whose grids were grown by torch (tensorf_base.py:1152-1188)."""
+    import torch.nn.functional as F
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    net = fn.model.color_model.net
+    old = {k: v.detach().cpu().clone() for k, v in net.named_parameters() if 'plane' in k or 'line' in k}
+    target = [57, 49, 41]
+    fn.model.upsample_volume_grid(target)
+    assert fn.model.grid_size == target
+    new_sd = dict(g.state_dict)
+    for k, v in old.items():
+        got = dict(net.named_parameters())[k].detach().cpu()
+        ref = F.interpolate(v, size=tuple(got.shape[2:]), mode='bilinear', align_corners=True)
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + 1), k
+        new_sd['model.color_model.net.' + k] = ref.numpy()
+    new_sd['model.color_model.net.gridSize'] = np.asarray(target, np.int64)
+    out = render_np(fn, g.rays)['rgb']
+    ref_rgb = HyperReelOracle(g.cfg, g.dataset, new_sd).render(g.rays)['rgb']
+    assert linf(out, ref_rgb) <= RGB_TOL
