@@ -1,0 +1,546 @@
+// Training path of the sample stage: forward WITHOUT the eval-mode clamp and the reverse-mode derivative
+// of everything between the MLP's raw output and the pixel colour -- head activations, ray/primitive intersection,
+// near/far mask, per-ray sort, contraction, flow / point offsets, VM feature gather, density, alpha compositing,
+// colour decode and per-sample colour scale/shift.  It is what torch.autograd derives for the reference when
+// INRSystem.training_step calls manual_backward (nlf/__init__.py:634-709) on
+//   Intersect.forward (nlf/intersect/base.py:142-259), AdvectPointsEmbedding / PointOffsetEmbedding
+//   (nlf/embedding/point.py:780-831, :371-396), TensorVMNoSample.forward (nlf/nets/tensorf_no_sample.py:128-280),
+//   TensorVMKeyframeTime.forward (nlf/nets/tensorf_dynamic.py:645-839), raw2alpha (utils/tensorf_utils.py:242-253)
+// with F.grid_sample(align_corners=True, bilinear, zeros) differentiated as ATen's grid_sampler_2d_backward does
+// (values: weighted scatter-add into the 4 taps; coordinates: +-tap values, taps outside the image skipped).
+//
+// Written as one sequential per-ray function over the packed grids so that the same source is compiled for the host by
+// the CPU test-suite (tests/host_math) and checked there against torch.autograd on the CPU restatement of the reference;
+// the device wraps it in one thread per ray (train_kernel.hip).  Gradients of shared parameters are accumulated with
+// HR_ATOMIC_ADD (hardware fp32 atomics on the device, plain adds in the single-threaded host build).
+#ifndef HR_TRAIN_H
+#define HR_TRAIN_H
+
+#include "hr_grid.h"
+#include "hr_math.h"
+
+#if defined(__HIPCC__)
+#define HR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#else
+#define HR_ATOMIC_ADD(p, v) (*(p) += (v))
+#endif
+
+#define HR_TRAIN_MAX_CA 64      // padded appearance slots the per-ray decode matrix holds
+
+struct HrTrainArgs {
+    const hr_config* cfg_dev;   // the caller's configuration (no head-column pruning: `head` is the user's layout)
+    const float* rays;          // (n, ray_dim)
+    const float* head;          // (n, Z * P) raw output of the last Linear, row-major
+    int64_t n_rays;
+    float* rgb;                 // (n, 3) forward result, not clamped (tensorf_no_sample.py:246 clamps in eval only); may be NULL
+    const float* d_rgb;         // (n, 3) dL/d rgb; NULL: forward only
+    float* d_head;              // (n, Z * P) dL/d head, written
+    HrGridPlane planes[3];      // packed parameter values (fp32 texels)
+    float* g_a[3];              // packed gradient accumulators, same texel layout as planes[j].a / .b
+    float* g_b[3];
+    const float* basis;         // (app_dim, n_basis_cols)
+    float* d_basis;             // accumulated
+    int n_basis_cols;
+    int ca_total;
+    int white_bg;               // this step's background decision: white_bg or (training and rand < 0.5), :236
+};
+
+// d/dx of hr_apply_act
+HR_FN float hr_act_grad(const hr_act& a, float x)
+{
+    const float u = x * a.inner + a.shift;
+    float d = 1.0f;
+    if (a.type == HR_ACT_SIGMOID) {
+        const float s = 1.0f / (1.0f + expf(-u));
+        d = s * (1.0f - s);
+    } else if (a.type == HR_ACT_TANH) {
+        const float t = tanhf(u);
+        d = 1.0f - t * t;
+    }
+    return d * a.inner * a.outer;
+}
+
+// d/dx of outer(inner(x)) for the two stacked activations the embeddings apply (head activation, then the stage's own)
+HR_FN float hr_act2_grad(const hr_act& outer, const hr_act& inner, float x)
+{
+    return hr_act_grad(outer, hr_apply_act(inner, x)) * hr_act_grad(inner, x);
+}
+
+// d hr_density / d feature  (relu: 0 at 0 like torch; |.|: sign; softplus with threshold 20)
+HR_FN float hr_density_grad(const hr_config& c, float f)
+{
+    if (c.density_act == HR_DENSITY_RELU) return (f > 0.0f) ? 1.0f : 0.0f;
+    if (c.density_act == HR_DENSITY_RELU_ABS) return hr_sign(f);
+    const float z = f + c.density_shift;
+    return (z > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-z));
+}
+
+// d hr_inverse_contract_distance / d distance
+HR_FN float hr_inverse_contract_distance_grad(const hr_config& c, float distance)
+{
+    if (c.contract_type == HR_CONTRACT_AFFINE) return c.c_aff_fac;
+    if (distance < -2.0f || distance > 2.0f) return 0.0f;           // clamp
+    if (fabsf(distance) < 1.0f) return c.c_d0;
+    const float inv = (2.0f - fabsf(distance)) / c.c_d_scale + c.c_d_inv_end;
+    return c.c_d0 / (inv * inv * c.c_d_scale);
+}
+
+// Transposed Jacobian of hr_contract_point applied to dq
+HR_FN void hr_contract_point_bwd(const hr_config& c, float px, float py, float pz, const float* dq, float* dp)
+{
+    if (c.contract_type == HR_CONTRACT_AFFINE) {
+        dp[0] = dq[0] / c.c_aff_size[0]; dp[1] = dq[1] / c.c_aff_size[1]; dp[2] = dq[2] / c.c_aff_size[2];
+        return;
+    }
+    const float x = px / c.c_r0, y = py / c.c_r0, z = pz / c.c_r0;
+    const float n = sqrtf(x * x + y * y + z * z);
+    if (n < 1.0f) {
+        dp[0] = dq[0] / c.c_r0; dp[1] = dq[1] / c.c_r0; dp[2] = dq[2] / c.c_r0;
+        return;
+    }
+    // q = (x / n) * s(n), s = 2 - (1/n - r_inv_end) * r_scale, s' = r_scale / n^2
+    const float s = 2.0f - (1.0f / n - c.c_r_inv_end) * c.c_r_scale;
+    const float sp = c.c_r_scale / (n * n);
+    const float ux = x / n, uy = y / n, uz = z / n;
+    const float ud = ux * dq[0] + uy * dq[1] + uz * dq[2];
+    const float k = s / n;
+    dp[0] = (k * (dq[0] - ux * ud) + sp * ux * ud) / c.c_r0;
+    dp[1] = (k * (dq[1] - uy * ud) + sp * uy * ud) / c.c_r0;
+    dp[2] = (k * (dq[2] - uz * ud) + sp * uz * ud) / c.c_r0;
+}
+
+// d hr_quadratic_t / d radius  (everything else of the quadratic is a function of the ray only)
+HR_FN float hr_quadratic_t_grad_radius(float oo, float dd, float od, float radius)
+{
+    const float a = dd, b = 2.0f * od, cc = oo - radius * radius;
+    float disc = b * b - 4.0f * a * cc;
+    if (disc <= 0.0f) return 0.0f;                    // clamped to 0 and t replaced by the constant 0
+    const float sq = sqrtf(disc + 1e-8f);
+    const float t2 = (-b - sq) / (2.0f * a);
+    // d disc / d radius = 8 a r; d t1 = +(1 / (2 sq)) / (2 a) d disc, d t2 = -(...)
+    const float g = 2.0f * radius / sq;
+    return ((t2 < 0.0f) || (radius < 0.0f)) ? g : -g;
+}
+
+// Which models the training path differentiates.  Returns NULL when supported, else the reason.
+HR_FN const char* hr_train_unsupported(const hr_config& c)
+{
+    if (c.casc_in_z != 0) return "point_prediction cascades";
+    if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";
+    if (c.color_table_views > 0) return "color_transform tables";
+    if (c.f_color_scale_global.offset >= 0) return "color_scale_global";
+    if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) return "sphere_new / cylinder_new intersections";
+    if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) return "deformable_voxel_grid";
+    if ((c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) && c.origin_scale != 0.0f) return "origin_scale_factor != 0";
+    return nullptr;
+}
+
+// Backward of hr_sample_distance for the sample of ORIGINAL index k: dt = dL/d(distance after the mask).
+// Adds to the z_vals channel and the intersect-sigma entry of dhk (the P gradients of sample k's head values).
+HR_FN void hr_sample_distance_bwd(const hr_config& c, const float* hk, int k, const float* ro, const float* rd, float dt, float* dhk)
+{
+    if (dt == 0.0f) return;
+    if (!c.isect_mask_off) {
+        const float dist = hr_sample_distance(c, hk, k, ro, rd);     // 0 when masked (near > 0 in every shipped dataset)
+        if (dist == 0.0f) return;
+    }
+    float sigma = 0.0f;
+    if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
+    const float one_m = 1.0f - sigma;
+    int ch = 0;
+    float scale = c.z_scale;
+    float dzp;                                   // dL / d processed z (or radius)
+    if (c.isect_type == HR_ISECT_Z_PLANE) {
+        const float dd = (fabsf(rd[2]) < 1e-5f) ? 1e12f : rd[2];
+        dzp = dt / dd;
+    } else if (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) {
+        ch = 3;
+        const float sx = c.origin_initial[0], sy = c.origin_initial[1], sz = c.origin_initial[2];
+        const float radius = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
+        const float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;
+        const float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
+        if (c.isect_type == HR_ISECT_SPHERE)
+            dzp = dt * hr_quadratic_t_grad_radius(ox * ox + oy * oy + oz * oz, dx * dx + dy * dy + dz * dz, ox * dx + oy * dy + oz * dz, radius);
+        else
+            dzp = dt * hr_quadratic_t_grad_radius(ox * ox + oz * oz, dx * dx + dz * dz, ox * dx + oz * dz, radius);
+    } else if (c.isect_type == HR_ISECT_VOXEL_GRID) {
+        const int axis = k % 3;
+        scale = c.voxel_scale[axis];
+        const float d = (axis == 0) ? rd[0] : (axis == 1) ? rd[1] : rd[2];
+        const float dd = (fabsf(d) < 1e-5f) ? 1e12f : d;
+        dzp = dt / dd;
+        if (c.isect_outward) dzp = dzp * hr_sign(d);
+    } else {                                     // euclidean_distance_unified: dist = z + f(ray)
+        dzp = dt;
+    }
+    // processed z = icd(zval * scale + anchor);  zval = act_z(act_f(h)) * (1 - sigma)
+    const float h = hk[c.f_z_vals.offset + ch];
+    const float zact = hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, h));
+    const float x = zact * one_m * scale + c.samples[k];
+    float dx_ = dzp;
+    if (c.contract_samples) dx_ = dx_ * hr_inverse_contract_distance_grad(c, x);
+    const float dzval = dx_ * scale;
+    dhk[c.f_z_vals.offset + ch] += dzval * one_m * hr_act2_grad(c.z_act, c.f_z_vals.act, h);
+    if (c.f_isect_sigma.offset >= 0)
+        dhk[c.f_isect_sigma.offset] += -(dzval * zact) * hr_act_grad(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
+}
+
+// Backward of hr_sample_point for the sample of sorted rank k: dp = dL/d point, ddist = dL/d (final distance).
+// Adds the flow / offset / offset-sigma gradients to dhk and returns dL/d (sorted pre-contraction distance).
+HR_FN float hr_sample_point_bwd(const hr_config& c, const float* hk, float dist_sorted, const float* ro, const float* rd,
+                                const float* oc, float time_offset, const float* dp, float ddist, float* dhk)
+{
+    const bool zero = (dist_sorted == 0.0f);
+    const float px = ro[0] + rd[0] * dist_sorted, py = ro[1] + rd[1] * dist_sorted, pz = ro[2] + rd[2] * dist_sorted;
+    float dP[3] = {dp[0], dp[1], dp[2]};
+    float dt = 0.0f;
+    if (c.contract_type != HR_CONTRACT_IDENTITY) {
+        float q[3];
+        hr_contract_point(c, px, py, pz, q);
+        const float ex = q[0] - oc[0], ey = q[1] - oc[1], ez = q[2] - oc[2];
+        const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
+        float dq[3] = {dp[0], dp[1], dp[2]};
+        if (!zero && dist > 0.0f) {                                  // torch.norm backward; base.py:246 cuts it where dist == 0
+            dq[0] += ddist * ex / dist; dq[1] += ddist * ey / dist; dq[2] += ddist * ez / dist;
+        }
+        hr_contract_point_bwd(c, px, py, pz, dq, dP);
+    } else if (!zero) {
+        dt = ddist;
+    }
+    dt += rd[0] * dP[0] + rd[1] * dP[1] + rd[2] * dP[2];
+    if (c.advect && c.use_spatial_flow) {
+        const hr_head_field& f = c.f_spatial_flow;
+        for (int i = 0; i < 3; ++i) dhk[f.offset + i] += dp[i] * time_offset * hr_act2_grad(c.flow_act, f.act, hk[f.offset + i]);
+    }
+    if (c.point_offset) {
+        float sig = 0.0f;
+        if (c.f_offset_sigma.offset >= 0) sig = hr_apply_act(c.f_offset_sigma.act, hk[c.f_offset_sigma.offset]);
+        const float om = 1.0f - sig;
+        const hr_head_field& f = c.f_point_offset;
+        float dsig = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            const float h = hk[f.offset + i];
+            dhk[f.offset + i] += dp[i] * om * hr_act2_grad(c.offset_act, f.act, h);
+            dsig -= dp[i] * hr_apply_act(c.offset_act, hr_apply_act(f.act, h));
+        }
+        if (c.f_offset_sigma.offset >= 0) dhk[c.f_offset_sigma.offset] += dsig * hr_act_grad(c.f_offset_sigma.act, hk[c.f_offset_sigma.offset]);
+    }
+    return dt;
+}
+
+// One axis of grid_sample with what its backward needs: d w0 / d ix and d w1 / d ix (taps outside the image contribute
+// nothing, grid_sampler_2d_backward) and d ix / d g = (n - 1) / 2.
+struct hr_axis_tap_g {
+    hr_axis_tap t;
+    float s0, s1;
+    float mult;
+};
+HR_FN hr_axis_tap_g hr_make_tap_g(float g, int n)
+{
+    hr_axis_tap_g r;
+    r.t = hr_make_tap(g, n);
+    const float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+    const int i0 = (int)floorf(ix), i1 = i0 + 1;
+    r.s0 = (i0 >= 0 && i0 < n) ? -1.0f : 0.0f;
+    r.s1 = (i1 >= 0 && i1 < n) ? 1.0f : 0.0f;
+    r.mult = 0.5f * (float)(n - 1);
+    return r;
+}
+
+// Texel indices and weights of one plane pair for a sample (the arithmetic of hr_gather_plane in sample_kernel.hip)
+struct HrTrainTaps {
+    int ia[4]; float wa[4];     // plane: nw, ne, sw, se
+    int ib[4]; float wb[4];     // line: low, high / time plane: 4
+    int nb;                     // 2 or 4
+};
+HR_FN HrTrainTaps hr_train_taps(const HrGridPlane& g, const hr_axis_tap& tx, const hr_axis_tap& ty, const hr_axis_tap& bx, const hr_axis_tap& by)
+{
+    HrTrainTaps t;
+    t.wa[0] = tx.w0 * ty.w0; t.wa[1] = tx.w1 * ty.w0; t.wa[2] = tx.w0 * ty.w1; t.wa[3] = tx.w1 * ty.w1;
+    t.ia[0] = ty.i0 * g.aw + tx.i0; t.ia[1] = ty.i0 * g.aw + tx.i1; t.ia[2] = ty.i1 * g.aw + tx.i0; t.ia[3] = ty.i1 * g.aw + tx.i1;
+    if (g.bw == 1) {
+        t.nb = 2;
+        t.ib[0] = bx.i0; t.ib[1] = bx.i1; t.ib[2] = 0; t.ib[3] = 0;
+        t.wb[0] = bx.w0; t.wb[1] = bx.w1; t.wb[2] = 0.0f; t.wb[3] = 0.0f;
+    } else {
+        t.nb = 4;
+        t.ib[0] = by.i0 * g.bw + bx.i0; t.ib[1] = by.i0 * g.bw + bx.i1; t.ib[2] = by.i1 * g.bw + bx.i0; t.ib[3] = by.i1 * g.bw + bx.i1;
+        t.wb[0] = bx.w0 * by.w0; t.wb[1] = bx.w1 * by.w0; t.wb[2] = bx.w0 * by.w1; t.wb[3] = bx.w1 * by.w1;
+    }
+    return t;
+}
+
+HR_FN int hr_plane_a0(int j) { return (j == 2) ? 1 : 0; }     // MAT_MODE[j][0]
+HR_FN int hr_plane_a1(int j) { return (j == 0) ? 1 : 2; }     // MAT_MODE[j][1]
+HR_FN int hr_plane_v(int j) { return 2 - j; }                 // VEC_MODE[j] == MAT_MODE_TIME[j][0]
+
+// Forward gather of one sample over the three plane pairs: density feature and the three decoded pre-activations.
+HR_FN void hr_train_gather(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, int CA,
+                           float* sig_feat, float* pre)
+{
+    float s = 0.0f, p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+    for (int j = 0; j < 3; ++j) {
+        const HrGridPlane& g = a.planes[j];
+        const int ng = g.cd4 + g.ca4;
+        if (ng == 0) continue;
+        const HrTrainTaps t = hr_train_taps(g, ax[hr_plane_a0(j)].t, ax[hr_plane_a1(j)].t, ax[hr_plane_v(j)].t, at.t);
+        const float* A = reinterpret_cast<const float*>(g.a);
+        const float* B = reinterpret_cast<const float*>(g.b);
+        for (int ch = 0; ch < 4 * ng; ++ch) {
+            float pa = A[(size_t)t.ia[0] * g.tex + ch] * t.wa[0];
+            pa = fmaf(A[(size_t)t.ia[1] * g.tex + ch], t.wa[1], pa);
+            pa = fmaf(A[(size_t)t.ia[2] * g.tex + ch], t.wa[2], pa);
+            pa = fmaf(A[(size_t)t.ia[3] * g.tex + ch], t.wa[3], pa);
+            float pb = B[(size_t)t.ib[0] * g.tex + ch] * t.wb[0];
+            pb = fmaf(B[(size_t)t.ib[1] * g.tex + ch], t.wb[1], pb);
+            if (t.nb == 4) {
+                pb = fmaf(B[(size_t)t.ib[2] * g.tex + ch], t.wb[2], pb);
+                pb = fmaf(B[(size_t)t.ib[3] * g.tex + ch], t.wb[3], pb);
+            }
+            const float f = pa * pb;
+            if (ch < 4 * g.cd4) {
+                s = s + f;
+            } else {
+                const int slot = g.app_off + (ch - 4 * g.cd4);
+                p0 = fmaf(M[slot], f, p0); p1 = fmaf(M[CA + slot], f, p1); p2 = fmaf(M[2 * CA + slot], f, p2);
+            }
+        }
+    }
+    *sig_feat = s; pre[0] = p0; pre[1] = p1; pre[2] = p2;
+}
+
+// Backward gather of one sample: dfeat = dL/d density feature, dpre = dL/d decoded pre-activations.  Scatter-adds the
+// texel gradients, accumulates the ray's decode-matrix gradient dM and returns dL/d normalised coordinates in dpn[3].
+HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, float* dM, int CA,
+                               float dfeat, const float* dpre, float* dpn)
+{
+    dpn[0] = 0.0f; dpn[1] = 0.0f; dpn[2] = 0.0f;
+    for (int j = 0; j < 3; ++j) {
+        const HrGridPlane& g = a.planes[j];
+        const int ng = g.cd4 + g.ca4;
+        if (ng == 0) continue;
+        const hr_axis_tap_g& gx = ax[hr_plane_a0(j)];
+        const hr_axis_tap_g& gy = ax[hr_plane_a1(j)];
+        const hr_axis_tap_g& gv = ax[hr_plane_v(j)];
+        const HrTrainTaps t = hr_train_taps(g, gx.t, gy.t, gv.t, at.t);
+        const float* A = reinterpret_cast<const float*>(g.a);
+        const float* B = reinterpret_cast<const float*>(g.b);
+        float* GA = a.g_a[j];
+        float* GB = a.g_b[j];
+        float dx = 0.0f, dy = 0.0f, dv = 0.0f;
+        for (int ch = 0; ch < 4 * ng; ++ch) {
+            const float a00 = A[(size_t)t.ia[0] * g.tex + ch], a01 = A[(size_t)t.ia[1] * g.tex + ch];
+            const float a10 = A[(size_t)t.ia[2] * g.tex + ch], a11 = A[(size_t)t.ia[3] * g.tex + ch];
+            const float b0 = B[(size_t)t.ib[0] * g.tex + ch], b1 = B[(size_t)t.ib[1] * g.tex + ch];
+            float b2 = 0.0f, b3 = 0.0f;
+            if (t.nb == 4) { b2 = B[(size_t)t.ib[2] * g.tex + ch]; b3 = B[(size_t)t.ib[3] * g.tex + ch]; }
+            const float pa = fmaf(a11, t.wa[3], fmaf(a10, t.wa[2], fmaf(a01, t.wa[1], a00 * t.wa[0])));
+            const float pb = fmaf(b3, t.wb[3], fmaf(b2, t.wb[2], fmaf(b1, t.wb[1], b0 * t.wb[0])));
+            const float f = pa * pb;
+            float u;
+            if (ch < 4 * g.cd4) {
+                u = dfeat;
+            } else {
+                const int slot = g.app_off + (ch - 4 * g.cd4);
+                u = dpre[0] * M[slot] + dpre[1] * M[CA + slot] + dpre[2] * M[2 * CA + slot];
+                dM[slot] += dpre[0] * f; dM[CA + slot] += dpre[1] * f; dM[2 * CA + slot] += dpre[2] * f;
+            }
+            if (u == 0.0f) continue;
+            const float dpa = u * pb, dpb = u * pa;
+            for (int i = 0; i < 4; ++i)
+                if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
+            for (int i = 0; i < t.nb; ++i)
+                if (t.wb[i] != 0.0f) HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+            // coordinates: d(weights)/d ix = (s0, s1) per axis
+            dx += dpa * ((a00 * gx.s0 + a01 * gx.s1) * gy.t.w0 + (a10 * gx.s0 + a11 * gx.s1) * gy.t.w1);
+            dy += dpa * ((a00 * gx.t.w0 + a01 * gx.t.w1) * gy.s0 + (a10 * gx.t.w0 + a11 * gx.t.w1) * gy.s1);
+            if (t.nb == 2) dv += dpb * (b0 * gv.s0 + b1 * gv.s1);
+            else dv += dpb * ((b0 * gv.s0 + b1 * gv.s1) * at.t.w0 + (b2 * gv.s0 + b3 * gv.s1) * at.t.w1);
+        }
+        dpn[hr_plane_a0(j)] += dx * gx.mult;
+        dpn[hr_plane_a1(j)] += dy * gy.mult;
+        dpn[hr_plane_v(j)] += dv * gv.mult;
+    }
+}
+
+// Coefficient of appearance slot `pos` in colour channel c's decode (the M matrix of sample_kernel.hip) and the
+// basis_mat column it comes from (-1 for a padding slot)
+HR_FN int hr_train_slot_col(const HrTrainArgs& a, int pos)
+{
+    int col = -1;
+    for (int j = 0; j < 3; ++j) {
+        const int rel = pos - a.planes[j].app_off;
+        if (rel >= 0 && rel < a.planes[j].app_real && a.planes[j].ca4 > 0) col = a.planes[j].app_real_off + rel;
+    }
+    return col;
+}
+
+// One ray of a training step.  ZP: compile-time bound on z_channels.
+template <int ZP>
+HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
+{
+    const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total, nat = a.n_basis_cols;
+    const float* r = a.rays + ray * c.ray_dim;
+    const float* head = a.head + ray * (int64_t)Z * P;
+    const float ro[3] = {r[0] - c.isect_origin[0], r[1] - c.isect_origin[1], r[2] - c.isect_origin[2]};
+    const float rd[3] = {r[3], r[4], r[5]};
+    const float t_ray = r[c.ray_dim - 1];
+
+    // decode matrix of the ray (RGB: basis_mat rows; SH: basis rows folded with the view direction's SH basis)
+    float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c.shading == HR_SHADING_SH) hr_sh_deg2(rd[0], rd[1], rd[2], sh);
+    float M[3 * HR_TRAIN_MAX_CA], dM[3 * HR_TRAIN_MAX_CA];
+    for (int cc = 0; cc < 3; ++cc)
+        for (int pos = 0; pos < CA; ++pos) {
+            const int col = hr_train_slot_col(a, pos);
+            float v = 0.0f;
+            if (col >= 0) {
+                if (c.shading == HR_SHADING_SH)
+                    for (int j = 0; j < 9; ++j) v = fmaf(sh[j], a.basis[(cc * 9 + j) * nat + col], v);
+                else
+                    v = a.basis[cc * nat + col];
+            }
+            M[cc * CA + pos] = v;
+            dM[cc * CA + pos] = 0.0f;
+        }
+
+    // ---- forward
+    float ds[ZP];                 // sorted pre-contraction distances
+    int src[ZP];                  // original sample index of each rank
+    for (int k = 0; k < Z; ++k) { ds[k] = hr_sample_distance(c, head + k * P, k, ro, rd); src[k] = k; }
+    if (c.sort)
+        for (int i = 1; i < Z; ++i) {             // stable insertion sort (sort_z, intersect_utils.py:12-16)
+            const float v = ds[i];
+            const int s = src[i];
+            int j = i - 1;
+            while (j >= 0 && ds[j] > v) { ds[j + 1] = ds[j]; src[j + 1] = src[j]; --j; }
+            ds[j + 1] = v; src[j + 1] = s;
+        }
+    float oc[3] = {0.f, 0.f, 0.f};
+    if (c.contract_type != HR_CONTRACT_IDENTITY) hr_contract_point(c, ro[0], ro[1], ro[2], oc);
+    float base_t = 0.0f, time_off = 0.0f;
+    if (c.advect) { base_t = hr_base_time(c, t_ray); time_off = t_ray - base_t; }
+    const hr_axis_tap_g tap_t = hr_make_tap_g(c.video ? hr_normalize_time(c, base_t) : 0.0f, c.video ? c.num_keyframes : 2);
+
+    float dc[ZP], feat[ZP], pre[ZP][3], trans[ZP], alpha[ZP], wgt[ZP];
+    bool valid[ZP];
+    for (int k = 0; k < Z; ++k) {
+        float p[3];
+        hr_sample_point(c, head + k * P, ds[k], ro, rd, oc, time_off, p, &dc[k]);
+        valid[k] = hr_sample_valid(c, p, dc[k]);
+        feat[k] = 0.0f; pre[k][0] = 0.0f; pre[k][1] = 0.0f; pre[k][2] = 0.0f;
+        if (valid[k]) {
+            hr_axis_tap_g ax[3];
+            for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
+            hr_train_gather(a, ax, tap_t, M, CA, &feat[k], pre[k]);
+        }
+    }
+    float T = 1.0f, acc_w = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int k = 0; k < Z; ++k) {
+        const float delta = (k == Z - 1) ? 1e10f : (dc[k + 1] - dc[k]);
+        const float sigma = valid[k] ? hr_density(c, feat[k]) : 0.0f;
+        alpha[k] = 1.0f - expf(-sigma * (delta * c.distance_scale));
+        trans[k] = T;
+        wgt[k] = alpha[k] * T;
+        T = T * ((1.0f - alpha[k]) + 1e-10f);
+        float rr[3] = {0.f, 0.f, 0.f};
+        if (wgt[k] > c.weight_thresh)
+            for (int i = 0; i < 3; ++i)
+                rr[i] = (c.shading == HR_SHADING_SH) ? fmaxf(pre[k][i] + 0.5f, 0.0f) : 1.0f / (1.0f + expf(-pre[k][i]));
+        if (c.f_color_scale.offset >= 0) {
+            const float* hk = head + k * P;
+            for (int i = 0; i < 3; ++i)
+                rr[i] = rr[i] * (hr_apply_act(c.f_color_scale.act, hk[c.f_color_scale.offset + i]) + 1.0f) +
+                        hr_apply_act(c.f_color_shift.act, hk[c.f_color_shift.offset + i]);
+        }
+        c0 += wgt[k] * rr[0]; c1 += wgt[k] * rr[1]; c2 += wgt[k] * rr[2];
+        acc_w += wgt[k];
+    }
+    if (a.white_bg) { const float bg = 1.0f - acc_w; c0 += bg; c1 += bg; c2 += bg; }
+    if (a.rgb) { a.rgb[ray * 3 + 0] = c0; a.rgb[ray * 3 + 1] = c1; a.rgb[ray * 3 + 2] = c2; }
+    if (!a.d_rgb) return;
+
+    // ---- backward
+    const float g[3] = {a.d_rgb[ray * 3 + 0], a.d_rgb[ray * 3 + 1], a.d_rgb[ray * 3 + 2]};
+    const float gsum = a.white_bg ? (g[0] + g[1] + g[2]) : 0.0f;
+    float* dhead = a.d_head + ray * (int64_t)Z * P;
+    for (int i = 0; i < Z * P; ++i) dhead[i] = 0.0f;
+    float ddc[ZP];                // dL / d final distance
+    float dfeat[ZP];
+    for (int k = 0; k < Z; ++k) ddc[k] = 0.0f;
+    float S = 0.0f;               // sum over later samples of dw_j * w_j
+    for (int k = Z - 1; k >= 0; --k) {
+        // colour of the sample again (cheap) for dw = g . rgb_k - [white] sum(g)
+        float rr[3] = {0.f, 0.f, 0.f}, raw[3] = {0.f, 0.f, 0.f};
+        const bool app = wgt[k] > c.weight_thresh;
+        if (app)
+            for (int i = 0; i < 3; ++i)
+                raw[i] = (c.shading == HR_SHADING_SH) ? fmaxf(pre[k][i] + 0.5f, 0.0f) : 1.0f / (1.0f + expf(-pre[k][i]));
+        const float* hk = head + k * P;
+        float* dhk = dhead + k * P;
+        float dpre[3];
+        for (int i = 0; i < 3; ++i) {
+            float sc = 1.0f;
+            rr[i] = raw[i];
+            const float dr = wgt[k] * g[i];
+            if (c.f_color_scale.offset >= 0) {
+                const float hs = hk[c.f_color_scale.offset + i], hh = hk[c.f_color_shift.offset + i];
+                sc = hr_apply_act(c.f_color_scale.act, hs) + 1.0f;
+                rr[i] = raw[i] * sc + hr_apply_act(c.f_color_shift.act, hh);
+                dhk[c.f_color_scale.offset + i] += dr * raw[i] * hr_act_grad(c.f_color_scale.act, hs);
+                dhk[c.f_color_shift.offset + i] += dr * hr_act_grad(c.f_color_shift.act, hh);
+            }
+            const float draw = dr * sc;
+            if (!app) dpre[i] = 0.0f;
+            else if (c.shading == HR_SHADING_SH) dpre[i] = (pre[k][i] + 0.5f > 0.0f) ? draw : 0.0f;
+            else dpre[i] = draw * raw[i] * (1.0f - raw[i]);
+        }
+        pre[k][0] = dpre[0]; pre[k][1] = dpre[1]; pre[k][2] = dpre[2];          // reuse the storage for dL/d pre
+        const float dw = (g[0] * rr[0] + g[1] * rr[1] + g[2] * rr[2]) - gsum;
+        const float inc = (1.0f - alpha[k]) + 1e-10f;
+        const float dalpha = dw * trans[k] - S / inc;
+        S += dw * wgt[k];
+        // alpha = 1 - exp(-sigma * delta * scale)
+        const float delta = (k == Z - 1) ? 1e10f : (dc[k + 1] - dc[k]);
+        const float sigma = valid[k] ? hr_density(c, feat[k]) : 0.0f;
+        const float e = 1.0f - alpha[k];
+        const float dsigma = dalpha * e * (delta * c.distance_scale);
+        dfeat[k] = valid[k] ? dsigma * hr_density_grad(c, feat[k]) : 0.0f;
+        if (k < Z - 1) {
+            const float ddelta = dalpha * e * sigma * c.distance_scale;
+            ddc[k + 1] += ddelta;
+            ddc[k] -= ddelta;
+        }
+    }
+    float dts[ZP];                // dL / d pre-sort distance, by ORIGINAL sample index
+    for (int k = 0; k < Z; ++k) {
+        float dp[3] = {0.f, 0.f, 0.f};
+        if (valid[k] && (dfeat[k] != 0.0f || pre[k][0] != 0.0f || pre[k][1] != 0.0f || pre[k][2] != 0.0f)) {
+            float p[3], dcc;
+            hr_sample_point(c, head + k * P, ds[k], ro, rd, oc, time_off, p, &dcc);
+            hr_axis_tap_g ax[3];
+            for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
+            float dpn[3];
+            hr_train_gather_bwd(a, ax, tap_t, M, dM, CA, dfeat[k], pre[k], dpn);
+            for (int i = 0; i < 3; ++i) dp[i] = dpn[i] * c.inv_size[i];
+        }
+        dts[src[k]] = hr_sample_point_bwd(c, head + k * P, ds[k], ro, rd, oc, time_off, dp, ddc[k], dhead + k * P);
+    }
+    for (int k = 0; k < Z; ++k) hr_sample_distance_bwd(c, head + k * P, k, ro, rd, dts[k], dhead + k * P);
+
+    // basis_mat gradient of this ray
+    for (int cc = 0; cc < 3; ++cc)
+        for (int pos = 0; pos < CA; ++pos) {
+            const float v = dM[cc * CA + pos];
+            if (v == 0.0f) continue;
+            const int col = hr_train_slot_col(a, pos);
+            if (col < 0) continue;
+            if (c.shading == HR_SHADING_SH) {
+                for (int j = 0; j < 9; ++j) HR_ATOMIC_ADD(a.d_basis + (cc * 9 + j) * nat + col, sh[j] * v);
+            } else {
+                HR_ATOMIC_ADD(a.d_basis + cc * nat + col, v);
+            }
+        }
+}
+
+#endif  // HR_TRAIN_H

@@ -108,11 +108,13 @@ class TorchPort:
             cols.append(y)
         return torch.cat(cols, -1)
 
-    def embed(self, rays):
+    def embed(self, rays, head=None):
+        """`head`: optional (B, Z*P) raw MLP output to use instead of running the MLP (gradient checks of the training
+        path differentiate with respect to it)."""
         o = self.o
         B, Z = rays.shape[0], o.Z
         x = {}
-        h = self._mlp(self._param_pe(rays))
+        h = self._mlp(self._param_pe(rays)) if head is None else head
         h = h.view(B, Z, -1)
         off = 0
         for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
@@ -196,7 +198,9 @@ class TorchPort:
             out.append(pa * pb)
         return torch.cat(out, 0)
 
-    def color(self, x):
+    def color(self, x, train=False, white_bg=None):
+        """train=True: no eval-mode clamp (tensorf_no_sample.py:246); white_bg overrides the configured background
+        (the reference draws it at random per training step, :236)."""
         o = self.o
         pts = x['points']
         B, Z = pts.shape[:2]
@@ -229,9 +233,9 @@ class TorchPort:
         if 'color_scale' in x:
             rgb = rgb * (x['color_scale'] + 1.0) + x['color_shift']
         out = (weight[..., None] * rgb).sum(-2)
-        if o.white_bg:
+        if o.white_bg if white_bg is None else white_bg:
             out = out + (1.0 - weight.sum(-1)[:, None])
-        return out.clamp(0, 1)
+        return out if train else out.clamp(0, 1)
 
     @torch.no_grad()
     def render(self, rays, chunk=16384):

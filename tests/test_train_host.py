@@ -1,0 +1,143 @@
+"""CPU check of the training path's per-ray forward + backward (hyperreel_amd/csrc/hr_train.h, compiled for the host)
+against torch.autograd on the CPU restatement of the reference (oracle/torch_port.py): gradients with respect to the
+raw MLP output, every plane / line and basis_mat, on the five benchmark families.  The device build wraps the same
+source in one thread per ray; the `-m gpu` test checks that build against this one's expectations."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden
+from hyperreel_amd import plan
+from torch_port import TorchPort
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'host_math', 'hr_train_host.cpp')
+OUT = os.path.join(HERE, 'host_math', '_build', 'libhr_train_host.so')
+CSRC = os.path.join(HERE, '..', 'hyperreel_amd', 'csrc')
+
+FP = C.POINTER(C.c_float)
+MAT, VEC = [(0, 1), (0, 2), (1, 2)], [2, 1, 0]
+
+
+class GridPlane(C.Structure):          # mirrors HrGridPlane (hyperreel_amd/csrc/hr_grid.h)
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p)] + [(k, C.c_int) for k in
+                ('tex', 'aw', 'ah', 'bw', 'bh', 'cd4', 'ca4', 'ax', 'ay', 'bx', 'app_off', 'app_real', 'app_real_off')]
+
+
+@pytest.fixture(scope='module')
+def ht():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ('hr_train.h', 'hr_math.h', 'hr_grid.h')] + [os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', OUT, SRC], check=True)
+    lib = C.CDLL(OUT)
+    lib.ht_unsupported.restype = C.c_char_p
+    assert lib.ht_sizeof_plane() == C.sizeof(GridPlane)
+    return lib
+
+
+def pack_grids(port, video):
+    """Texel layout of hr_model_finalize (api.hip): [H][W][4*cd4 density | 4*ca4 appearance] per plane pair."""
+    planes, packed, app_off, real_off = (GridPlane * 3)(), [], 0, 0
+    for j in range(3):
+        da, db, aa, ab = [t.detach().numpy()[0] for t in (port.d_a[j], port.d_b[j], port.a_a[j], port.a_b[j])]
+        nd, na = da.shape[0], aa.shape[0]
+        if video and nd == 0:
+            na = 0
+        g = planes[j]
+        g.cd4, g.ca4 = (nd + 3) // 4, (na + 3) // 4
+        g.ah, g.aw = da.shape[1], da.shape[2]
+        g.bh, g.bw = db.shape[1], db.shape[2]
+        g.app_off, g.app_real, g.app_real_off = app_off, na, real_off
+        app_off += 4 * g.ca4
+        real_off += na
+        g.tex = 4 * (g.cd4 + g.ca4)
+        pa = np.zeros((g.ah, g.aw, max(g.tex, 1)), np.float32)
+        pb = np.zeros((g.bh, g.bw, max(g.tex, 1)), np.float32)
+        pa[..., :nd] = da.transpose(1, 2, 0)
+        pb[..., :nd] = db.transpose(1, 2, 0)
+        pa[..., 4 * g.cd4:4 * g.cd4 + na] = aa[:na].transpose(1, 2, 0)
+        pb[..., 4 * g.cd4:4 * g.cd4 + na] = ab[:na].transpose(1, 2, 0)
+        g.a, g.b = pa.ctypes.data, pb.ctypes.data
+        packed.append((pa, pb, nd, na, 4 * g.cd4))
+    return planes, packed, app_off
+
+
+CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small']
+
+
+@pytest.mark.parametrize('white', [0, 1])
+@pytest.mark.parametrize('case', CASES)
+def test_backward_matches_autograd(ht, case, white):
+    g = Golden(case)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    assert ht.ht_unsupported(C.byref(hc)) is None
+    port = TorchPort(g.cfg, g.dataset, g.state_dict)
+    n = min(192, g.rays.shape[0])
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:n], np.float32))
+    grids = [t for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp]
+    for t in grids + [port.basis]:
+        t.requires_grad_(True)
+    with torch.no_grad():
+        head0 = port._mlp(port._param_pe(rays))
+    head = head0.clone().requires_grad_(True)
+    rgb_ref = port.color(port.embed(rays, head=head), train=True, white_bg=bool(white))
+    gen = torch.Generator().manual_seed(3)
+    G = torch.randn(rgb_ref.shape, generator=gen)
+    (rgb_ref * G).sum().backward()
+
+    planes, packed, ca_total = pack_grids(port, port.o.video)
+    gbuf = [(np.zeros_like(pa), np.zeros_like(pb)) for pa, pb, *_ in packed]
+    g_a = (FP * 3)(*[b[0].ctypes.data_as(FP) for b in gbuf])
+    g_b = (FP * 3)(*[b[1].ctypes.data_as(FP) for b in gbuf])
+    basis = np.ascontiguousarray(port.basis.detach().numpy())
+    d_basis = np.zeros_like(basis)
+    rgb = np.zeros((n, 3), np.float32)
+    d_head = np.zeros_like(head0.numpy())
+    hnp, rnp, Gnp = np.ascontiguousarray(head0.numpy()), np.ascontiguousarray(rays.numpy()), np.ascontiguousarray(G.numpy())
+    f = lambda a: a.ctypes.data_as(FP)
+    rc = ht.ht_train(C.byref(hc), f(rnp), f(hnp), C.c_longlong(n), f(Gnp), f(rgb), f(d_head), planes, g_a, g_b, f(basis), f(d_basis),
+                     basis.shape[1], ca_total, white)
+    assert rc == 0
+
+    def close(got, ref, what):
+        ref = np.asarray(ref, np.float64)
+        scale = np.abs(ref).max()
+        err = np.abs(np.asarray(got, np.float64) - ref).max()
+        assert scale > 0, f'{what}: reference gradient is identically zero'
+        assert err <= 2e-4 * scale + 1e-7, f'{what}: |err| {err:.3e} vs scale {scale:.3e}'
+
+    assert np.abs(rgb - rgb_ref.detach().numpy()).max() <= 1e-5
+    close(d_head, head.grad.numpy(), 'd head')
+    P, ref_h = hc.preds_per_z, head.grad.numpy().reshape(n, hc.z_channels, -1)
+    live = 0
+    for col in range(P):                                   # every head column on its own scale (offsets, sigma, colour ...)
+        if np.abs(ref_h[..., col]).max() > 0:
+            close(d_head.reshape(ref_h.shape)[..., col], ref_h[..., col], f'd head column {col}')
+            live += 1
+        else:
+            assert not d_head.reshape(ref_h.shape)[..., col].any()
+    assert live >= 5
+    close(d_basis, port.basis.grad.numpy(), 'd basis_mat')
+    for j, (pa, pb, nd, na, aoff) in enumerate(packed):
+        ga, gb = gbuf[j]
+        for name, got, ref_t, cnt, off in (('density a', ga, port.d_a[j], nd, 0), ('density b', gb, port.d_b[j], nd, 0),
+                                           ('app a', ga, port.a_a[j], na, aoff), ('app b', gb, port.a_b[j], na, aoff)):
+            if cnt == 0:
+                continue
+            ref = ref_t.grad.numpy()[0][:cnt].transpose(1, 2, 0)
+            close(got[..., off:off + cnt], ref, f'{name} {j}')
+        pad = np.ones(ga.shape[-1], bool)
+        pad[:nd] = False
+        pad[aoff:aoff + na] = False
+        assert not ga[..., pad].any() and not gb[..., pad].any()          # padding channels stay untouched
+
+
+def test_unsupported_models_are_named(ht):
+    g = Golden('sweep/technicolor_cascaded')
+    _, fine = plan.compile_cascade(g.cfg, g.dataset, g.grid)
+    assert b'cascade' in ht.ht_unsupported(C.byref(fine))
