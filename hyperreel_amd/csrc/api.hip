@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "hr_kernels.h"
+#include "hr_train.h"
 
 namespace {
 
@@ -73,6 +74,10 @@ struct hr_model {
     hr_model* coarse = nullptr;
     bool is_coarse = false;
     float* rows = nullptr;   // input rows of the point MLP for one chunk: (chunk * casc_in_z, casc_row_dim)
+    // training path (hr_train_*): the caller's configuration on the device and packed gradient accumulators
+    hr_config* ucfg_dev = nullptr;
+    float* grad_a[3] = {};
+    float* grad_b[3] = {};
 };
 
 namespace {
@@ -764,6 +769,136 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
     return HR_OK;
 }
 
+// ---------------------------------------------------------------- training path
+static int check_train(hr_model* m, const float* rays, int64_t n)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    if (m->is_coarse || m->coarse) return fail(HR_E_INVALID, "training path: point_prediction cascades are not differentiated");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called (or tensors changed since)");
+    if (const char* why = hr_train_unsupported(m->cfg)) return fail(HR_E_INVALID, "training path: %s not differentiated", why);
+    if (m->ca_total > HR_TRAIN_MAX_CA) return fail(HR_E_INVALID, "training path: more than %d appearance components", HR_TRAIN_MAX_CA);
+    if (n < 0 || (n > 0 && !rays)) return fail(HR_E_INVALID, "bad ray buffer");
+    if (!m->ucfg_dev) {
+        HR_HIP(hipMalloc((void**)&m->ucfg_dev, sizeof(hr_config)));
+        HR_HIP(hipMemcpy(m->ucfg_dev, &m->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
+    }
+    return HR_OK;
+}
+
+// the four reference-layout tensors of plane pair j: {density a, app a, density b, app b} with their channel counts
+struct TrainPlaneIO {
+    float* p[4];
+    int ch[4];
+};
+static TrainPlaneIO train_plane_io(const hr_model* m, const hr_train_tensors* t, int j)
+{
+    const hr_config& c = m->cfg;
+    int nd = c.n_den[j], na = c.n_app[j];
+    if (c.video && nd == 0) na = 0;
+    return TrainPlaneIO{{t->density_a[j], t->app_a[j], t->density_b[j], t->app_b[j]}, {nd, na, nd, na}};
+}
+
+int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float* feats_dev, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (n_rays > 0 && !feats_dev) return fail(HR_E_INVALID, "null feature buffer");
+    hr_launch_features(m->ucfg_dev, rays_dev, n_rays, feats_dev, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays, const float* head, int64_t n, int white_bg)
+{
+    a = HrTrainArgs();
+    a.cfg_dev = m->ucfg_dev;
+    a.rays = rays;
+    a.head = head;
+    a.n_rays = n;
+    for (int j = 0; j < 3; ++j) { a.planes[j] = m->planes[j]; a.g_a[j] = m->grad_a[j]; a.g_b[j] = m->grad_b[j]; }
+    a.basis = m->basis;
+    a.n_basis_cols = m->n_basis_cols;
+    a.ca_total = m->ca_total;
+    a.white_bg = white_bg ? 1 : 0;
+}
+
+int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                     int32_t white_bg, float* rgb_dev, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (n_rays > 0 && (!head_dev || !rgb_dev)) return fail(HR_E_INVALID, "null head / rgb buffer");
+    hipStream_t st = (hipStream_t)stream;
+    if (params) {                     // this step's parameter values -> the kernels' texel layout (no allocation, no sync)
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& g = m->planes[j];
+            if (g.tex == 0) continue;
+            const TrainPlaneIO io = train_plane_io(m, params, j);
+            for (int t = 0; t < 4; ++t) {
+                if (io.ch[t] == 0) continue;
+                if (!io.p[t]) return fail(HR_E_INVALID, "hr_train_forward: params tensor of plane pair %d is NULL", j);
+                const bool is_a = t < 2;
+                hr_launch_interleave(io.p[t], is_a ? m->grid_a[j] : m->grid_b[j], 0, io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
+                                     (t & 1) ? 4 * g.cd4 : 0, st);
+            }
+        }
+        const size_t bytes = m->raw["basis_mat.weight"].bytes;
+        if (bytes > 0) {
+            if (!params->basis) return fail(HR_E_INVALID, "hr_train_forward: params->basis is NULL");
+            HR_HIP(hipMemcpyAsync(m->basis, params->basis, bytes, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HrTrainArgs a;
+    fill_train_args(m, a, rays_dev, head_dev, n_rays, white_bg);
+    a.rgb = rgb_dev;
+    hr_launch_train(m->cfg, a, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
+                      int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (!grads) return fail(HR_E_INVALID, "null grads");
+    if (n_rays > 0 && (!head_dev || !d_rgb_dev || !d_head_dev)) return fail(HR_E_INVALID, "null head / d_rgb / d_head buffer");
+    hipStream_t st = (hipStream_t)stream;
+    for (int j = 0; j < 3; ++j) {     // packed accumulators, allocated once, cleared per step on the stream
+        const HrGridPlane& g = m->planes[j];
+        if (g.tex == 0) continue;
+        const size_t a_bytes = sizeof(float) * (size_t)g.aw * g.ah * g.tex, b_bytes = sizeof(float) * (size_t)g.bw * g.bh * g.tex;
+        if (!m->grad_a[j]) HR_HIP(hipMalloc((void**)&m->grad_a[j], a_bytes));
+        if (!m->grad_b[j]) HR_HIP(hipMalloc((void**)&m->grad_b[j], b_bytes));
+        HR_HIP(hipMemsetAsync(m->grad_a[j], 0, a_bytes, st));
+        HR_HIP(hipMemsetAsync(m->grad_b[j], 0, b_bytes, st));
+    }
+    const size_t basis_bytes = m->raw["basis_mat.weight"].bytes;
+    // basis_mat's gradient needs no re-layout: accumulate in the caller's buffer (or a scratch nobody reads)
+    float* d_basis = grads->basis;
+    if (!d_basis) return fail(HR_E_INVALID, "hr_train_backward: grads->basis is NULL");
+    if (basis_bytes > 0) HR_HIP(hipMemsetAsync(d_basis, 0, basis_bytes, st));
+    HrTrainArgs a;
+    fill_train_args(m, a, rays_dev, head_dev, n_rays, white_bg);
+    a.d_rgb = d_rgb_dev;
+    a.d_head = d_head_dev;
+    a.d_basis = d_basis;
+    hr_launch_train(m->cfg, a, st);
+    for (int j = 0; j < 3; ++j) {
+        const HrGridPlane& g = m->planes[j];
+        if (g.tex == 0) continue;
+        const TrainPlaneIO io = train_plane_io(m, grads, j);
+        for (int t = 0; t < 4; ++t) {
+            if (io.ch[t] == 0 || !io.p[t]) continue;
+            const bool is_a = t < 2;
+            hr_launch_deinterleave(is_a ? m->grad_a[j] : m->grad_b[j], io.p[t], io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
+                                   (t & 1) ? 4 * g.cd4 : 0, st);
+        }
+    }
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream)
 {
     int rc = check_render(m, rays_dev, n_rays, rays_dev);
@@ -826,6 +961,8 @@ void hr_model_destroy(hr_model* m)
     free_dev(m->head);
     free_dev(m->rows);
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
+    if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
+    for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); }
     hr_model_destroy(m->coarse);
     delete m;
 }

@@ -89,6 +89,13 @@ void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z,
                            const HrColMap& map,
                            hipStream_t stream);
 void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst, int H2, int W2, hipStream_t stream);
+void hr_launch_deinterleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream);
+
+
+// ---------------------------------------------------------------- training path (train_kernel.hip, hr_train.h)
+struct HrTrainArgs;
+void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream);
+void hr_launch_features(const hr_config* cfg_dev, const float* rays, int64_t n, float* out, hipStream_t stream);
 
 #endif

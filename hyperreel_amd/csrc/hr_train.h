@@ -123,7 +123,12 @@ HR_FN float hr_quadratic_t_grad_radius(float oo, float dd, float od, float radiu
 }
 
 // Which models the training path differentiates.  Returns NULL when supported, else the reason.
-HR_FN const char* hr_train_unsupported(const hr_config& c)
+#if defined(__HIPCC__)
+__host__ __device__ inline
+#else
+static inline
+#endif
+const char* hr_train_unsupported(const hr_config& c)
 {
     if (c.casc_in_z != 0) return "point_prediction cascades";
     if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";

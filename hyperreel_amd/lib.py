@@ -11,7 +11,15 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
+
+
+
+class hr_train_tensors(C.Structure):
+    """Device pointers of the trainable tensors (or of their gradients), reference layouts (include/hyperreel_hip.h)."""
+    _fields_ = [('density_a', C.c_void_p * 3), ('density_b', C.c_void_p * 3), ('app_a', C.c_void_p * 3), ('app_b', C.c_void_p * 3),
+                ('basis', C.c_void_p)]
+
 
 # every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -27,6 +35,11 @@ SYMBOLS = [
     ('hr_render_fields', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(hr_fields), C.c_void_p]),
     ('hr_generate_rays', C.c_int, [C.POINTER(hr_camera), C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_upsample_plane', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('hr_train_features', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ('hr_train_forward', C.c_int, [C.c_void_p, C.POINTER(hr_train_tensors), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                   C.c_void_p]),
+    ('hr_train_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                    C.POINTER(hr_train_tensors), C.c_void_p]),
     ('hr_stage_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('hr_stage_samples', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_debug_trace_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

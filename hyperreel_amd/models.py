@@ -410,10 +410,35 @@ class HipLightfieldModel(nn.Module):
         its host round trips: pose -> rays -> rgb, all on the device and on the current stream."""
         return self.render(self.generate_rays(pose, K, width, height, time, cam_id, pixel_range))['rgb']
 
+    def forward_train(self, rays, white_bg=None):
+        """One differentiable forward of the training step (nlf/__init__.py:634-709 calls `self(coords)` in train mode):
+        rgb (B, 3) WITHOUT the eval-mode clamp, with autograd history to the MLP, the planes / lines and basis_mat.
+        white_bg: this step's background; default = the reference's draw `white_bg or rand() < 0.5` unless black_bg
+        (tensorf_no_sample.py:236).  The activation schedules are the converged ones (see set_iter)."""
+        from . import train as T
+        if self._native is None or self._native_grid != self.grid_size:
+            self.native()
+        h, hc = self._native, self._hc
+        rays = self._check_rays(rays)
+        net_cfg = self.cfg['color']['net']
+        if white_bg is None:
+            white_bg = (bool(net_cfg.get('white_bg', False)) or bool(torch.rand(()) < 0.5)) and not bool(net_cfg.get('black_bg', False))
+        types = [e['type'] for e in self.cfg['embedding']['embeddings'].values()]
+        pred = self.embedding_model.embeddings[types.index('ray_prediction')]
+        if hc.mlp_layers == 0:                                  # ZeroMLP, nlf/nets/mlp.py:14-33
+            head = torch.zeros((rays.shape[0], hc.z_channels * hc.preds_per_z), dtype=torch.float32, device=rays.device)
+        else:
+            head = T.mlp_forward(pred.net, T.ray_features(h, rays, hc.mlp_in), hc.mlp_skip_mask)
+        vm = self.color_model.net
+        return T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm))
+
     def forward(self, rays, render_kwargs=None):
-        """LightfieldModel.forward (models.py:135-138)."""
+        """LightfieldModel.forward (models.py:135-138).  In train mode with autograd enabled this is the
+        differentiable path (forward_train); otherwise the inference renderer."""
         render_kwargs = render_kwargs or {}
         fields = list(render_kwargs.get('fields', []))
+        if self.training and torch.is_grad_enabled() and not fields:
+            return {'rgb': self.forward_train(rays)}
         if not fields:
             return {'rgb': self.render(rays)['rgb']}
         return self._forward_fields(rays, render_kwargs)

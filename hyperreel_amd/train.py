@@ -1,0 +1,113 @@
+"""Training step on the HIP device.
+
+What INRSystem.training_step (nlf/__init__.py:634-709) gets from torch.autograd for the reference, split the way the
+hardware wants it:
+  * ray parameterisation + positional encoding: hr_train_features (no parameters, no gradient);
+  * the sample-prediction MLP: plain GEMMs -- torch.nn.functional.linear on the reference-named nn.Linear parameters
+    (rocBLAS forward and backward), exactly BaseMLP.forward (nlf/nets/mlp.py:159-172);
+  * everything after the MLP (head activations, intersection, sort, contraction, offsets / flow, VM gather, density,
+    compositing, colour): one hand-written HIP forward and one backward kernel behind `SampleStage`, a
+    torch.autograd.Function over the C ABI (hr_train_forward / hr_train_backward).
+Gradients arrive on the reference's own parameters (planes, lines, basis_mat, MLP weights), so the reference's optimizers,
+schedulers and regularizers apply unchanged.  There is no CPU path: the tensors must live on the HIP device.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _tensors_struct(groups, basis):
+    """groups: 4 lists of 3 tensors (density a, density b, app a, app b) -> hr_train_tensors."""
+    t = _lib.hr_train_tensors()
+    for name, grp in zip(('density_a', 'density_b', 'app_a', 'app_b'), groups):
+        arr = getattr(t, name)
+        for j in range(3):
+            arr[j] = grp[j].data_ptr() if grp[j].numel() > 0 else None
+    t.basis = basis.data_ptr() if basis.numel() > 0 else None
+    return t
+
+
+class SampleStage(torch.autograd.Function):
+    """rgb = f(head; planes, lines, basis_mat), not clamped (training mode, tensorf_no_sample.py:246).
+    Inputs after `white_bg`: basis_mat.weight, then the 12 grid tensors in the order density a[0..2], density b[0..2],
+    app a[0..2], app b[0..2] (a = plane | plane_space, b = line | plane_time)."""
+
+    @staticmethod
+    def forward(ctx, handle, rays, head, white_bg, basis, *grids):
+        L = _lib.load()
+        dev = rays.device
+        if dev.type != 'cuda' or head.device != dev:
+            raise RuntimeError('SampleStage runs on the HIP device; there is no CPU path')
+        rays, head = rays.contiguous().float(), head.contiguous().float()
+        vals = [g.detach().contiguous() for g in grids]
+        groups = [vals[0:3], vals[3:6], vals[6:9], vals[9:12]]
+        params = _tensors_struct(groups, basis.detach().contiguous())
+        rgb = torch.empty((rays.shape[0], 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_train_forward(handle, C.byref(params), _ptr(rays), _ptr(head), rays.shape[0], int(bool(white_bg)), _ptr(rgb),
+                                          _stream(dev)), 'hr_train_forward')
+        ctx.handle, ctx.white_bg = handle, int(bool(white_bg))
+        ctx.save_for_backward(rays, head, basis, *grids)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        L = _lib.load()
+        rays, head, basis, *grids = ctx.saved_tensors
+        dev = rays.device
+        d_rgb = d_rgb.contiguous().float()
+        d_head = torch.empty_like(head)
+        g_grids = [torch.zeros_like(g, memory_format=torch.contiguous_format) for g in grids]
+        g_basis = torch.zeros_like(basis, memory_format=torch.contiguous_format)
+        gt = _tensors_struct([g_grids[0:3], g_grids[3:6], g_grids[6:9], g_grids[9:12]], g_basis)
+        if g_basis.numel() == 0:
+            raise RuntimeError('basis_mat has no columns')
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_train_backward(ctx.handle, _ptr(rays), _ptr(head), _ptr(d_rgb), rays.shape[0], ctx.white_bg, _ptr(d_head),
+                                           C.byref(gt), _stream(dev)), 'hr_train_backward')
+        return (None, None, d_head, None, g_basis, *g_grids)
+
+
+def ray_features(handle, rays, mlp_in):
+    """rays (B, ray_dim) -> MLP input (B, mlp_in): RayParam + positional encoding on the device."""
+    L = _lib.load()
+    rays = rays.contiguous().float()
+    out = torch.empty((rays.shape[0], int(mlp_in)), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        _lib.check(L.hr_train_features(handle, _ptr(rays), rays.shape[0], _ptr(out), _stream(rays.device)), 'hr_train_features')
+    return out
+
+
+def mlp_forward(net, x, skip_mask):
+    """BaseMLP.forward (nlf/nets/mlp.py:159-172) on the reference-named parameters: Linear + LeakyReLU(0.01), the
+    input concatenated in front of the activations at the skip layers, no activation after the last Linear."""
+    inp = x
+    n = len(net.layers)
+    for i, layer in enumerate(net.layers):
+        lin = layer[0] if i < n - 1 else layer
+        if (skip_mask >> i) & 1:
+            x = torch.cat([inp, x], -1)
+        x = F.linear(x, lin.weight, lin.bias)
+        if i < n - 1:
+            x = F.leaky_relu(x, 0.01)
+    return x
+
+
+def grid_parameters(net):
+    """The 12 grid tensors of a HostTensorVM in SampleStage's order."""
+    if net.video:
+        groups = (net.density_plane_space, net.density_plane_time, net.app_plane_space, net.app_plane_time)
+    else:
+        groups = (net.density_plane, net.density_line, net.app_plane, net.app_line)
+    return [p for grp in groups for p in grp]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 10
+#define HR_ABI_VERSION 11
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -263,15 +263,50 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
  * with image-parallel rendering every rank generates only its own pixel range. */
 int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays_dev, void* stream);
 
-/* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
- * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
- * must not exceed the reserved chunk size. */
 /* Grid management: F.interpolate(plane, size=(h2, w2), mode='bilinear', align_corners=True) of one
  * (1, C, H, W) float32 plane or line, as TensorVMSplit.up_sampling_VM / TensorVMKeyframeTime.up_sampling_VM apply it
  * when the reference grows its grids (nlf/nets/tensorf_base.py:1152-1176, tensorf_dynamic.py:395-427).  Both buffers
  * are device memory in the reference layout; no model is involved. */
 int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t w, float* dst_dev, int32_t h2, int32_t w2, void* stream);
 
+/* ---- training path --------------------------------------------------------------------------
+ * What torch.autograd does for the reference in INRSystem.training_step (nlf/__init__.py:634-709), for the stage
+ * after the MLP: forward without the eval-mode clamp (nlf/nets/tensorf_no_sample.py:246) and the reverse-mode
+ * derivative of Intersect.forward (nlf/intersect/base.py:142-259), the point embeddings (nlf/embedding/point.py:371-396,
+ * 780-831), TensorVMNoSample / TensorVMKeyframeTime.forward (tensorf_no_sample.py:128-280, tensorf_dynamic.py:645-839)
+ * and raw2alpha (utils/tensorf_utils.py:242-253).  The MLP itself (plain GEMMs) stays with the caller's autograd:
+ * hr_train_features gives its input, `head_dev` is its raw output (n_rays, z_channels * preds_per_z) row-major in the
+ * caller's column order, and hr_train_backward returns dL/d head for it.
+ * All tensors are device memory, float32, in the reference's parameter layouts (same shapes as the hr_model_upload
+ * names): a[j] = density_plane.j | density_plane_space.j, b[j] = density_line.j | density_plane_time.j, likewise app_*.
+ * Supported: single-level models with z_plane / sphere / cylinder (origin_scale_factor 0) / voxel_grid /
+ * euclidean_distance_unified intersections and float32 grids; anything else returns HR_E_INVALID and names the feature.
+ * Activation schedules are those of the compiled configuration (the converged EaseValue / WindowedPE weights). */
+typedef struct hr_train_tensors {
+    float* density_a[3];
+    float* density_b[3];
+    float* app_a[3];
+    float* app_b[3];
+    float* basis;                        /* basis_mat.weight (app_dim, sum n_app) */
+} hr_train_tensors;
+
+/* rays (n, ray_dim) -> feats_dev (n, mlp_in): ray parameterisation + positional encoding (nlf/param.py, nlf/pe.py) */
+int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float* feats_dev, void* stream);
+
+/* rgb_dev (n, 3), not clamped.  `params`: current parameter values, re-packed into the model's texel layout on `stream`
+ * before the launch (NULL: keep what the model holds).  white_bg: this step's background decision
+ * (`white_bg or (training and rand() < 0.5)`, tensorf_no_sample.py:236). */
+int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                     int32_t white_bg, float* rgb_dev, void* stream);
+
+/* Given d_rgb_dev (n, 3) writes d_head_dev (n, z_channels * preds_per_z) and every non-NULL tensor of `grads` (overwritten,
+ * not accumulated), for the parameter values of the last hr_train_forward / hr_model_finalize. */
+int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
+                      int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream);
+
+/* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
+ * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
+ * must not exceed the reserved chunk size. */
 int hr_stage_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, void* stream);
 int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 

@@ -1,0 +1,110 @@
+"""`-m gpu`: the training step (hyperreel_amd/train.py over hr_train_forward / hr_train_backward) against torch.autograd
+on the CPU restatement of the reference -- the gradient of every trainable tensor of the path (MLP weights and biases,
+planes, lines, basis_mat), the un-clamped forward, and a few optimizer steps."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden
+from torch_port import TorchPort
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small']
+
+
+def _reference_grads(g, rays, G, white):
+    port = TorchPort(g.cfg, g.dataset, g.state_dict)
+    leaves = {}
+    for name, grp in (('d_a', port.d_a), ('d_b', port.d_b), ('a_a', port.a_a), ('a_b', port.a_b)):
+        for j, t in enumerate(grp):
+            leaves[f'{name}{j}'] = t.requires_grad_(True)
+    leaves['basis'] = port.basis.requires_grad_(True)
+    for i, (w, b) in enumerate(port.layers):
+        leaves[f'w{i}'], leaves[f'b{i}'] = w.requires_grad_(True), b.requires_grad_(True)
+    r = torch.from_numpy(rays)
+    rgb = port.color(port.embed(r), train=True, white_bg=bool(white))
+    (rgb * torch.from_numpy(G)).sum().backward()
+    return rgb.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else None) for k, v in leaves.items()}
+
+
+@pytest.mark.parametrize('white', [0, 1])
+@pytest.mark.parametrize('case', CASES)
+def test_training_gradients_match_autograd_of_the_reference_restatement(case, white):
+    from gpu_common import make_render_fn
+    from hyperreel_amd.train import grid_parameters
+    g = Golden(case)
+    n = min(192, g.rays.shape[0])
+    rays = np.ascontiguousarray(g.rays[:n], np.float32)
+    G = np.random.default_rng(3).standard_normal((n, 3)).astype(np.float32)
+    rgb_ref, ref = _reference_grads(g, rays, G, white)
+
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='fp32')
+    fn.train()
+    model = fn.model
+    rgb = model.forward_train(torch.from_numpy(rays).cuda(), white_bg=bool(white))
+    assert rgb.requires_grad
+    (rgb * torch.from_numpy(G).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert np.abs(rgb.detach().cpu().numpy() - rgb_ref).max() <= 2e-5
+
+    def close(got, want, what):
+        want = np.asarray(want, np.float64)
+        scale = np.abs(want).max()
+        assert scale > 0, what
+        err = np.abs(got.detach().cpu().numpy().astype(np.float64).reshape(want.shape) - want).max()
+        assert err <= 1e-3 * scale + 1e-7, f'{what}: |err| {err:.3e} vs scale {scale:.3e}'
+
+    vm = model.color_model.net
+    grids = grid_parameters(vm)
+    for name, p in zip([f'{k}{j}' for k in ('d_a', 'd_b', 'a_a', 'a_b') for j in range(3)], grids):
+        if p.numel() == 0:
+            continue
+        if ref[name] is None or not np.abs(ref[name]).max() > 0:      # a plane pair the video net never samples
+            assert p.grad is None or not p.grad.abs().max().item() > 0
+            continue
+        close(p.grad, ref[name], name)
+    close(vm.basis_mat.weight.grad, ref['basis'], 'basis_mat')
+    pred = [m for m in model.embedding_model.embeddings if hasattr(m, 'net')][0]
+    layers = pred.net.layers
+    for i, layer in enumerate(layers):
+        lin = layer[0] if i < len(layers) - 1 else layer
+        close(lin.weight.grad, ref[f'w{i}'], f'mlp.{i}.weight')
+        close(lin.bias.grad, ref[f'b{i}'], f'mlp.{i}.bias')
+
+
+def test_a_few_adam_steps_reduce_the_image_loss():
+    """The optimizer loop of the reference (nlf/__init__.py:690-695) over the HIP training path: parameters move, the
+    packed copies follow them, and the loss towards a fixed target image goes down."""
+    from gpu_common import make_render_fn
+    g = Golden('donerf_sphere_small')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    fn.train()
+    model = fn.model
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays, np.float32)).cuda()
+    target = torch.from_numpy(np.random.default_rng(0).uniform(0.2, 0.8, (rays.shape[0], 3)).astype(np.float32)).cuda()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = ((model.forward_train(rays, white_bg=False) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.8 * losses[0], losses
+    # the inference renderer sees the trained parameters (re-upload on the next render) and agrees with the training forward
+    fn.eval()
+    with torch.no_grad():
+        a = fn.model.render(rays)['rgb']
+        b = model.forward_train(rays, white_bg=bool(g.cfg['color']['net'].get('white_bg', False))).clamp(0, 1)
+    assert float((a - b).abs().max()) <= 1e-4
+
+
+def test_unsupported_models_raise_by_name():
+    from gpu_common import make_render_fn
+    g = Golden('sweep/technicolor_cascaded')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:64], np.float32)).cuda()
+    with pytest.raises((RuntimeError, NotImplementedError), match='cascade'):
+        fn.model.forward_train(rays, white_bg=False)
