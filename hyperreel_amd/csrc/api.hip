@@ -78,6 +78,8 @@ struct hr_model {
     hr_config* ucfg_dev = nullptr;
     float* grad_a[3] = {};
     float* grad_b[3] = {};
+    float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
+    int64_t tape_samples = 0;
 };
 
 namespace {
@@ -878,8 +880,22 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     float* d_basis = grads->basis;
     if (!d_basis) return fail(HR_E_INVALID, "hr_train_backward: grads->basis is NULL");
     if (basis_bytes > 0) HR_HIP(hipMemsetAsync(d_basis, 0, basis_bytes, st));
+    const int64_t ns = n_rays * m->cfg.z_channels;
+    if (ns > m->tape_samples) {          // grows on the first step (and if the batch grows): not in steady state
+        HR_HIP(hipStreamSynchronize(st));
+        free_dev(m->tape);
+        m->tape_samples = 0;
+        HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 8 * (size_t)ns));
+        m->tape_samples = ns;
+    }
     HrTrainArgs a;
     fill_train_args(m, a, rays_dev, head_dev, n_rays, white_bg);
+    a.tape.ds = m->tape;
+    a.tape.src = reinterpret_cast<int*>(m->tape + ns);
+    a.tape.dfeat = m->tape + 2 * ns;
+    a.tape.dpre = m->tape + 3 * ns;      // 3 planes
+    a.tape.ddc = m->tape + 6 * ns;
+    a.tape.dts = m->tape + 7 * ns;
     a.d_rgb = d_rgb_dev;
     a.d_head = d_head_dev;
     a.d_basis = d_basis;
@@ -963,6 +979,7 @@ void hr_model_destroy(hr_model* m)
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); }
+    free_dev(m->tape);
     hr_model_destroy(m->coarse);
     delete m;
 }

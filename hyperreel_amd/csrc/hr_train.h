@@ -9,10 +9,16 @@
 // with F.grid_sample(align_corners=True, bilinear, zeros) differentiated as ATen's grid_sampler_2d_backward does
 // (values: weighted scatter-add into the 4 taps; coordinates: +-tap values, taps outside the image skipped).
 //
-// Written as one sequential per-ray function over the packed grids so that the same source is compiled for the host by
-// the CPU test-suite (tests/host_math) and checked there against torch.autograd on the CPU restatement of the reference;
-// the device wraps it in one thread per ray (train_kernel.hip).  Gradients of shared parameters are accumulated with
-// HR_ATOMIC_ADD (hardware fp32 atomics on the device, plain adds in the single-threaded host build).
+// Three phases, each a plain function of one ray or one sample, so that the same source is compiled for the host by the
+// CPU test-suite (tests/host_math) and checked there against torch.autograd on the CPU restatement of the reference:
+//   A  hr_ray_train          per ray: forward, and the backward of the compositing (the only part that couples a ray's
+//                            samples); leaves per-sample upstream gradients on a small tape
+//   B  hr_sample_train_bwd   per (ray, sorted sample): feature-gather backward (texel scatter-adds, point gradient),
+//                            contraction / flow / offset backward
+//   C  hr_sample_distance_bwd  per (ray, original sample): intersection + head-activation backward
+// The device runs A with one thread per ray and B / C with one thread per sample (train_kernel.hip): 32x the threads
+// where the scatter-adds are.  Gradients of shared parameters are accumulated with HR_ATOMIC_ADD (hardware fp32
+// atomics on the device, plain adds in the single-threaded host build).
 #ifndef HR_TRAIN_H
 #define HR_TRAIN_H
 
@@ -21,11 +27,31 @@
 
 #if defined(__HIPCC__)
 #define HR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#define HR_ATOMIC_ADD_RAY(p, v) atomicAdd((p), (v))      // per-ray accumulators in LDS, shared by the ray's sample threads
+// sum of v over the `lanes` adjacent lanes that work on one sample (all of them active), returned to every one of them
+__device__ __forceinline__ float hr_lane_sum(float v, int lanes)
+{
+    for (int d = lanes >> 1; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+#define HR_LANE_SUM(v, lanes) hr_lane_sum((v), (lanes))
 #else
 #define HR_ATOMIC_ADD(p, v) (*(p) += (v))
+#define HR_ATOMIC_ADD_RAY(p, v) (*(p) += (v))
+#define HR_LANE_SUM(v, lanes) (v)
 #endif
 
 #define HR_TRAIN_MAX_CA 64      // padded appearance slots the per-ray decode matrix holds
+
+// Per-sample values handed from phase A to phases B and C, each (n_rays * Z)
+struct HrTrainTape {
+    float* ds;        // sorted pre-contraction distance of rank k
+    int* src;         // original sample index of rank k
+    float* dfeat;     // dL / d density feature
+    float* dpre;      // dL / d decoded colour pre-activation, 3 planes of n_rays * Z
+    float* ddc;       // dL / d final distance
+    float* dts;       // dL / d pre-sort distance by ORIGINAL sample index (written by phase B)
+};
 
 struct HrTrainArgs {
     const hr_config* cfg_dev;   // the caller's configuration (no head-column pruning: `head` is the user's layout)
@@ -43,6 +69,7 @@ struct HrTrainArgs {
     int n_basis_cols;
     int ca_total;
     int white_bg;               // this step's background decision: white_bg or (training and rand < 0.5), :236
+    HrTrainTape tape;
 };
 
 // d/dx of hr_apply_act
@@ -314,57 +341,70 @@ HR_FN void hr_train_gather(const HrTrainArgs& a, const hr_axis_tap_g* ax, const 
     *sig_feat = s; pre[0] = p0; pre[1] = p1; pre[2] = p2;
 }
 
-// Backward gather of one sample: dfeat = dL/d density feature, dpre = dL/d decoded pre-activations.  Scatter-adds the
-// texel gradients, accumulates the ray's decode-matrix gradient dM and returns dL/d normalised coordinates in dpn[3].
+// Backward gather of ONE CHANNEL `ch` of plane pair j for a sample: dfeat = dL/d density feature, dpre = dL/d decoded
+// pre-activations.  Scatter-adds the channel's texel gradients, adds the channel's share of the ray's decode-matrix
+// gradient to dM and accumulates dL/d (unnormalised tap coordinates) of the pair's three axes in d3 = {x, y, line axis}.
+// The device gives every channel of a texel its own lane: the 8..16 channels of a tap are then one contiguous 32..64-byte
+// run per atomic instruction, which the memory system retires 17x faster than 64 lanes on 64 different cache lines
+// (tools/atomic_ubench.hip: 331 vs 19.5 G atomics/s).
+HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrainTaps& t, const hr_axis_tap_g& gx, const hr_axis_tap_g& gy,
+                                       const hr_axis_tap_g& gv, const hr_axis_tap_g& at, int ch, const float* M, float* dM, int CA,
+                                       float dfeat, const float* dpre, float* d3)
+{
+    const HrGridPlane& g = a.planes[j];
+    const float* A = reinterpret_cast<const float*>(g.a);
+    const float* B = reinterpret_cast<const float*>(g.b);
+    const float a00 = A[(size_t)t.ia[0] * g.tex + ch], a01 = A[(size_t)t.ia[1] * g.tex + ch];
+    const float a10 = A[(size_t)t.ia[2] * g.tex + ch], a11 = A[(size_t)t.ia[3] * g.tex + ch];
+    const float b0 = B[(size_t)t.ib[0] * g.tex + ch], b1 = B[(size_t)t.ib[1] * g.tex + ch];
+    float b2 = 0.0f, b3 = 0.0f;
+    if (t.nb == 4) { b2 = B[(size_t)t.ib[2] * g.tex + ch]; b3 = B[(size_t)t.ib[3] * g.tex + ch]; }
+    const float pa = fmaf(a11, t.wa[3], fmaf(a10, t.wa[2], fmaf(a01, t.wa[1], a00 * t.wa[0])));
+    const float pb = fmaf(b3, t.wb[3], fmaf(b2, t.wb[2], fmaf(b1, t.wb[1], b0 * t.wb[0])));
+    const float f = pa * pb;
+    float u;
+    if (ch < 4 * g.cd4) {
+        u = dfeat;
+    } else {
+        const int slot = g.app_off + (ch - 4 * g.cd4);
+        u = dpre[0] * M[slot] + dpre[1] * M[CA + slot] + dpre[2] * M[2 * CA + slot];
+        HR_ATOMIC_ADD_RAY(dM + slot, dpre[0] * f); HR_ATOMIC_ADD_RAY(dM + CA + slot, dpre[1] * f); HR_ATOMIC_ADD_RAY(dM + 2 * CA + slot, dpre[2] * f);
+    }
+    if (u == 0.0f) return;
+    const float dpa = u * pb, dpb = u * pa;
+    float* GA = a.g_a[j];
+    float* GB = a.g_b[j];
+    for (int i = 0; i < 4; ++i)
+        if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
+    for (int i = 0; i < t.nb; ++i)
+        if (t.wb[i] != 0.0f) HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+    // coordinates: d(weights)/d ix = (s0, s1) per axis
+    d3[0] += dpa * ((a00 * gx.s0 + a01 * gx.s1) * gy.t.w0 + (a10 * gx.s0 + a11 * gx.s1) * gy.t.w1);
+    d3[1] += dpa * ((a00 * gx.t.w0 + a01 * gx.t.w1) * gy.s0 + (a10 * gx.t.w0 + a11 * gx.t.w1) * gy.s1);
+    if (t.nb == 2) d3[2] += dpb * (b0 * gv.s0 + b1 * gv.s1);
+    else d3[2] += dpb * ((b0 * gv.s0 + b1 * gv.s1) * at.t.w0 + (b2 * gv.s0 + b3 * gv.s1) * at.t.w1);
+}
+
+// Backward gather of one sample, channels `ch0, ch0 + stride, ...` of every plane pair: returns this caller's share of
+// dL/d normalised coordinates in dpn[3] (the host walks all channels with stride 1; on the device the 16 lanes of a
+// sample take stride 16 and add their shares up).
 HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, float* dM, int CA,
-                               float dfeat, const float* dpre, float* dpn)
+                               float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1)
 {
     dpn[0] = 0.0f; dpn[1] = 0.0f; dpn[2] = 0.0f;
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = a.planes[j];
-        const int ng = g.cd4 + g.ca4;
-        if (ng == 0) continue;
+        const int nch = 4 * (g.cd4 + g.ca4);
+        if (nch == 0) continue;
         const hr_axis_tap_g& gx = ax[hr_plane_a0(j)];
         const hr_axis_tap_g& gy = ax[hr_plane_a1(j)];
         const hr_axis_tap_g& gv = ax[hr_plane_v(j)];
         const HrTrainTaps t = hr_train_taps(g, gx.t, gy.t, gv.t, at.t);
-        const float* A = reinterpret_cast<const float*>(g.a);
-        const float* B = reinterpret_cast<const float*>(g.b);
-        float* GA = a.g_a[j];
-        float* GB = a.g_b[j];
-        float dx = 0.0f, dy = 0.0f, dv = 0.0f;
-        for (int ch = 0; ch < 4 * ng; ++ch) {
-            const float a00 = A[(size_t)t.ia[0] * g.tex + ch], a01 = A[(size_t)t.ia[1] * g.tex + ch];
-            const float a10 = A[(size_t)t.ia[2] * g.tex + ch], a11 = A[(size_t)t.ia[3] * g.tex + ch];
-            const float b0 = B[(size_t)t.ib[0] * g.tex + ch], b1 = B[(size_t)t.ib[1] * g.tex + ch];
-            float b2 = 0.0f, b3 = 0.0f;
-            if (t.nb == 4) { b2 = B[(size_t)t.ib[2] * g.tex + ch]; b3 = B[(size_t)t.ib[3] * g.tex + ch]; }
-            const float pa = fmaf(a11, t.wa[3], fmaf(a10, t.wa[2], fmaf(a01, t.wa[1], a00 * t.wa[0])));
-            const float pb = fmaf(b3, t.wb[3], fmaf(b2, t.wb[2], fmaf(b1, t.wb[1], b0 * t.wb[0])));
-            const float f = pa * pb;
-            float u;
-            if (ch < 4 * g.cd4) {
-                u = dfeat;
-            } else {
-                const int slot = g.app_off + (ch - 4 * g.cd4);
-                u = dpre[0] * M[slot] + dpre[1] * M[CA + slot] + dpre[2] * M[2 * CA + slot];
-                dM[slot] += dpre[0] * f; dM[CA + slot] += dpre[1] * f; dM[2 * CA + slot] += dpre[2] * f;
-            }
-            if (u == 0.0f) continue;
-            const float dpa = u * pb, dpb = u * pa;
-            for (int i = 0; i < 4; ++i)
-                if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
-            for (int i = 0; i < t.nb; ++i)
-                if (t.wb[i] != 0.0f) HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
-            // coordinates: d(weights)/d ix = (s0, s1) per axis
-            dx += dpa * ((a00 * gx.s0 + a01 * gx.s1) * gy.t.w0 + (a10 * gx.s0 + a11 * gx.s1) * gy.t.w1);
-            dy += dpa * ((a00 * gx.t.w0 + a01 * gx.t.w1) * gy.s0 + (a10 * gx.t.w0 + a11 * gx.t.w1) * gy.s1);
-            if (t.nb == 2) dv += dpb * (b0 * gv.s0 + b1 * gv.s1);
-            else dv += dpb * ((b0 * gv.s0 + b1 * gv.s1) * at.t.w0 + (b2 * gv.s0 + b3 * gv.s1) * at.t.w1);
-        }
-        dpn[hr_plane_a0(j)] += dx * gx.mult;
-        dpn[hr_plane_a1(j)] += dy * gy.mult;
-        dpn[hr_plane_v(j)] += dv * gv.mult;
+        float d3[3] = {0.0f, 0.0f, 0.0f};
+        for (int ch = ch0; ch < nch; ch += stride) hr_train_gather_bwd_channel(a, j, t, gx, gy, gv, at, ch, M, dM, CA, dfeat, dpre, d3);
+        dpn[hr_plane_a0(j)] += d3[0] * gx.mult;
+        dpn[hr_plane_a1(j)] += d3[1] * gy.mult;
+        dpn[hr_plane_v(j)] += d3[2] * gv.mult;
     }
 }
 
@@ -380,11 +420,91 @@ HR_FN int hr_train_slot_col(const HrTrainArgs& a, int pos)
     return col;
 }
 
-// One ray of a training step.  ZP: compile-time bound on z_channels.
+// M[cc][pos] of the ray's decode matrix (RGB: basis_mat rows; SH: basis rows folded with the view direction's SH basis)
+HR_FN float hr_train_decode_coef(const hr_config& c, const HrTrainArgs& a, const float* sh, int cc, int pos)
+{
+    const int col = hr_train_slot_col(a, pos);
+    if (col < 0) return 0.0f;
+    if (c.shading != HR_SHADING_SH) return a.basis[cc * a.n_basis_cols + col];
+    float v = 0.0f;
+    for (int j = 0; j < 9; ++j) v = fmaf(sh[j], a.basis[(cc * 9 + j) * a.n_basis_cols + col], v);
+    return v;
+}
+
+// dM[cc][pos] of one ray -> basis_mat gradient
+HR_FN void hr_train_fold_basis(const hr_config& c, const HrTrainArgs& a, const float* sh, int cc, int pos, float v)
+{
+    if (v == 0.0f) return;
+    const int col = hr_train_slot_col(a, pos);
+    if (col < 0) return;
+    if (c.shading == HR_SHADING_SH) {
+        for (int j = 0; j < 9; ++j) HR_ATOMIC_ADD(a.d_basis + (cc * 9 + j) * a.n_basis_cols + col, sh[j] * v);
+    } else {
+        HR_ATOMIC_ADD(a.d_basis + cc * a.n_basis_cols + col, v);
+    }
+}
+
+// Per-ray quantities every phase recomputes from the ray itself
+struct HrTrainRay {
+    float ro[3], rd[3], oc[3];
+    float time_off;
+    hr_axis_tap_g tap_t;
+};
+HR_FN HrTrainRay hr_train_ray(const hr_config& c, const float* r)
+{
+    HrTrainRay q;
+    for (int i = 0; i < 3; ++i) { q.ro[i] = r[i] - c.isect_origin[i]; q.rd[i] = r[3 + i]; q.oc[i] = 0.0f; }
+    if (c.contract_type != HR_CONTRACT_IDENTITY) hr_contract_point(c, q.ro[0], q.ro[1], q.ro[2], q.oc);
+    float base_t = 0.0f;
+    q.time_off = 0.0f;
+    if (c.advect) { base_t = hr_base_time(c, r[c.ray_dim - 1]); q.time_off = r[c.ray_dim - 1] - base_t; }
+    q.tap_t = hr_make_tap_g(c.video ? hr_normalize_time(c, base_t) : 0.0f, c.video ? c.num_keyframes : 2);
+    return q;
+}
+
+// Phase B: the sample of sorted rank k of `ray`.  M / dM: the ray's decode matrix and its gradient accumulator (3 * CA).
+// The host calls it once per sample; on the device the `lanes` (a power of two <= 64, adjacent lanes of one wavefront)
+// threads of a sample call it together with their `lane`, split the channels between them and combine their shares of
+// the point gradient with HR_LANE_SUM.
+HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane = 0,
+                               int lanes = 1)
+{
+    const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total;
+    const int64_t s = ray * Z + k, NS = a.n_rays * Z;
+    const HrTrainRay q = hr_train_ray(c, a.rays + ray * c.ray_dim);
+    const float* hk = a.head + s * P;
+    const float ds = a.tape.ds[s], dfeat = a.tape.dfeat[s];
+    const float dpre[3] = {a.tape.dpre[s], a.tape.dpre[NS + s], a.tape.dpre[2 * NS + s]};
+    float dp[3] = {0.f, 0.f, 0.f};
+    if (dfeat != 0.0f || dpre[0] != 0.0f || dpre[1] != 0.0f || dpre[2] != 0.0f) {     // only samples that were valid
+        float p[3], dcc;
+        hr_sample_point(c, hk, ds, q.ro, q.rd, q.oc, q.time_off, p, &dcc);
+        hr_axis_tap_g ax[3];
+        for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
+        float dpn[3];
+        hr_train_gather_bwd(a, ax, q.tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes);
+        for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], lanes) * c.inv_size[i];
+    }
+    if (lane != 0) return;
+    const float dt = hr_sample_point_bwd(c, hk, ds, q.ro, q.rd, q.oc, q.time_off, dp, a.tape.ddc[s], a.d_head + s * P);
+    a.tape.dts[ray * Z + a.tape.src[s]] = dt;
+}
+
+// Phase C: the sample of ORIGINAL index k of `ray`
+HR_FN void hr_sample_train_dist_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k)
+{
+    const int64_t s = ray * c.z_channels + k;
+    const float* r = a.rays + ray * c.ray_dim;
+    const float ro[3] = {r[0] - c.isect_origin[0], r[1] - c.isect_origin[1], r[2] - c.isect_origin[2]};
+    const float rd[3] = {r[3], r[4], r[5]};
+    hr_sample_distance_bwd(c, a.head + s * c.preds_per_z, k, ro, rd, a.tape.dts[s], a.d_head + s * c.preds_per_z);
+}
+
+// Phase A: one ray of a training step (forward, compositing backward).  ZP: compile-time bound on z_channels.
 template <int ZP>
 HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
 {
-    const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total, nat = a.n_basis_cols;
+    const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total;
     const float* r = a.rays + ray * c.ray_dim;
     const float* head = a.head + ray * (int64_t)Z * P;
     const float ro[3] = {r[0] - c.isect_origin[0], r[1] - c.isect_origin[1], r[2] - c.isect_origin[2]};
@@ -394,20 +514,9 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
     // decode matrix of the ray (RGB: basis_mat rows; SH: basis rows folded with the view direction's SH basis)
     float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c.shading == HR_SHADING_SH) hr_sh_deg2(rd[0], rd[1], rd[2], sh);
-    float M[3 * HR_TRAIN_MAX_CA], dM[3 * HR_TRAIN_MAX_CA];
+    float M[3 * HR_TRAIN_MAX_CA];
     for (int cc = 0; cc < 3; ++cc)
-        for (int pos = 0; pos < CA; ++pos) {
-            const int col = hr_train_slot_col(a, pos);
-            float v = 0.0f;
-            if (col >= 0) {
-                if (c.shading == HR_SHADING_SH)
-                    for (int j = 0; j < 9; ++j) v = fmaf(sh[j], a.basis[(cc * 9 + j) * nat + col], v);
-                else
-                    v = a.basis[cc * nat + col];
-            }
-            M[cc * CA + pos] = v;
-            dM[cc * CA + pos] = 0.0f;
-        }
+        for (int pos = 0; pos < CA; ++pos) M[cc * CA + pos] = hr_train_decode_coef(c, a, sh, cc, pos);
 
     // ---- forward
     float ds[ZP];                 // sorted pre-contraction distances
@@ -517,35 +626,16 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
             ddc[k] -= ddelta;
         }
     }
-    float dts[ZP];                // dL / d pre-sort distance, by ORIGINAL sample index
+    // hand the per-sample upstream gradients to phases B and C
+    const int64_t NS = a.n_rays * Z;
     for (int k = 0; k < Z; ++k) {
-        float dp[3] = {0.f, 0.f, 0.f};
-        if (valid[k] && (dfeat[k] != 0.0f || pre[k][0] != 0.0f || pre[k][1] != 0.0f || pre[k][2] != 0.0f)) {
-            float p[3], dcc;
-            hr_sample_point(c, head + k * P, ds[k], ro, rd, oc, time_off, p, &dcc);
-            hr_axis_tap_g ax[3];
-            for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
-            float dpn[3];
-            hr_train_gather_bwd(a, ax, tap_t, M, dM, CA, dfeat[k], pre[k], dpn);
-            for (int i = 0; i < 3; ++i) dp[i] = dpn[i] * c.inv_size[i];
-        }
-        dts[src[k]] = hr_sample_point_bwd(c, head + k * P, ds[k], ro, rd, oc, time_off, dp, ddc[k], dhead + k * P);
+        const int64_t s = ray * Z + k;
+        a.tape.ds[s] = ds[k];
+        a.tape.src[s] = src[k];
+        a.tape.dfeat[s] = dfeat[k];
+        a.tape.dpre[s] = pre[k][0]; a.tape.dpre[NS + s] = pre[k][1]; a.tape.dpre[2 * NS + s] = pre[k][2];
+        a.tape.ddc[s] = ddc[k];
     }
-    for (int k = 0; k < Z; ++k) hr_sample_distance_bwd(c, head + k * P, k, ro, rd, dts[k], dhead + k * P);
-
-    // basis_mat gradient of this ray
-    for (int cc = 0; cc < 3; ++cc)
-        for (int pos = 0; pos < CA; ++pos) {
-            const float v = dM[cc * CA + pos];
-            if (v == 0.0f) continue;
-            const int col = hr_train_slot_col(a, pos);
-            if (col < 0) continue;
-            if (c.shading == HR_SHADING_SH) {
-                for (int j = 0; j < 9; ++j) HR_ATOMIC_ADD(a.d_basis + (cc * 9 + j) * nat + col, sh[j] * v);
-            } else {
-                HR_ATOMIC_ADD(a.d_basis + cc * nat + col, v);
-            }
-        }
 }
 
 #endif  // HR_TRAIN_H

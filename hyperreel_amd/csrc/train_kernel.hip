@@ -1,12 +1,18 @@
-// Training path on the device: hr_ray_train (hr_train.h) for one ray per thread, plus the layout
-// kernels around it -- MLP input features for the caller's autograd MLP, and the packed texel gradients back to
-// the reference's (C, H, W) parameter layout.
+// Training path on the device: the three phases of hr_train.h, plus the layout kernels around them --
+// MLP input features for the caller's autograd MLP, and the packed texel gradients back to the reference's (C, H, W)
+// parameter layout.
 //
 // Mapping: a training batch is 16 384 rays (conf/experiment/training/*.yaml: batch_size), i.e. 0.5 M samples against
-// the 20 M of a rendered frame, so the step is latency- and atomics-bound rather than bandwidth-bound: one 64-thread
-// workgroup per 64 rays spreads the batch over all 256 CUs (one wavefront each), every lane walks its ray's samples
-// with the intermediates in registers / scratch, and texel gradients go straight to HBM through hardware fp32 atomics
-// (global_atomic_add_f32) on the channel-last packed layout, where the 4..16 channels of one tap share a cache line.
+// the 20 M of a rendered frame, so the step is latency- and atomics-bound rather than bandwidth-bound.
+//   phase A (forward, compositing backward): one thread per ray, 64-thread workgroups -> one wavefront on each of the
+//     256 CUs; the ray's samples are walked with the intermediates in registers / scratch;
+//   phase B (gather backward): 16 lanes per (ray, sample), ONE TEXEL CHANNEL PER LANE: texel gradients go straight to
+//     HBM through hardware fp32 atomics (global_atomic_add_f32) on the channel-last packed layout, and the channels of a
+//     tap are one contiguous 32..64-byte run per instruction.  The memory system retires atomics per cache-line request,
+//     not per lane: tools/atomic_ubench.hip measures 331 G atomics/s this way against 19.5 G/s for 64 lanes on 64
+//     different lines, and the phase measured 12.2 ms (one thread per ray) and 10.4 ms (one thread per sample, channels
+//     in a loop) per DoNeRF step before.  The ray's decode matrix and its gradient live in LDS (ds_add_f32);
+//   phase C (intersection backward): one thread per (ray, sample), elementwise.
 #include "hr_kernels.h"
 #include "hr_train.h"
 
@@ -16,6 +22,58 @@ __global__ __launch_bounds__(64) void hr_train_kernel(const hr_config* __restric
     const int64_t ray = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (ray >= a.n_rays) return;
     hr_ray_train<ZP>(*cfgp, a, ray);
+}
+
+// Phase B.  HR_TRAIN_LPS = 16 adjacent lanes per sample, one texel channel each (a plane pair has 8 or 16 channels per
+// texel in every shipped model), so that the atomics of one tap are one contiguous run; a workgroup is 16 such groups
+// and walks the samples of RPB whole rays (1 ray when it has 16 samples or more).
+#define HR_TRAIN_LPS 16
+template <int ZP>
+__global__ __launch_bounds__(256) void hr_train_gather_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+{
+    const hr_config& c = *cfgp;
+    constexpr int GROUPS = 256 / HR_TRAIN_LPS;
+    constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix, then [RPB][3 * CA] its gradient
+    const int CA = a.ca_total, Z = c.z_channels;
+    const int64_t ray0 = (int64_t)blockIdx.x * RPB;
+    for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
+        const int r = e / (3 * CA), i = e - r * 3 * CA;
+        float v = 0.0f;
+        if (ray0 + r < a.n_rays) {
+            float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+            if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+            v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
+        }
+        lds[e] = v;
+        lds[RPB * 3 * CA + e] = 0.0f;
+    }
+    __syncthreads();
+    const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
+    for (int si = grp; si < RPB * Z; si += GROUPS) {
+        const int r = si / Z, k = si - r * Z;
+        if (ray0 + r >= a.n_rays) continue;
+        hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
+        const int r = e / (3 * CA), i = e - r * 3 * CA;
+        if (ray0 + r >= a.n_rays) continue;
+        float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+        if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+        hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e]);
+    }
+}
+
+// Phase C
+__global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+{
+    const hr_config& c = *cfgp;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_rays * c.z_channels) return;
+    hr_sample_train_dist_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
 }
 
 void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
@@ -33,6 +91,22 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t 
         case 256: hipLaunchKernelGGL(hr_train_kernel<256>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
         default: break;
     }
+    if (!args.d_rgb) return;
+    const int GROUPS = 256 / HR_TRAIN_LPS;
+    const int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    const unsigned bblocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
+    const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total;
+    switch (ZP) {
+        case 8: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<8>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        case 16: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<16>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        case 32: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<32>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        case 64: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<64>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        case 128: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<128>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        case 256: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<256>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
+        default: break;
+    }
+    const int64_t ns = args.n_rays * cfg.z_channels;
+    hipLaunchKernelGGL(hr_train_dist_bwd_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }
 
 // rays (n, ray_dim) -> MLP input features (n, mlp_in): ray parameterisation + positional encoding

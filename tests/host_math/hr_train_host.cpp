@@ -1,6 +1,8 @@
 // TEST-ONLY host build of hyperreel_amd/csrc/hr_train.h (the per-ray forward + backward of the training path), so the
 // CPU suite can compare it with torch.autograd on the CPU restatement of the reference without a GPU.
 // Nothing in the product links or loads this file.
+#include <vector>
+
 #include "../../hyperreel_amd/csrc/hr_train.h"
 
 extern "C" {
@@ -21,6 +23,12 @@ int ht_train(const hr_config* c, const float* rays, const float* head, long long
     a.rays = rays; a.head = head; a.n_rays = n; a.rgb = rgb; a.d_rgb = d_rgb; a.d_head = d_head;
     for (int j = 0; j < 3; ++j) { a.planes[j] = planes[j]; a.g_a[j] = g_a[j]; a.g_b[j] = g_b[j]; }
     a.basis = basis; a.d_basis = d_basis; a.n_basis_cols = n_basis_cols; a.ca_total = ca_total; a.white_bg = white_bg;
+    // the tape between the phases (the device keeps it in a workspace of the model)
+    const size_t NS = (size_t)n * c->z_channels;
+    std::vector<float> ds(NS), dfeat(NS), dpre(3 * NS), ddc(NS), dts(NS);
+    std::vector<int> src(NS);
+    a.tape.ds = ds.data(); a.tape.src = src.data(); a.tape.dfeat = dfeat.data(); a.tape.dpre = dpre.data();
+    a.tape.ddc = ddc.data(); a.tape.dts = dts.data();
     int ZP = 8;
     while (ZP < c->z_channels) ZP <<= 1;
     for (long long i = 0; i < n; ++i) {
@@ -33,6 +41,20 @@ int ht_train(const hr_config* c, const float* rays, const float* head, long long
             default: hr_ray_train<256>(*c, a, i); break;
         }
     }
+    if (!d_rgb) return 0;
+    for (long long i = 0; i < n; ++i) {                     // phase B, the way a workgroup of the device does it per ray
+        const float* r = rays + (size_t)i * c->ray_dim;
+        float sh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (c->shading == HR_SHADING_SH) hr_sh_deg2(r[3], r[4], r[5], sh);
+        float M[3 * HR_TRAIN_MAX_CA], dM[3 * HR_TRAIN_MAX_CA];
+        for (int cc = 0; cc < 3; ++cc)
+            for (int pos = 0; pos < ca_total; ++pos) { M[cc * ca_total + pos] = hr_train_decode_coef(*c, a, sh, cc, pos); dM[cc * ca_total + pos] = 0.0f; }
+        for (int k = 0; k < c->z_channels; ++k) hr_sample_train_bwd(*c, a, i, k, M, dM);
+        for (int cc = 0; cc < 3; ++cc)
+            for (int pos = 0; pos < ca_total; ++pos) hr_train_fold_basis(*c, a, sh, cc, pos, dM[cc * ca_total + pos]);
+    }
+    for (long long i = 0; i < n; ++i)                       // phase C
+        for (int k = 0; k < c->z_channels; ++k) hr_sample_train_dist_bwd(*c, a, i, k);
     return 0;
 }
 

@@ -1,0 +1,121 @@
+"""Training-step timing: one optimizer step of the reference's loop (nlf/__init__.py:634-709: forward,
+MSE image loss, backward, Adam) at the shipped batch size (conf/experiment/training/*.yaml: batch_size 16384) on the
+full-size synthetic scene of bench.py.
+
+    python tools/train_bench.py [--model donerf_sphere] [--batch 16384] [--steps 30] [--torch-gpu]
+
+Prints one JSON line: ms per step of the HIP training path (hr_train_features + rocBLAS MLP + hr_train_forward /
+hr_train_backward) with the sample stage's forward and backward kernels timed on their own, and with --torch-gpu the
+same step of the PyTorch-ROCm restatement of the reference (oracle/torch_port.py, autograd over grid_sample / sort /
+cumprod) on the same GPU, weights and rays.  The oracle is only the comparator here, never the thing shipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+from hyperreel_amd import config as C          # noqa: E402
+from hyperreel_amd import scenes               # noqa: E402
+
+
+def timed(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='donerf_sphere')
+    ap.add_argument('--batch', type=int, default=16384)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--torch-gpu', action='store_true')
+    args = ap.parse_args()
+
+    from hyperreel_amd.render import build_render_fn
+    from hyperreel_amd.train import SampleStage, grid_parameters, mlp_forward, ray_features
+    cfg, ds = C.model_config(args.model), C.dataset_scalars(args.model)
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    grid = [int(v) for v in sd['model.color_model.net.gridSize']]
+    fn = build_render_fn(cfg, dataset=ds, grid_size=grid)
+    fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    fn.train()
+    model = fn.model
+    rays_np = scenes.benchmark_rays(args.model, 800, 800, frame=7)
+    idx = np.random.default_rng(0).choice(rays_np.shape[0], args.batch, replace=False)     # a training batch: random pixels
+    rays = torch.from_numpy(np.ascontiguousarray(rays_np[idx])).cuda()
+    target = torch.rand((args.batch, 3), device='cuda')
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ((model.forward_train(rays, white_bg=False) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+
+    ms_step = timed(step, args.steps)
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        ((model.forward_train(rays, white_bg=False) - target) ** 2).mean().backward()
+
+    ms_fwd_bwd = timed(fwd_bwd, args.steps)
+    # the sample stage alone
+    h, hc = model._native, model._hc
+    types = [e['type'] for e in cfg['embedding']['embeddings'].values()]
+    pred = model.embedding_model.embeddings[types.index('ray_prediction')]
+    with torch.no_grad():
+        head = mlp_forward(pred.net, ray_features(h, rays, hc.mlp_in), hc.mlp_skip_mask)
+    vm = model.color_model.net
+    grids = grid_parameters(vm)
+    with torch.no_grad():
+        ms_stage_fwd = timed(lambda: SampleStage.apply(h, rays, head, False, vm.basis_mat.weight, *grids), args.steps)
+    head_g = head.clone().requires_grad_(True)
+    d_rgb = torch.rand((args.batch, 3), device='cuda')
+
+    def stage_both():
+        SampleStage.apply(h, rays, head_g, False, vm.basis_mat.weight, *grids).backward(d_rgb)
+
+    ms_stage_both = timed(stage_both, args.steps)
+    out = {'workload': f'{args.model}: training step, batch {args.batch} rays x {hc.z_channels} samples, grid {grid[0]}x{grid[1]}x{grid[2]}',
+           'hip_ms_per_step': round(ms_step, 3), 'hip_ms_forward_backward': round(ms_fwd_bwd, 3),
+           'hip_ms_sample_stage_forward': round(ms_stage_fwd, 3),
+           'hip_ms_sample_stage_backward': round(ms_stage_both - ms_stage_fwd, 3),
+           'hip_krays_per_s': round(args.batch / ms_step, 1)}
+
+    if args.torch_gpu:
+        from torch_port import TorchPort
+        port = TorchPort(cfg, ds, sd, device='cuda')
+        leaves = [t.requires_grad_(True) for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp if t.numel() > 0]
+        leaves += [port.basis.requires_grad_(True)] + [t.requires_grad_(True) for wb in port.layers for t in wb]
+        opt2 = torch.optim.Adam(leaves, lr=1e-3)
+
+        def step_ref():
+            opt2.zero_grad(set_to_none=True)
+            loss = ((port.color(port.embed(rays), train=True, white_bg=False) - target) ** 2).mean()
+            loss.backward()
+            opt2.step()
+
+        ms_ref = timed(step_ref, max(5, args.steps // 3))
+        out['torch_rocm_port_ms_per_step'] = round(ms_ref, 3)
+        out['speedup_vs_torch_rocm_port'] = round(ms_ref / ms_step, 2)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
