@@ -771,6 +771,24 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
     return HR_OK;
 }
 
+int hr_plane_reg_forward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, float* sums_dev, void* stream)
+{
+    if (channels < 0 || h < 1 || w < 1) return fail(HR_E_INVALID, "bad plane shape");
+    if (!sums_dev || (channels > 0 && !plane_dev)) return fail(HR_E_INVALID, "null argument");
+    hr_launch_plane_reg_forward(plane_dev, channels, h, w, sums_dev, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_plane_reg_backward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, const float* coef_dev, float* grad_dev, void* stream)
+{
+    if (channels < 0 || h < 1 || w < 1) return fail(HR_E_INVALID, "bad plane shape");
+    if (channels > 0 && (!plane_dev || !coef_dev || !grad_dev)) return fail(HR_E_INVALID, "null argument");
+    hr_launch_plane_reg_backward(plane_dev, channels, h, w, coef_dev, grad_dev, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 // ---------------------------------------------------------------- training path
 static int check_train(hr_model* m, const float* rays, int64_t n)
 {

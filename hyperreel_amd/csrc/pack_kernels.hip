@@ -132,3 +132,59 @@ void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, i
         hipLaunchKernelGGL(hr_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
                            reinterpret_cast<float*>(dst), C, H, W, tex, c_off);
 }
+
+// ---------------------------------------------------------------- TensoRF plane regularisers
+// TVLoss (nlf/regularizers/tensorf.py:14-34) and density_L1 (nlf/nets/tensorf_base.py:1024-1035) of one (1, C, H, W)
+// plane in one pass over it: sums += { sum (x[y] - x[y-1])^2, sum (x[x] - x[x-1])^2, sum |x| }.  The reference's torch
+// expression reads the plane five times and materialises four temporaries of its size; this is one read (neighbours
+// come from cache) and 3 atomics per workgroup.
+__global__ __launch_bounds__(256) void hr_plane_reg_fwd_kernel(const float* __restrict__ p, int64_t n, int H, int W, float* __restrict__ sums)
+{
+    float sh = 0.0f, sw = 0.0f, sl = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float v = p[i];
+        if (y > 0) { const float d = v - p[i - W]; sh = __builtin_fmaf(d, d, sh); }
+        if (x > 0) { const float d = v - p[i - 1]; sw = __builtin_fmaf(d, d, sw); }
+        sl += fabsf(v);
+    }
+    for (int d = 32; d > 0; d >>= 1) { sh += __shfl_xor(sh, d, 64); sw += __shfl_xor(sw, d, 64); sl += __shfl_xor(sl, d, 64); }
+    __shared__ float part[4][3];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = sh; part[threadIdx.x >> 6][1] = sw; part[threadIdx.x >> 6][2] = sl; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(sums + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// grad = coef[0] * d(sum_h)/dx + coef[1] * d(sum_w)/dx + coef[2] * sign(x), coef on the device (the upstream gradient)
+__global__ __launch_bounds__(256) void hr_plane_reg_bwd_kernel(const float* __restrict__ p, int64_t n, int H, int W, const float* __restrict__ coef,
+                                                               float* __restrict__ grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ch = coef[0], cw = coef[1], cl = coef[2];
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float v = p[i];
+    float gh = 0.0f, gw = 0.0f;
+    if (y > 0) gh += v - p[i - W];
+    if (y < H - 1) gh -= p[i + W] - v;
+    if (x > 0) gw += v - p[i - 1];
+    if (x < W - 1) gw -= p[i + 1] - v;
+    const float sgn = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
+    grad[i] = ch * (2.0f * gh) + cw * (2.0f * gw) + cl * sgn;
+}
+
+void hr_launch_plane_reg_forward(const float* p, int C, int H, int W, float* sums, hipStream_t stream)
+{
+    const int64_t n = (int64_t)C * H * W;
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hr_plane_reg_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n, H, W, sums);
+}
+
+void hr_launch_plane_reg_backward(const float* p, int C, int H, int W, const float* coef, float* grad, hipStream_t stream)
+{
+    const int64_t n = (int64_t)C * H * W;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(hr_plane_reg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n, H, W, coef, grad);
+}

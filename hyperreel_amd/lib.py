@@ -40,6 +40,8 @@ SYMBOLS = [
                                    C.c_void_p]),
     ('hr_train_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                     C.POINTER(hr_train_tensors), C.c_void_p]),
+    ('hr_plane_reg_forward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ('hr_plane_reg_backward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('hr_stage_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('hr_stage_samples', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_debug_trace_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -149,6 +149,46 @@ class HostTensorVM(nn.Module):
     def set_iter(self, i):
         self.cur_iter = i
 
+    # -- regularizers, as the reference's TensoRF regularizer calls them (nlf/regularizers/tensorf.py:57-92) ----------
+    def _reg_planes(self):
+        if self.video:
+            return self.density_plane_space, self.density_plane_time, self.app_plane_space
+        return self.density_plane, self.density_line, self.app_plane
+
+    def density_L1(self):
+        """tensorf_base.py:1024-1035 / tensorf_dynamic.py:246-259."""
+        from .train import l1_mean
+        da, db, _ = self._reg_planes()
+        total = 0
+        for i in range(3):
+            if da[i].shape[1] == 0:
+                continue
+            total = total + l1_mean(da[i]) + l1_mean(db[i])
+        return total
+
+    def TV_loss_density(self, reg):
+        """tensorf_base.py:1037-1046 / tensorf_dynamic.py:261-272; `reg` is the reference's TVLoss module (only its weight
+        is read: the differences are computed by hr_plane_reg_forward)."""
+        from .train import tv_loss
+        da, db, _ = self._reg_planes()
+        total = 0
+        for i in range(3):
+            if da[i].shape[1] == 0 or (self.video and db[i].shape[1] == 0):
+                continue
+            total = total + tv_loss(da[i], getattr(reg, 'TVLoss_weight', 1)) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        """tensorf_base.py:1048-1057 / tensorf_dynamic.py:274-285."""
+        from .train import tv_loss
+        da, db, aa = self._reg_planes()
+        total = 0
+        for i in range(3):
+            if (aa[i].shape[1] == 0) if not self.video else (da[i].shape[1] == 0 or db[i].shape[1] == 0):
+                continue
+            total = total + tv_loss(aa[i], getattr(reg, 'TVLoss_weight', 1)) * 1e-2
+        return total
+
     @torch.no_grad()
     def upsample_volume_grid(self, res_target):
         """TensorVMSplit.upsample_volume_grid (nlf/nets/tensorf_base.py:1152-1188) /

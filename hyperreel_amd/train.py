@@ -111,3 +111,44 @@ def grid_parameters(net):
     else:
         groups = (net.density_plane, net.density_line, net.app_plane, net.app_line)
     return [p for grp in groups for p in grp]
+
+
+class PlaneReg(torch.autograd.Function):
+    """(1, C, H, W) plane -> [sum of squared vertical differences, sum of squared horizontal differences, sum |x|] in one
+    pass (hr_plane_reg_forward); the backward is one elementwise kernel driven by the upstream gradient on the device."""
+
+    @staticmethod
+    def forward(ctx, plane):
+        L = _lib.load()
+        if plane.device.type != 'cuda':
+            raise RuntimeError('PlaneReg runs on the HIP device; there is no CPU path')
+        x = plane.detach().contiguous().float()
+        _, c, h, w = x.shape
+        sums = torch.zeros(3, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.hr_plane_reg_forward(_ptr(x), c, h, w, _ptr(sums), _stream(x.device)), 'hr_plane_reg_forward')
+        ctx.save_for_backward(x)
+        return sums
+
+    @staticmethod
+    def backward(ctx, d_sums):
+        L = _lib.load()
+        (x,) = ctx.saved_tensors
+        _, c, h, w = x.shape
+        coef = d_sums.contiguous().float()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(L.hr_plane_reg_backward(_ptr(x), c, h, w, _ptr(coef), _ptr(grad), _stream(x.device)), 'hr_plane_reg_backward')
+        return grad
+
+
+def tv_loss(plane, weight=1.0):
+    """TVLoss.forward (nlf/regularizers/tensorf.py:19-31) of one plane."""
+    b, c, h, w = plane.shape
+    s = PlaneReg.apply(plane)
+    return weight * 2 * (s[0] / (c * (h - 1) * w) + s[1] / (c * h * (w - 1))) / b
+
+
+def l1_mean(plane):
+    """torch.mean(torch.abs(plane)) (density_L1, nlf/nets/tensorf_base.py:1024-1035)."""
+    return PlaneReg.apply(plane)[2] / plane.numel()

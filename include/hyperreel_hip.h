@@ -304,6 +304,14 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
 int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
                       int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream);
 
+/* TensoRF regularisers of one (1, C, H, W) float32 plane (TVLoss, nlf/regularizers/tensorf.py:14-34; density_L1,
+ * nlf/nets/tensorf_base.py:1024-1035), no model involved.  Forward ADDS to sums_dev[3] =
+ *   { sum (x[:, 1:, :] - x[:, :-1, :])^2,  sum (x[:, :, 1:] - x[:, :, :-1])^2,  sum |x| };
+ * backward writes grad_dev = coef_dev[0] * d sums[0]/dx + coef_dev[1] * d sums[1]/dx + coef_dev[2] * sign(x), with the
+ * three upstream coefficients read from device memory (no host synchronisation inside a training step). */
+int hr_plane_reg_forward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, float* sums_dev, void* stream);
+int hr_plane_reg_backward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, const float* coef_dev, float* grad_dev, void* stream);
+
 /* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
  * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
  * must not exceed the reserved chunk size. */

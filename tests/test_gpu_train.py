@@ -108,3 +108,42 @@ def test_unsupported_models_raise_by_name():
     rays = torch.from_numpy(np.ascontiguousarray(g.rays[:64], np.float32)).cuda()
     with pytest.raises((RuntimeError, NotImplementedError), match='cascade'):
         fn.model.forward_train(rays, white_bg=False)
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small'])
+def test_regularizers_match_the_reference_formulas(case):
+    """density_L1 / TV_loss_density / TV_loss_app of the colour net (what nlf/regularizers/tensorf.py:57-92 calls) against
+    the reference's torch expressions, values and gradients."""
+    from gpu_common import make_render_fn
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    net = fn.model.color_model.net
+
+    def tv_ref(x):                                             # TVLoss.forward, nlf/regularizers/tensorf.py:19-31
+        h_x, w_x = x.size()[2], x.size()[3]
+        count_h = x[:, :, 1:, :].size()[1] * x[:, :, 1:, :].size()[2] * x[:, :, 1:, :].size()[3]
+        count_w = x[:, :, :, 1:].size()[1] * x[:, :, :, 1:].size()[2] * x[:, :, :, 1:].size()[3]
+        h_tv = torch.pow(x[:, :, 1:, :] - x[:, :, :h_x - 1, :], 2).sum()
+        w_tv = torch.pow(x[:, :, :, 1:] - x[:, :, :, :w_x - 1], 2).sum()
+        return 2 * (h_tv / count_h + w_tv / count_w) / x.size()[0]
+
+    da, db, aa = net._reg_planes()
+    used = [i for i in range(3) if da[i].shape[1] > 0]
+    total = 0.3 * net.density_L1() + 1.7 * net.TV_loss_density(None) + 0.9 * net.TV_loss_app(None)
+    total.backward()
+    got = {id(p): p.grad.clone() for p in net.parameters() if p.grad is not None}
+    for p in net.parameters():
+        p.grad = None
+    ref = 0.3 * sum(da[i].abs().mean() + db[i].abs().mean() for i in used) + 1.7 * sum(tv_ref(da[i]) * 1e-2 for i in used) \
+        + 0.9 * sum(tv_ref(aa[i]) * 1e-2 for i in used)
+    ref.backward()
+    assert abs(float(total.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    n = 0
+    for p in net.parameters():
+        if p.grad is None:
+            assert id(p) not in got
+            continue
+        n += 1
+        scale = float(p.grad.abs().max())
+        assert float((got[id(p)] - p.grad).abs().max()) <= 1e-5 * scale + 1e-12
+    assert n >= 3
