@@ -109,6 +109,9 @@ int validate(const hr_config& c, bool coarse = false)
 {
     if (c.ray_dim != 6 && c.ray_dim != 8) return fail(HR_E_INVALID, "ray_dim must be 6 or 8 (got %d)", c.ray_dim);
     if (c.n_groups < 1 || c.n_groups > HR_MAX_GROUPS) return fail(HR_E_INVALID, "n_groups out of range");
+    for (int g = 0; g < c.n_groups; ++g)
+        if (c.groups[g].pe_type == HR_PE_WINDOWED && c.groups[g].pe_n_freqs > HR_MAX_FREQS)
+            return fail(HR_E_INVALID, "windowed positional encoding with more than %d frequencies", HR_MAX_FREQS);
     if (c.mlp_layers != 0) {   // 0: ZeroMLP (nlf/nets/mlp.py:14-33), the head is all zeros and samples sit on their anchors
         if (c.mlp_hidden != 64 && c.mlp_hidden != 128 && c.mlp_hidden != 256)
             return fail(HR_E_INVALID, "mlp_hidden must be 64, 128 or 256 (got %d)", c.mlp_hidden);
@@ -593,6 +596,35 @@ int hr_model_finalize(hr_model* m)
         rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
         return hr_model_reserve(m, rays);
     }
+    return HR_OK;
+}
+
+// the configuration with every schedule-dependent constant blanked: what hr_model_update_config may not change
+static hr_config structure_of(const hr_config& in)
+{
+    hr_config c = in;
+    hr_act* acts[] = {&c.f_z_vals.act, &c.f_isect_sigma.act, &c.f_offset_sigma.act, &c.f_point_offset.act, &c.f_color_scale.act,
+                      &c.f_color_shift.act, &c.f_spatial_flow.act, &c.f_color_scale_global.act, &c.f_color_shift_global.act,
+                      &c.z_act, &c.flow_act, &c.offset_act, &c.color_table_t_act, &c.color_table_s_act};
+    for (hr_act* a : acts) { a->outer = 0.0f; a->add = 0.0f; }
+    for (int g = 0; g < HR_MAX_GROUPS; ++g)
+        for (int j = 0; j < HR_MAX_FREQS; ++j) c.groups[g].pe_weight[j] = 0.0f;
+    return c;
+}
+
+int hr_model_update_config(hr_model* m, const hr_config* cfg, void* stream)
+{
+    if (!m || !cfg) return fail(HR_E_INVALID, "null argument");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_update_config before hr_model_finalize");
+    if (m->coarse || m->is_coarse) return fail(HR_E_INVALID, "hr_model_update_config: cascades are re-created instead");
+    const hr_config a = structure_of(m->cfg), b = structure_of(*cfg);
+    if (memcmp(&a, &b, sizeof(hr_config)) != 0)
+        return fail(HR_E_INVALID, "hr_model_update_config: the configurations differ in more than activation / PE schedule constants");
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));      // launches in flight still read the device copies
+    m->cfg = *cfg;
+    analyse_live_columns(m);                                  // same live columns (structure unchanged): rebuilds kcfg
+    if (m->kcfg_dev) HR_HIP(hipMemcpy(m->kcfg_dev, &m->kcfg, sizeof(hr_config), hipMemcpyHostToDevice));
+    if (m->ucfg_dev) HR_HIP(hipMemcpy(m->ucfg_dev, &m->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
     return HR_OK;
 }
 

@@ -81,7 +81,7 @@ HR_FN float hr_apply_act(const hr_act& a, float x)
     } else if (a.type == HR_ACT_TANH) {
         y = tanhf(y);
     }
-    return y * a.outer;
+    return y * a.outer + a.add;      // add: the (1 - w) * start_value term of an EaseValue inside its window, else 0
 }
 
 // The same activation for heads that only feed continuous quantities (point offsets, flow, colour scale / shift)
@@ -95,7 +95,7 @@ HR_FN float hr_apply_act_post(const hr_act& a, float x)
         const float e = __expf(2.0f * fminf(fmaxf(y, -15.0f), 15.0f));
         y = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
     }
-    return y * a.outer;
+    return y * a.outer + a.add;
 #else
     return hr_apply_act(a, x);
 #endif
@@ -164,11 +164,12 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
             for (int j = 0; j < pg.pe_n_freqs; ++j) {
                 f = f * pg.pe_freq_mult;                           // freq_multiplier ** (j+1)
                 float bf = pg.pe_base_mult * f;
+                const float w = pg.pe_weight[j];                   // WindowedPE.weight(j), pe.py:186-208 (1 after the window)
                 for (int i = 0; i < nx; ++i) {                     // [sin(all i), cos(all i)] per frequency
                     float sv, cv;
                     HR_SINCOS(bf * HR_X(i), &sv, &cv);
-                    out[n_out + i] = sv;
-                    out[n_out + nx + i] = cv;
+                    out[n_out + i] = w * sv;
+                    out[n_out + nx + i] = w * cv;
                 }
                 n_out += 2 * nx;
             }

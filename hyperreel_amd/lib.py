@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 
@@ -30,6 +30,7 @@ SYMBOLS = [
     ('hr_model_create_cascade', C.c_int, [C.POINTER(hr_config), C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
     ('hr_model_upload', C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     ('hr_model_finalize', C.c_int, [C.c_void_p]),
+    ('hr_model_update_config', C.c_int, [C.c_void_p, C.POINTER(hr_config), C.c_void_p]),
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
     ('hr_render', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_render_fields', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(hr_fields), C.c_void_p]),

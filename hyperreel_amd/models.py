@@ -262,9 +262,11 @@ class HipLightfieldModel(nn.Module):
         self.param = _Dummy()
         self.embedding_model = HostEmbedding(cfg, mlp_layer_shapes(cfg), self.dataset)
         self.color_model = HostColorModel(net, grid, self.dataset['num_keyframes'])
-        self.cur_iter = 0
+        self.cur_iter = None           # training iteration of the activation / PE schedules; None = converged (see set_iter)
         self._native = None
         self._native_key = None
+        self._native_cfg = None        # bytes of the hr_config the native handle currently holds
+        self._sched_built = None       # cur_iter that configuration was compiled at
         # fail on configurations outside the supported path now, not at the first render
         self._compile(grid)
 
@@ -275,14 +277,16 @@ class HipLightfieldModel(nn.Module):
         self._native_key = None
 
     def _compile(self, grid):
-        """-> (coarse hr_config or None, hr_config of the level that renders)."""
-        return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype)
+        """-> (coarse hr_config or None, hr_config of the level that renders), schedules evaluated at cur_iter."""
+        return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype, iteration=self.cur_iter)
 
     # -- reference surface ---------------------------------------------------------
     def set_iter(self, i):
-        """Inference-time no-op: every EaseValue/WindowedPE weight is 1 once training has
-        passed its windows, which is the only regime this renderer serves
-        (nlf/__init__.py:582-583 sets iter=1e7 for render/test)."""
+        """LightfieldModel.set_iter (what INRSystem.set_train_iter calls every step, nlf/__init__.py:608-614): the EaseValue
+        activations (nlf/activations.py:462-496) and WindowedPE weights (nlf/pe.py:166-208) of the model are evaluated at
+        training iteration `i`.  Render / test call it with 1e7 (nlf/__init__.py:582-583), where every weight is 1; a model
+        that was never told an iteration is in that converged state too.  Only constants of the compiled configuration
+        change: the next call swaps them in with hr_model_update_config, no weights are re-packed."""
         self.cur_iter = i
         self.color_model.set_iter(i)
 
@@ -326,10 +330,29 @@ class HipLightfieldModel(nn.Module):
         # updates bump ._version, re-allocations change data_ptr/shape
         return (self.mlp_precision, self.grid_dtype) + tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
 
+    def _sync_schedule(self, hc=None, coarse=None):
+        """Hands the configuration compiled at cur_iter to an existing native handle if it differs from what it holds."""
+        import ctypes as C
+        if hc is None:
+            coarse, hc = self._compile(self.grid_size)
+        blob = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
+        if blob != self._native_cfg:
+            if coarse is not None:
+                raise NotImplementedError('activation / PE schedules inside their windows on a point_prediction cascade')
+            dev = next(self.parameters()).device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().hr_model_update_config(self._native, C.byref(hc), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                           'hr_model_update_config')
+            self._native_cfg = blob
+        self._hc = hc
+        self._sched_built = self.cur_iter
+
     def native(self):
         """Returns the hr_model handle, (re)uploading weights if any parameter changed."""
         key = self._param_key()
         if self._native is not None and key == self._native_key:
+            if self._sched_built != self.cur_iter:
+                self._sync_schedule()
             return self._native
         coarse, hc, tensors = self._tensors()
         L = _lib.load()
@@ -345,6 +368,7 @@ class HipLightfieldModel(nn.Module):
                 _lib.check(L.hr_model_create_cascade(C.byref(coarse), C.byref(hc), C.byref(h)), 'hr_model_create_cascade')
             self._native = h
             self._native_grid = self.grid_size
+            self._native_cfg = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
 
         with torch.cuda.device(dev):
             if self._native is None:
@@ -361,6 +385,7 @@ class HipLightfieldModel(nn.Module):
             _lib.check(L.hr_model_finalize(self._native), 'hr_model_finalize')
         self._native_key = key
         self._hc = hc
+        self._sync_schedule(hc, coarse)          # an existing handle may still hold another iteration's constants
         return self._native
 
     def reserve(self, rays_per_chunk):
@@ -458,6 +483,8 @@ class HipLightfieldModel(nn.Module):
         from . import train as T
         if self._native is None or self._native_grid != self.grid_size:
             self.native()
+        elif self._sched_built != self.cur_iter:
+            self._sync_schedule()
         h, hc = self._native, self._hc
         rays = self._check_rays(rays)
         net_cfg = self.cfg['color']['net']
@@ -496,7 +523,7 @@ class HipLightfieldModel(nn.Module):
                 y = torch.sigmoid(y)
             elif f.act.type == 2:
                 y = torch.tanh(y)
-            return y * f.act.outer
+            return y * f.act.outer + f.act.add
 
         for name, f in (('color_scale', hc.f_color_scale), ('color_shift', hc.f_color_shift)):
             if f.offset >= 0:

@@ -42,13 +42,14 @@ SHADING = {'RGB': 0, 'SH': 1}
 
 
 class hr_act(C.Structure):
-    _fields_ = [('type', C.c_int32), ('inner', C.c_float), ('shift', C.c_float), ('outer', C.c_float)]
+    _fields_ = [('type', C.c_int32), ('inner', C.c_float), ('shift', C.c_float), ('outer', C.c_float), ('add', C.c_float)]
 
 
 class hr_param_group(C.Structure):
     _fields_ = [('start', C.c_int32), ('end', C.c_int32), ('fn', C.c_int32), ('origin', C.c_float * 3),
                 ('a', C.c_float), ('b', C.c_float), ('pe_type', C.c_int32), ('pe_n_freqs', C.c_int32),
-                ('pe_exclude_identity', C.c_int32), ('pe_freq_mult', C.c_float), ('pe_base_mult', C.c_float)]
+                ('pe_exclude_identity', C.c_int32), ('pe_freq_mult', C.c_float), ('pe_base_mult', C.c_float),
+                ('pe_weight', C.c_float * 8)]
 
 
 class hr_head_field(C.Structure):
@@ -98,13 +99,84 @@ class hr_fields(C.Structure):
 
 
 # --------------------------------------------------------------------------- small helpers
+# Training iteration the schedules are evaluated at while compile_config runs (None: converged, every weight 1)
+_ITERATION = None
+
+
+def ease_weight(cfg, iteration):
+    """EaseValue.weight at `iteration` (nlf/activations.py:462-496): cur = iteration - wait_iters; 1 once
+    cur >= window_iters, 0 while waiting on a zero-length window, else clamp(cur / window_iters, 0, 1)."""
+    if iteration is None:
+        return 1.0
+    cur = iteration - cfg.get('wait_iters', 0.0)
+    window = cfg.get('window_iters', 0.0)
+    if cur >= window:
+        return 1.0
+    if window == 0:
+        return 0.0
+    return min(max(float(cur) / window, 0.0), 1.0)
+
+
+def windowed_pe_weights(pe, iteration):
+    """WindowedPE.weight(j + window_identity) for j < n_freqs (nlf/pe.py:166-208)."""
+    n = int(pe['n_freqs'])
+    max_freq_iter = float(pe.get('max_freq_iter', 0))
+    wait = float(pe.get('wait_iters', 0))
+    window_identity = 1 if pe.get('window_identity', False) else 0
+    if iteration is None or n == 0 or max_freq_iter == 0:
+        return [1.0] * n
+    window_after = max_freq_iter / n
+    if window_identity:
+        windows = [(wait, window_after + wait)] + [(window_after * i + wait, window_after * (i + 1) + wait) for i in range(1, n + 1)]
+        max_freq_iter = (n + 1) * window_after
+    else:
+        windows = [(window_after * i + wait, window_after * (i + 1) + wait) for i in range(n)]
+    out = []
+    for j in range(n):
+        jj = j + window_identity
+        cur = iteration - wait
+        if cur < 0:
+            out.append(0.0)
+        elif iteration > max_freq_iter:
+            out.append(1.0)
+        elif windows[jj][1] - windows[jj][0] == 0:
+            out.append(1.0 if iteration >= windows[jj][0] else 0.0)
+        else:
+            alpha = (cur - windows[jj][0]) / float(windows[jj][1] - windows[jj][0])
+            out.append(float((1.0 - np.cos(np.pi * np.clip(alpha, 0.0, 1.0))) / 2))
+    return out
+
+
+class at_iteration:
+    """with at_iteration(i): compile_* evaluates the EaseValue / WindowedPE schedules at training iteration i
+    (None: converged).  INRSystem.set_train_iter (nlf/__init__.py:608-614) is the reference's equivalent."""
+
+    def __init__(self, iteration):
+        self.iteration = iteration
+
+    def __enter__(self):
+        global _ITERATION
+        self.prev, _ITERATION = _ITERATION, self.iteration
+        return self
+
+    def __exit__(self, *exc):
+        global _ITERATION
+        _ITERATION = self.prev
+        return False
+
+
 def _act(cfg):
-    """get_activation (nlf/activations.py:566-570) at inference: EaseValue -> inner."""
+    """get_activation (nlf/activations.py:566-570).  EaseValue (:462-496), w * act(x) + (1 - w) * start_value, is folded
+    into the inner activation's `outer` (times w) and `add`; with _ITERATION None (inference) w == 1."""
     if cfg is None:
         cfg = 'identity'
     if isinstance(cfg, str):
         cfg = {'type': cfg}
+    scale, add = 1.0, 0.0                      # y_final = scale * inner(x) + add
     while cfg['type'] == 'ease_value':
+        w = ease_weight(cfg, _ITERATION)
+        add += scale * (1.0 - w) * float(cfg.get('start_value', 0.0))
+        scale *= w
         cfg = cfg['activation']
         if isinstance(cfg, str):
             cfg = {'type': cfg}
@@ -115,7 +187,8 @@ def _act(cfg):
     a.type = ACT[t]
     a.inner = float(cfg.get('inner_fac', 1.0))
     a.shift = float(cfg.get('shift', 0.0))
-    a.outer = float(cfg['fac']) if 'fac' in cfg else float(cfg.get('outer_fac', 1.0))
+    a.outer = (float(cfg['fac']) if 'fac' in cfg else float(cfg.get('outer_fac', 1.0))) * scale
+    a.add = add
     return a
 
 
@@ -193,9 +266,14 @@ MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3}
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
 
 
-def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', _coarse=False):
+def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', _coarse=False, iteration='inherit'):
     """cfg: `experiment.model` group (dict/Cfg); dataset: {near, far, depth_range,
-    num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes."""
+    num_keyframes, num_frames}; grid_size: [Nx, Ny, Nz] of the uploaded planes.
+    iteration: training iteration of the EaseValue / WindowedPE schedules (None: converged; default: whatever an
+    enclosing `at_iteration` set, else converged)."""
+    if iteration != 'inherit':
+        with at_iteration(iteration):
+            return compile_config(cfg, dataset, grid_size, mlp_precision, grid_dtype, _coarse)
     if cfg.get('param', {}).get('fn', 'identity') != 'identity':
         raise NotImplementedError("model.param.fn other than 'identity'")
     if cfg['embedding']['type'] != 'ray_point':
@@ -263,12 +341,17 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
             if pe['type'] not in ('windowed', 'basic'):
                 raise NotImplementedError(f"pe '{pe['type']}' is outside the hot-path scope")
             if 'window_iters' in pe or pe.get('ceil', False):
-                raise NotImplementedError('windowed PE schedules are training-time only')
+                raise NotImplementedError('windowed PE with explicit window_iters / ceil is outside the hot-path scope')
             pg.pe_type = PE[pe['type']]
             pg.pe_n_freqs = int(pe['n_freqs'])
             pg.pe_exclude_identity = int(bool(pe.get('exclude_identity', False))) if pe['type'] == 'windowed' else 0
             pg.pe_freq_mult = float(pe.get('freq_multiplier', 2.0))
             pg.pe_base_mult = float(pe.get('base_multiplier', 1.0)) if pe['type'] == 'windowed' else 1.0
+            if pe['type'] == 'windowed':
+                if pg.pe_n_freqs > 8:
+                    raise NotImplementedError('windowed PE with more than 8 frequencies')
+                for j, w in enumerate(windowed_pe_weights(pe, _ITERATION)):
+                    pg.pe_weight[j] = w
             k = 2 * pg.pe_n_freqs
             n = n * (k if pg.pe_exclude_identity else k + 1)
         mlp_in += n
@@ -677,11 +760,13 @@ def compile_cascade(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='f
     return hc0, hc1
 
 
-def compile_model(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32'):
-    """-> (coarse hr_config or None, hr_config of the rendering level): cascade-aware front door."""
-    if is_cascade(cfg):
-        return compile_cascade(cfg, dataset, grid_size, mlp_precision, grid_dtype)
-    return None, compile_config(cfg, dataset, grid_size, mlp_precision, grid_dtype)
+def compile_model(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', iteration=None):
+    """-> (coarse hr_config or None, hr_config of the rendering level): cascade-aware front door.
+    iteration: training iteration of the activation / PE schedules (None: converged, what render and test use)."""
+    with at_iteration(iteration):
+        if is_cascade(cfg):
+            return compile_cascade(cfg, dataset, grid_size, mlp_precision, grid_dtype)
+        return None, compile_config(cfg, dataset, grid_size, mlp_precision, grid_dtype)
 
 
 def live_head_columns(hc):

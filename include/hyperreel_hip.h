@@ -30,12 +30,13 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 11
+#define HR_ABI_VERSION 12
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
 #define HR_MAX_GROUPS 4      /* ray-parameterisation groups feeding the MLP (`params:` in the YAML) */
 #define HR_MAX_LAYERS 8      /* Linear layers of the sample-prediction MLP */
+#define HR_MAX_FREQS 8       /* frequencies of a windowed positional encoding */
 #define HR_MAX_MLP_IN 64     /* MLP input features after positional encoding */
 
 /* error codes */
@@ -45,17 +46,18 @@ extern "C" {
 #define HR_E_HIP (-3)        /* a HIP runtime call failed */
 #define HR_E_MISSING (-4)    /* finalize: a required tensor was never uploaded */
 
-/* nlf/activations.py: Identity (:163-178), Sigmoid (:53-69), Tanh (:121-137); EaseValue
- * (:462-496) is resolved to its inner activation by the host (inference). y = act(x*inner+shift)*outer */
+/* nlf/activations.py: Identity (:163-178), Sigmoid (:53-69), Tanh (:121-137).  y = act(x*inner+shift)*outer + add.
+ * EaseValue (:462-496), w * act(x) + (1 - w) * start_value with the iteration-dependent weight w, is folded by the host
+ * into outer (times w) and add ((1 - w) * start_value); once its window has passed w == 1 and add == 0. */
 enum { HR_ACT_IDENTITY = 0, HR_ACT_SIGMOID = 1, HR_ACT_TANH = 2 };
 typedef struct hr_act {
     int32_t type;
-    float inner, shift, outer;
+    float inner, shift, outer, add;
 } hr_act;
 
 /* nlf/param.py: identity (:20-24), PlueckerParam (:223-256), TwoPlaneParam (:63-118) */
 enum { HR_PARAM_IDENTITY = 0, HR_PARAM_PLUECKER = 1, HR_PARAM_TWO_PLANE = 2 };
-/* nlf/pe.py: IdentityPE, WindowedPE (:130-224, weights == 1 at inference), BasicPE (:32-71) */
+/* nlf/pe.py: IdentityPE, WindowedPE (:130-224, per-frequency weights in pe_weight), BasicPE (:32-71) */
 enum { HR_PE_NONE = 0, HR_PE_WINDOWED = 1, HR_PE_BASIC = 2 };
 typedef struct hr_param_group {
     int32_t start, end;          /* ray columns [start, end) (nlf/embedding/ray.py:319-321) */
@@ -66,6 +68,7 @@ typedef struct hr_param_group {
     int32_t pe_n_freqs;
     int32_t pe_exclude_identity;
     float pe_freq_mult, pe_base_mult;
+    float pe_weight[HR_MAX_FREQS]; /* windowed: WindowedPE.weight(j) of frequency j (nlf/pe.py:186-208), 1 once its window has passed */
 } hr_param_group;
 
 /* One per-sample output of the MLP head (nlf/embedding/ray.py:333-337): `channels`
@@ -247,6 +250,12 @@ int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes
 /* Re-lays the uploaded tensors out for the kernels (channel-last interleaved planes,
  * MFMA-tiled MLP weights).  May be called again after further uploads. */
 int hr_model_finalize(hr_model* m);
+
+/* Replaces the model's configuration by one that differs only in schedule-dependent constants -- the `outer` / `add`
+ * of the activations (EaseValue) and `pe_weight` (WindowedPE) -- as INRSystem.set_train_iter does for the reference
+ * modules every training step (nlf/__init__.py:608-614).  No weights are re-packed.  Any other difference is refused
+ * with HR_E_INVALID.  Waits for `stream` before the device copies are replaced. */
+int hr_model_update_config(hr_model* m, const hr_config* cfg, void* stream);
 
 /* Sizes the per-launch workspace (rays processed per internal chunk).  Optional. */
 int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);

@@ -127,6 +127,15 @@ def _v_deformable_3axes(cfg):                 # default start normals (x, y, z),
     ic.end = [1.0, 0.9, 1.6]
 
 
+def _v_pe_window(cfg):
+    """a WindowedPE schedule on the ray encoding (no runnable shipped YAML has one; shiny_z_depth's sits in an MLP the
+    reference cannot build): 2 epochs = 8000 iterations over the encoding's frequencies"""
+    for p in cfg.embedding.embeddings.ray_prediction_0.params.values():
+        if 'pe' in p:
+            p.pe.max_freq_epoch = 2
+
+
+# (name, base YAML, edit, [training iteration the schedules are evaluated at])
 VARIANTS = [
     ('variant_deformable_3axes', 'shiny_z_deformable', _v_deformable_3axes),
     ('variant_cylinder_new', 'bom_cylinder', _v_cylinder_new),
@@ -134,6 +143,11 @@ VARIANTS = [
     ('variant_z_depth_contract', 'llff_z_plane', _v_z_depth),
     ('variant_voxel_outward', 'donerf_voxel', _v_voxel_outward),
     ('variant_mask_off_unsorted', 'donerf_sphere', _v_mask_off_unsorted),
+    # inside the activation / encoding warm-up windows (EaseValue, activations.py:462-496; WindowedPE, pe.py:166-208)
+    ('variant_ease_iter2000', 'donerf_sphere', None, 2000),
+    ('variant_ease_iter6000', 'immersive_sphere', None, 6000),
+    ('variant_ease_iter0', 'technicolor_z_plane', None, 0),
+    ('variant_pe_window_iter3000', 'donerf_sphere', _v_pe_window, 3000),
 ]
 
 
@@ -143,8 +157,8 @@ def main(only=None, force=False):
     os.makedirs(OUT, exist_ok=True)
     coverage = {}
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(f'{ref_shim.REF}/conf/experiment/model/*.yaml'))
-    jobs = [(n, n, None) for n in names] + VARIANTS
-    for i, (name, base, edit) in enumerate(jobs):
+    jobs = [(n, n, None, None) for n in names] + [(v + (None,))[:4] for v in VARIANTS]
+    for i, (name, base, edit, iteration) in enumerate(jobs):
         if only and name not in only:
             continue
         path = f'{ref_shim.REF}/conf/experiment/model/{base}.yaml'
@@ -160,7 +174,7 @@ def main(only=None, force=False):
         model_cfg = C.epoch_to_iter(C.to_cfg(C.to_plain(raw)), 4000)
         rejected = None
         try:
-            plan.compile_model(model_cfg, ds, GRID)
+            plan.compile_model(model_cfg, ds, GRID, iteration=iteration)
         except (NotImplementedError, ValueError) as e:
             coverage[name] = {'status': 'rejected', 'reason': str(e)}
             print(f'{name:36s} rejected: {e}')
@@ -186,7 +200,7 @@ def main(only=None, force=False):
                 for k, v in list(_isect(cfg).items()):      # plain dicts written by an edit -> attr dicts
                     _isect(cfg)[k] = ref_shim.to_attr(v)
         ref_cfg = ref_shim.load_model_cfg(base, overrides)
-        fn = ref_shim.build_reference(ref_cfg, ds)
+        fn = ref_shim.build_reference(ref_cfg, ds) if iteration is None else ref_shim.build_reference(ref_cfg, ds, iteration=iteration)
         seed = 100 + i
         sd = scenes.make_state_dict(model_cfg, ds, GRID, seed, 'dense', 1.0)
         own = dict(fn.state_dict())
@@ -211,7 +225,7 @@ def main(only=None, force=False):
             sys.path.insert(0, os.path.join(ROOT, 'oracle'))
             from hyperreel_oracle import HyperReelOracle
             try:
-                got = HyperReelOracle(model_cfg, ds, sd).render(rays)['rgb']
+                got = HyperReelOracle(model_cfg, ds, sd, iteration=iteration).render(rays)['rgb']
                 print(f'{name:36s} oracle vs reference: L-inf {np.abs(got - rgb).max():.3e} (rgb std {rgb.std():.3f})')
             except NotImplementedError as e:
                 print(f'{name:36s} oracle: NotImplementedError {e}')
@@ -220,12 +234,18 @@ def main(only=None, force=False):
         recipe = {'case': 'sweep/' + name, 'model': name, 'model_cfg': C.to_plain(raw), 'z_channels': None,
                   'grid': GRID, 'seed': seed, 'density': 'dense', 'app_scale': 1.0, 'dataset': ds,
                   'checksum': scenes.state_dict_checksum(sd)}
+        if iteration is not None:
+            recipe['iter'] = iteration
         np.savez_compressed(os.path.join(OUT, name + '.npz'), rays=rays, rgb=rgb,
                             recipe=np.frombuffer(json.dumps(recipe).encode(), dtype=np.uint8))
         coverage[name] = {'status': 'golden', 'rgb_std': float(rgb.std())}
         print(f'{name:36s} golden: {rays.shape[0]} rays, rgb mean {rgb.mean():.4f} std {rgb.std():.4f}')
-    if not only and not force:
-        with open(os.path.join(OUT, 'coverage.json'), 'w') as f:
+    cov_path = os.path.join(OUT, 'coverage.json')
+    if only and not force and os.path.exists(cov_path):      # a partial run updates its own entries only
+        with open(cov_path) as f:
+            coverage = {**json.load(f), **coverage}
+    if not force:
+        with open(cov_path, 'w') as f:
             json.dump(coverage, f, indent=1, sort_keys=True)
     n_ok = sum(1 for k, v in coverage.items() if v['status'] == 'golden' and not k.startswith('variant_'))
     n_all = sum(1 for k in coverage if not k.startswith('variant_'))

@@ -152,8 +152,9 @@ def make_system(dataset):
     )
 
 
-def build_reference(cfg, dataset, net_chunk=16384, seed=0):
-    """Returns the reference's RenderLightfield (eval mode, iter=1e7) on CPU."""
+def build_reference(cfg, dataset, net_chunk=16384, seed=0, iteration=10_000_000):
+    """Returns the reference's RenderLightfield (eval mode) on CPU at training iteration `iteration` (1e7: the converged
+    state render / test run in, nlf/__init__.py:582-583; smaller values sit inside the EaseValue / WindowedPE windows)."""
     install()
     torch.manual_seed(seed)
     with cpu_mode():
@@ -162,7 +163,7 @@ def build_reference(cfg, dataset, net_chunk=16384, seed=0):
         system = make_system(dataset)
         model = LightfieldModel(cfg, system=system)
         fn = RenderLightfield(model, None, cfg.render, net_chunk=net_chunk).eval()
-        model.set_iter(10_000_000)
+        model.set_iter(iteration)
     return fn
 
 

@@ -24,12 +24,16 @@ def _act(a, x):
         y = torch.sigmoid(y)
     elif a.type == 'tanh':
         y = torch.tanh(y)
-    return y * float(a.outer)
+    y = y * float(a.outer)
+    for w, sv in reversed(getattr(a, 'ease', [])):          # EaseValue.ease_out inside its window
+        if w != 1.0:
+            y = w * y + (1 - w) * sv
+    return y
 
 
 class TorchPort:
-    def __init__(self, cfg, dataset, sd, device='cpu'):
-        self.o = HyperReelOracle(cfg, dataset, sd)          # setup-time constants only
+    def __init__(self, cfg, dataset, sd, device='cpu', iteration=None):
+        self.o = HyperReelOracle(cfg, dataset, sd, iteration=iteration)          # setup-time constants only
         o = self.o
         self.dev = torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
@@ -99,8 +103,10 @@ class TorchPort:
                 if pe['type'] == 'windowed':
                     bm = float(pe.get('base_multiplier', 1.0))
                     out = [] if pe.get('exclude_identity', False) else [y]
-                    for f in freqs:
-                        out += [torch.sin(bm * f * y), torch.cos(bm * f * y)]
+                    from hyperreel_oracle import windowed_pe_weights
+                    for f, w in zip(freqs, windowed_pe_weights(pe, self.o.iteration)):
+                        out += [w * torch.sin(bm * f * y), w * torch.cos(bm * f * y)] if w != 1.0 else \
+                               [torch.sin(bm * f * y), torch.cos(bm * f * y)]
                 else:
                     cur = (torch.tensor(freqs, device=self.dev)[None, None] * y[..., None]).reshape(y.shape[0], -1)
                     out = [y, torch.sin(cur), torch.cos(cur)]
@@ -111,7 +117,9 @@ class TorchPort:
     def embed(self, rays, head=None):
         """`head`: optional (B, Z*P) raw MLP output to use instead of running the MLP (gradient checks of the training
         path differentiate with respect to it)."""
+        import hyperreel_oracle as H
         o = self.o
+        H.ITERATION = o.iteration                           # stages build their activations while they run
         B, Z = rays.shape[0], o.Z
         x = {}
         h = self._mlp(self._param_pe(rays)) if head is None else head

@@ -10,13 +10,15 @@ def to_torch_state_dict(sd):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 
-def make_render_fn(cfg, dataset, sd, device='cuda', mlp_precision='auto', grid_dtype='fp32'):
+def make_render_fn(cfg, dataset, sd, device='cuda', mlp_precision='auto', grid_dtype='fp32', iteration=None):
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
     fn = build_render_fn(cfg, dataset=dataset, grid_size=grid, device=device, mlp_precision=mlp_precision, grid_dtype=grid_dtype)
     missing, unexpected = fn.model.load_state_dict(to_torch_state_dict(sd), strict=False)
     # the synthetic scenes carry no dummy_layer entries; everything else must be present
     assert not [m for m in missing if 'dummy_layer' not in m], missing
     assert not unexpected, unexpected
+    if iteration is not None:                 # inside the activation / encoding warm-up windows (INRSystem.set_train_iter)
+        fn.model.set_iter(iteration)
     return fn
 
 

@@ -35,6 +35,7 @@ class Golden:
             self.cfg = C.epoch_to_iter(C.to_cfg(r['model_cfg']), 4000)
         else:
             self.cfg = C.model_config(r['model'], z_channels=r['z_channels'])
+        self.iteration = r.get('iter')          # training iteration of the activation / PE schedules (None: converged)
         self.dataset = r['dataset']
         self.grid = r['grid']
         self.rays = self.arrays['rays']

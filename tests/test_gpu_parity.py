@@ -18,7 +18,7 @@ RGB_TOL = 1e-4
 
 def _oracle(g):
     from hyperreel_oracle import HyperReelOracle
-    return HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+    return HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
 
 
 @pytest.fixture(scope='module')
@@ -29,7 +29,7 @@ def fns():
         if (case, precision) not in cache:
             from gpu_common import make_render_fn
             g = Golden(case)
-            cache[(case, precision)] = (g, make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision))
+            cache[(case, precision)] = (g, make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision, iteration=g.iteration))
         return cache[(case, precision)]
 
     yield get
@@ -58,7 +58,7 @@ def test_every_accepted_shipped_yaml_matches_the_reference(case):
     reference built from that very YAML vs the HIP path built from the same parsed group."""
     from gpu_common import make_render_fn, render_np
     g = Golden(case)
-    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     out = render_np(fn, g.rays)
     err = np.abs(out['rgb'] - g.rgb).max(-1)
     assert np.isfinite(out['rgb']).all()
@@ -193,7 +193,7 @@ def test_errors_are_loud(fns):
     import ctypes
     from hyperreel_amd import lib, plan
     L = lib.load()
-    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
     h = ctypes.c_void_p()
     assert L.hr_model_create(ctypes.byref(hc), ctypes.byref(h)) == 0
     assert L.hr_model_finalize(h) == -4 and b'never uploaded' in L.hr_last_error()
@@ -438,9 +438,9 @@ def test_cascade_intermediates_and_ragged_counts(case, precision):
     g = Golden(case)
     video = g.rays.shape[1] == 8
     rays = scenes.random_rays(515, 9, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
-    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision, iteration=g.iteration)
     out = render_np(fn, rays, want=('distances', 'render_weights'))
-    ref = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(rays, keep='all')
+    ref = HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(rays, keep='all')
     Z = ref['distances'].shape[1]
     assert Z == 32
     d_ref = ref['distances'].reshape(-1, Z)
@@ -464,9 +464,9 @@ def test_dead_column_pruning_changes_nothing(case, monkeypatch):
     the last Linear; with HR_PRUNE=0 it keeps them.  Same arithmetic on the live columns -> bit-identical images."""
     from gpu_common import make_render_fn, render_np
     g = Golden(case)
-    pruned = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict), g.rays)['rgb']
+    pruned = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration), g.rays)['rgb']
     monkeypatch.setenv('HR_PRUNE', '0')
-    full = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict), g.rays)['rgb']
+    full = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration), g.rays)['rgb']
     assert np.array_equal(pruned, full)
 
 
@@ -533,7 +533,7 @@ def test_upsample_volume_grid_matches_interpolate(fns, case):
     from gpu_common import make_render_fn, render_np
     from hyperreel_oracle import HyperReelOracle
     g = Golden(case)
-    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     net = fn.model.color_model.net
     old = {k: v.detach().cpu().clone() for k, v in net.named_parameters() if 'plane' in k or 'line' in k}
     target = [57, 49, 41]
@@ -550,3 +550,23 @@ def test_upsample_volume_grid_matches_interpolate(fns, case):
     out = render_np(fn, g.rays)['rgb']
     ref_rgb = HyperReelOracle(g.cfg, g.dataset, new_sd).render(g.rays)['rgb']
     assert linf(out, ref_rgb) <= RGB_TOL
+
+
+@pytest.mark.parametrize('case', ['sweep/variant_ease_iter0', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000'])
+def test_set_iter_moves_an_existing_model_through_its_schedules(case):
+    """INRSystem.set_train_iter -> model.set_iter(i) every step (nlf/__init__.py:608-614): the same native handle renders
+    the converged image, the in-window image of the reference (golden rendered at that iteration) and the converged one
+    again -- hr_model_update_config swaps constants only."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)              # never told an iteration: converged
+    converged = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(g.rays)['rgb']
+    handle = fn.model.native().value
+    assert linf(render_np(fn, g.rays)['rgb'], converged) <= RGB_TOL
+    fn.model.set_iter(g.iteration)
+    assert linf(render_np(fn, g.rays)['rgb'], g.rgb) <= RGB_TOL
+    assert linf(g.rgb, converged) > 1e-3              # the schedules are active at that iteration
+    fn.model.set_iter(10_000_000)
+    assert linf(render_np(fn, g.rays)['rgb'], converged) <= RGB_TOL
+    assert fn.model.native().value == handle                          # no re-creation, no re-upload

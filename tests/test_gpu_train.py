@@ -10,11 +10,13 @@ from torch_port import TorchPort
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small']
+CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
+         # inside the EaseValue / WindowedPE warm-up windows: the derivative carries the schedule weights
+         'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000']
 
 
 def _reference_grads(g, rays, G, white):
-    port = TorchPort(g.cfg, g.dataset, g.state_dict)
+    port = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     leaves = {}
     for name, grp in (('d_a', port.d_a), ('d_b', port.d_b), ('a_a', port.a_a), ('a_b', port.a_b)):
         for j, t in enumerate(grp):
@@ -39,7 +41,7 @@ def test_training_gradients_match_autograd_of_the_reference_restatement(case, wh
     G = np.random.default_rng(3).standard_normal((n, 3)).astype(np.float32)
     rgb_ref, ref = _reference_grads(g, rays, G, white)
 
-    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='fp32')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='fp32', iteration=g.iteration)
     fn.train()
     model = fn.model
     rgb = model.forward_train(torch.from_numpy(rays).cuda(), white_bg=bool(white))

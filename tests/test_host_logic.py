@@ -168,3 +168,28 @@ def test_cascade_creation_contract():
     assert rc in (0, -3)                                   # created (GPU present) or "no HIP device"
     if rc == 0:
         L.hr_model_destroy(h)
+
+
+def test_ease_value_and_windowed_pe_weights():
+    """nlf/activations.py:462-496 and nlf/pe.py:166-208 restated in plan.py: the weights the host folds into hr_config."""
+    ev = {'type': 'ease_value', 'start_value': 1.0, 'window_iters': 12000, 'wait_iters': 4000, 'activation': 'sigmoid'}
+    assert plan.ease_weight(ev, None) == 1.0
+    assert plan.ease_weight(ev, 0) == 0.0 and plan.ease_weight(ev, 4000) == 0.0
+    assert plan.ease_weight(ev, 10000) == 0.5 and plan.ease_weight(ev, 16000) == 1.0 and plan.ease_weight(ev, 10**7) == 1.0
+    zero = dict(ev, window_iters=0)
+    assert plan.ease_weight(zero, 3999) == 0.0 and plan.ease_weight(zero, 4000) == 1.0
+    with plan.at_iteration(10000):
+        a = plan._act(ev)
+    assert a.type == 1 and a.outer == 0.5 and a.add == 0.5
+    a = plan._act(ev)
+    assert a.outer == 1.0 and a.add == 0.0
+    pe = {'type': 'windowed', 'n_freqs': 4, 'max_freq_iter': 8000, 'wait_iters': 0}
+    assert plan.windowed_pe_weights(pe, None) == [1.0] * 4
+    w = plan.windowed_pe_weights(pe, 3000)
+    assert w[0] == 1.0 and abs(w[1] - 0.5) < 1e-12 and w[2] == 0.0 and w[3] == 0.0
+    assert plan.windowed_pe_weights(pe, 8001) == [1.0] * 4
+    # the converged configuration is what a model that was never told an iteration compiles to
+    # (INRSystem rewrites *_epochs into *_iters before it builds the model, nlf/__init__.py:305-315)
+    cfg, ds = C.epoch_to_iter(C.model_config('donerf_sphere'), 4000), C.dataset_scalars('donerf_sphere')
+    a = bytes(plan.compile_config(cfg, ds, [8, 8, 8]))
+    assert a == bytes(plan.compile_config(cfg, ds, [8, 8, 8], iteration=10**7)) != bytes(plan.compile_config(cfg, ds, [8, 8, 8], iteration=2000))

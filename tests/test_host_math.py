@@ -50,8 +50,8 @@ def test_features_and_embedding_match_oracle(hm, case):
     g = Golden(case)
     if plan.is_cascade(g.cfg):
         pytest.skip('two-level models are exercised end to end on the GPU')
-    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
-    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     rays = np.ascontiguousarray(g.rays[:300], np.float32)
     n = rays.shape[0]
     assert rays.shape[1] == hc.ray_dim

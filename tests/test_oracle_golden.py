@@ -10,7 +10,7 @@ from hyperreel_oracle import HyperReelOracle
 @pytest.mark.parametrize('case', golden_cases())
 def test_oracle_matches_reference_golden(case):
     g = Golden(case)
-    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict)
+    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     out = orc.render(g.rays, keep='all')
     # fp32 on both sides; only BLAS summation order / libm ulps differ
     assert linf(out['rgb'], g.rgb) <= 2e-5
@@ -40,14 +40,14 @@ def test_torch_port_matches_reference_golden(case):
     """The multi-threaded torch-op port used as bench.py's CPU baseline computes the same image."""
     from torch_port import TorchPort
     g = Golden(case)
-    out = TorchPort(g.cfg, g.dataset, g.state_dict).render(g.rays)
+    out = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(g.rays)
     assert linf(out['rgb'], g.rgb) <= 2e-5
 
 
 @pytest.mark.parametrize('case', sweep_cases())
 def test_oracle_matches_reference_on_every_accepted_shipped_yaml(case):
     g = Golden(case)
-    out = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(g.rays)
+    out = HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(g.rays)
     assert np.isfinite(g.rgb).all() and g.rgb.std() > 0.02
     assert linf(out['rgb'], g.rgb) <= 2e-5
 
@@ -63,3 +63,13 @@ def test_sweep_coverage_matches_the_plan_compiler():
     # nothing the reference can run is left out
     left = {k: v for k, v in cov.items() if v['status'] != 'golden' and v.get('reference_runs')}
     assert not left, left
+
+
+@pytest.mark.parametrize('case', [c for c in sweep_cases() if 'iter' in c])
+def test_schedule_fixtures_sit_inside_their_windows(case):
+    """The *_iterN fixtures were rendered by the reference at training iteration N (model.set_iter(N)): the EaseValue /
+    WindowedPE schedules must actually be active there, i.e. the converged model renders a different image."""
+    g = Golden(case)
+    assert g.iteration is not None
+    converged = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(g.rays)['rgb']
+    assert linf(converged, g.rgb) > 1.5e-4          # 10x what the oracle itself is held to

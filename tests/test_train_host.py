@@ -67,16 +67,18 @@ def pack_grids(port, video):
     return planes, packed, app_off
 
 
-CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small']
+CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
+         # inside the EaseValue warm-up windows: eased activations (outer * w, + (1 - w) * start_value) in forward and derivative
+         'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_ease_iter0']
 
 
 @pytest.mark.parametrize('white', [0, 1])
 @pytest.mark.parametrize('case', CASES)
 def test_backward_matches_autograd(ht, case, white):
     g = Golden(case)
-    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
     assert ht.ht_unsupported(C.byref(hc)) is None
-    port = TorchPort(g.cfg, g.dataset, g.state_dict)
+    port = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     n = min(192, g.rays.shape[0])
     rays = torch.from_numpy(np.ascontiguousarray(g.rays[:n], np.float32))
     grids = [t for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp]
