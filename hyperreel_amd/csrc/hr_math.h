@@ -81,7 +81,9 @@ HR_FN float hr_apply_act(const hr_act& a, float x)
     } else if (a.type == HR_ACT_TANH) {
         y = tanhf(y);
     }
-    return y * a.outer + a.add;      // add: the (1 - w) * start_value term of an EaseValue inside its window, else 0
+    // add: the (1 - w) * start_value term of an EaseValue inside its window, else 0 (one fma either way; with add == 0 it
+    // rounds exactly like the plain product)
+    return fmaf(y, a.outer, a.add);
 }
 
 // The same activation for heads that only feed continuous quantities (point offsets, flow, colour scale / shift)
@@ -95,7 +97,7 @@ HR_FN float hr_apply_act_post(const hr_act& a, float x)
         const float e = __expf(2.0f * fminf(fmaxf(y, -15.0f), 15.0f));
         y = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
     }
-    return y * a.outer + a.add;
+    return __builtin_fmaf(y, a.outer, a.add);
 #else
     return hr_apply_act(a, x);
 #endif
