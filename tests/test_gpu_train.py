@@ -149,3 +149,35 @@ def test_regularizers_match_the_reference_formulas(case):
         scale = float(p.grad.abs().max())
         assert float((got[id(p)] - p.grad).abs().max()) <= 1e-5 * scale + 1e-12
     assert n >= 3
+
+
+def test_flat_gradient_views_receive_the_hip_gradients():
+    """parallel.FlatGradients (the data-parallel reduction buffer): autograd accumulates the HIP path's gradients into
+    views of one flat buffer, identical to the stand-alone .grad tensors."""
+    from gpu_common import make_render_fn
+    from hyperreel_amd.parallel import FlatGradients
+    g = Golden('donerf_sphere_small')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    fn.train()
+    model = fn.model
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:128], np.float32)).cuda()
+    G = torch.from_numpy(np.random.default_rng(1).standard_normal((128, 3)).astype(np.float32)).cuda()
+    params = [p for p in model.parameters() if p.requires_grad]
+    (model.forward_train(rays, white_bg=False) * G).sum().backward()
+    plain = [None if p.grad is None else p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    flat = FlatGradients(params)
+    flat.zero()
+    (model.forward_train(rays, white_bg=False) * G).sum().backward()
+    flat.all_reduce()                                   # single process: no-op
+    o = 0
+    for p, ref in zip(flat.params, plain):
+        got = flat.flat[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+        assert p.grad.data_ptr() == got.data_ptr()
+        if ref is None:
+            assert not got.any()
+        else:
+            # scatter-adds are not ordered: equal up to fp32 summation order
+            assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12

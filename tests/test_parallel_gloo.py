@@ -100,3 +100,53 @@ def test_camera_sharding_assembles_the_frame(tmp_path, wh):
     ref = _FakeCameraModel().render_camera(None, None, wh[0], wh[1]).numpy()
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f'cam{r}.npy'), ref)
+
+
+def _train_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from hyperreel_amd.parallel import FlatGradients
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)                                         # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.LeakyReLU(0.01), torch.nn.Linear(16, 3))
+    plane = torch.nn.Parameter(torch.rand(1, 4, 8, 8))
+    params = list(net.parameters()) + [plane]
+    flat = FlatGradients(params)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    g = torch.Generator().manual_seed(100 + rank)               # every rank its own ray batch
+    for step in range(3):
+        x = torch.randn(32, 6, generator=g)
+        flat.zero()
+        loss = (net(x) * plane.mean()).pow(2).mean()
+        loss.backward()
+        local = flat.flat.clone()
+        flat.all_reduce()
+        if step == 0:
+            torch.save({'local': local, 'reduced': flat.flat.clone()}, os.path.join(out_dir, f'g{rank}.pt'))
+        if step == 1:
+            opt.zero_grad(set_to_none=True)                      # someone drops the views: zero() must re-attach
+            flat.zero()
+            (net(x) * plane.mean()).pow(2).mean().backward()
+            flat.all_reduce()
+        opt.step()
+    torch.save([p.detach().clone() for p in params], os.path.join(out_dir, f'p{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradients_all_reduce_keeps_replicas_identical(tmp_path):
+    """Data-parallel training step: one all-reduce of the flat gradient buffer, world size 2 on gloo."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = [torch.load(tmp_path / f'g{r}.pt') for r in range(world)]
+    want = (g[0]['local'] + g[1]['local']) / 2
+    assert float(want.abs().max()) > 0 and not torch.equal(g[0]['local'], g[1]['local'])
+    for r in range(world):
+        assert torch.allclose(g[r]['reduced'], want, rtol=0, atol=1e-7)
+    p = [torch.load(tmp_path / f'p{r}.pt') for r in range(world)]
+    for a, b in zip(*p):
+        assert torch.equal(a, b)                                 # same averaged gradients -> bitwise identical replicas
