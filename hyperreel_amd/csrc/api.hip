@@ -607,6 +607,7 @@ static hr_config structure_of(const hr_config& in)
                       &c.f_color_shift.act, &c.f_spatial_flow.act, &c.f_color_scale_global.act, &c.f_color_shift_global.act,
                       &c.z_act, &c.flow_act, &c.offset_act, &c.color_table_t_act, &c.color_table_s_act};
     for (hr_act* a : acts) { a->outer = 0.0f; a->add = 0.0f; }
+    c.isect_mask_off = 0;                          // the near/far mask is dropped after mask.stop_iters (intersect/base.py:104-108)
     for (int g = 0; g < HR_MAX_GROUPS; ++g)
         for (int j = 0; j < HR_MAX_FREQS; ++j) c.groups[g].pe_weight[j] = 0.0f;
     return c;

@@ -453,7 +453,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     if ic.get('num_repeat', 1) != 1:
         raise NotImplementedError('intersect.num_repeat')
     if 'mask' in ic:                              # base.py:104-108,197-198; inference runs at iter 1e7
-        hc.isect_mask_off = int(10_000_000 > ic['mask'].get('stop_iters', float('inf')))
+        hc.isect_mask_off = int((10_000_000 if _ITERATION is None else _ITERATION) > ic['mask'].get('stop_iters', float('inf')))
     udb = ic.get('use_dataset_bounds', False)
     org = ic.get('origin', [0.0, 0.0, 0.0])
     for k in range(3):

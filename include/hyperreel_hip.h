@@ -252,7 +252,7 @@ int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes
 int hr_model_finalize(hr_model* m);
 
 /* Replaces the model's configuration by one that differs only in schedule-dependent constants -- the `outer` / `add`
- * of the activations (EaseValue) and `pe_weight` (WindowedPE) -- as INRSystem.set_train_iter does for the reference
+ * of the activations (EaseValue), `pe_weight` (WindowedPE) and `isect_mask_off` (mask.stop_iters) -- as INRSystem.set_train_iter does for the reference
  * modules every training step (nlf/__init__.py:608-614).  No weights are re-packed.  Any other difference is refused
  * with HR_E_INVALID.  Waits for `stream` before the device copies are replaced. */
 int hr_model_update_config(hr_model* m, const hr_config* cfg, void* stream);

@@ -456,7 +456,7 @@ class _Isect:
             raise NotImplementedError('use_disparity')
         # base.py:104-108,197-198: the near/far mask is dropped once cur_iter > mask.stop_iters (inference: 1e7)
         stop = c['mask'].get('stop_iters', float('inf')) if 'mask' in c else float('inf')
-        self.mask_on = not (10_000_000 > stop)
+        self.mask_on = not ((10_000_000 if ITERATION is None else ITERATION) > stop)
         t = self.isect_type
         if t == 'voxel_grid':                           # voxel.py:19-70: Z/3 planes per axis
             self._setup_voxel_grid(c, udb)

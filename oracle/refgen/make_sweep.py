@@ -148,6 +148,7 @@ VARIANTS = [
     ('variant_ease_iter6000', 'immersive_sphere', None, 6000),
     ('variant_ease_iter0', 'technicolor_z_plane', None, 0),
     ('variant_pe_window_iter3000', 'donerf_sphere', _v_pe_window, 3000),
+    ('variant_mask_stop_iter3', 'donerf_sphere', _v_mask_off_unsorted, 3),       # before mask.stop_iters = 5: the mask is still on
 ]
 
 

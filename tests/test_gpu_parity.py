@@ -552,7 +552,8 @@ def test_upsample_volume_grid_matches_interpolate(fns, case):
     assert linf(out, ref_rgb) <= RGB_TOL
 
 
-@pytest.mark.parametrize('case', ['sweep/variant_ease_iter0', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000'])
+@pytest.mark.parametrize('case', ['sweep/variant_ease_iter0', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000',
+                                  'sweep/variant_mask_stop_iter3'])
 def test_set_iter_moves_an_existing_model_through_its_schedules(case):
     """INRSystem.set_train_iter -> model.set_iter(i) every step (nlf/__init__.py:608-614): the same native handle renders
     the converged image, the in-window image of the reference (golden rendered at that iteration) and the converged one
