@@ -160,7 +160,6 @@ const char* hr_train_unsupported(const hr_config& c)
     if (c.casc_in_z != 0) return "point_prediction cascades";
     if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";
     if (c.color_table_views > 0) return "color_transform tables";
-    if (c.f_color_scale_global.offset >= 0) return "color_scale_global";
     if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) return "sphere_new / cylinder_new intersections";
     if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) return "deformable_voxel_grid";
     if ((c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) && c.origin_scale != 0.0f) return "origin_scale_factor != 0";
@@ -571,14 +570,33 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
         acc_w += wgt[k];
     }
     if (a.white_bg) { const float bg = 1.0f - acc_w; c0 += bg; c1 += bg; c2 += bg; }
+    const float cpre[3] = {c0, c1, c2};          // the composited colour before the per-ray scale / shift
+    float gscale[3] = {1.0f, 1.0f, 1.0f};
+    if (c.f_color_scale_global.offset >= 0) {    // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+        for (int i = 0; i < 3; ++i) gscale[i] = hr_apply_act(fs.act, head[fs.offset + i]) + 1.0f;
+        c0 = c0 * gscale[0] + hr_apply_act(fh.act, head[fh.offset + 0]);
+        c1 = c1 * gscale[1] + hr_apply_act(fh.act, head[fh.offset + 1]);
+        c2 = c2 * gscale[2] + hr_apply_act(fh.act, head[fh.offset + 2]);
+    }
     if (a.rgb) { a.rgb[ray * 3 + 0] = c0; a.rgb[ray * 3 + 1] = c1; a.rgb[ray * 3 + 2] = c2; }
     if (!a.d_rgb) return;
 
     // ---- backward
-    const float g[3] = {a.d_rgb[ray * 3 + 0], a.d_rgb[ray * 3 + 1], a.d_rgb[ray * 3 + 2]};
-    const float gsum = a.white_bg ? (g[0] + g[1] + g[2]) : 0.0f;
+    float g[3] = {a.d_rgb[ray * 3 + 0], a.d_rgb[ray * 3 + 1], a.d_rgb[ray * 3 + 2]};
     float* dhead = a.d_head + ray * (int64_t)Z * P;
     for (int i = 0; i < Z * P; ++i) dhead[i] = 0.0f;
+    if (c.f_color_scale_global.offset >= 0) {
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+        for (int i = 0; i < 3; ++i) {
+            dhead[fs.offset + i] += g[i] * cpre[i] * hr_act_grad(fs.act, head[fs.offset + i]);
+            dhead[fh.offset + i] += g[i] * hr_act_grad(fh.act, head[fh.offset + i]);
+            g[i] = g[i] * gscale[i];             // everything below sees the gradient of the un-scaled colour
+        }
+    }
+    const float gsum = a.white_bg ? (g[0] + g[1] + g[2]) : 0.0f;
     float ddc[ZP];                // dL / d final distance
     float dfeat[ZP];
     for (int k = 0; k < Z; ++k) ddc[k] = 0.0f;

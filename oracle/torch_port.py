@@ -38,7 +38,7 @@ class TorchPort:
         self.dev = torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.layers = [(t(w), t(b)) for w, b in o.layers]
-        self.samples = t(o.samples)
+        self.samples = t(o.samples) if hasattr(o, 'samples') else None      # voxel_grid keeps per-axis anchors instead
         self.aabb = t(o.aabb)
         self.inv_size = t(o.inv_size)
         self.basis = t(o.basis)
@@ -61,16 +61,23 @@ class TorchPort:
                 x = F.leaky_relu(x, 0.01)
         return x
 
-    def _contract_points(self, p):                          # nlf/contract.py:178-192
+    def _contract_points(self, p):                          # nlf/contract.py:178-192 (mipnerf), :84-85 / :110-111 (affine)
         c = self.o.contract
+        if hasattr(c, 'bbox_min'):
+            lo = torch.from_numpy(c.bbox_min).to(self.dev)
+            return (p - lo) / (torch.from_numpy(c.bbox_max).to(self.dev) - lo)
+        if not hasattr(c, 'r0'):
+            return p / float(c.fac)
         p = p / c.r0
         d = torch.norm(p, dim=-1, keepdim=True)
         inv_end = c.r0 / c.r1
         t = (1.0 / d.abs() - inv_end) * (1.0 / (1.0 - inv_end))
         return torch.where(d < 1, p, (p / d) * (2.0 - t))
 
-    def _inv_contract_distance(self, z):                    # nlf/contract.py:143-158
+    def _inv_contract_distance(self, z):                    # nlf/contract.py:143-158 (mipnerf), :78-79 / :104-105 (affine)
         c = self.o.contract
+        if not hasattr(c, 'r0'):
+            return z * float(c.fac) if hasattr(c, 'fac') else z
         inv_end = c.d0 / c.d1
         z = (z / 2.0) * 2.0
         z = z.clamp(-2.0, 2.0)
@@ -122,7 +129,12 @@ class TorchPort:
         H.ITERATION = o.iteration                           # stages build their activations while they run
         B, Z = rays.shape[0], o.Z
         x = {}
-        h = self._mlp(self._param_pe(rays)) if head is None else head
+        if head is not None:
+            h = head
+        elif o.zero_net:                                    # ZeroMLP, nlf/nets/mlp.py:14-33
+            h = torch.zeros(B, Z * sum(o.out_shapes), device=self.dev)
+        else:
+            h = self._mlp(self._param_pe(rays))
         h = h.view(B, Z, -1)
         off = 0
         for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
@@ -136,11 +148,30 @@ class TorchPort:
             z = z * float(o.z_scale) + self.samples[None]
             return self._inv_contract_distance(z) if o.contract.contract_samples else z
 
-        if o.isect_type == 'z_plane':                       # z.py:77-97, intersect_utils.py:127-150
+        if o.isect_type == 'euclidean_distance_unified':    # primitive.py:162-176, param.py:297-307
+            z = proc(zv.reshape(B, Z))
+            dn = F.normalize(r[:, 3:6], p=2.0, dim=-1)
+            pos = torch.cross(dn, torch.cross(r[:, :3], dn, dim=-1), dim=-1)
+            diff = pos - r[:, :3]
+            dists = z + (torch.sign((r[:, 3:6] * diff).sum(-1)) * torch.norm(diff, dim=-1))[:, None]
+        elif o.isect_type == 'voxel_grid':                  # voxel.py:72-112, intersect_utils.py:152-179
+            nz = Z // 3
+            z = zv.reshape(B, nz, 3) * torch.from_numpy(o.voxel_scale).to(self.dev)[None, None] \
+                + torch.from_numpy(o.voxel_samples).to(self.dev)[None]
+            if o.contract.contract_samples:
+                z = self._inv_contract_distance(z)
+            if o.outward_facing:
+                z = z * torch.sign(r[:, None, 3:6])
+            d = r[:, None, 3:6]
+            d = torch.where(d.abs() < 1e-5, torch.full_like(d, 1e12), d)
+            dists = ((z - r[:, None, 0:3]) / d).reshape(B, Z)
+        elif o.isect_type == 'z_plane':                     # z.py:77-97, intersect_utils.py:127-150
             z = proc(zv.reshape(B, Z))
             d = r[:, None, 3:6]
             d = torch.where(d.abs() < 1e-5, torch.full_like(d, 1e12), d)
             dists = (z - r[:, None, 2]) / d[..., 2]
+        elif o.isect_type not in ('sphere', 'cylinder'):
+            raise NotImplementedError(o.isect_type)
         else:                                               # primitive.py:420-438 / 235-253
             origins = zv[..., :3] * float(o.origin_scale) + torch.from_numpy(o.origin_initial).to(self.dev)[None, None]
             radii = proc(zv[..., 3])
@@ -157,14 +188,15 @@ class TorchPort:
             t1 = torch.where(disc <= 0, torch.zeros_like(t1), t1)
             t2 = torch.where(disc <= 0, torch.zeros_like(t2), t2)
             dists = torch.where((t2 < 0) | (radii < 0), t1, t2)
-        mask = (dists <= float(o.near)) | (dists >= float(o.far))
-        dists = torch.where(mask, torch.zeros_like(dists), dists)
+        if o.mask_on:
+            mask = (dists <= float(o.near)) | (dists >= float(o.far))
+            dists = torch.where(mask, torch.zeros_like(dists), dists)
         if o.sort:
             dists = torch.sort(dists, dim=1)[0]
         dists = dists[..., None]
         mask = dists == 0
         points = r[:, None, :3] + r[:, None, 3:6] * dists
-        if hasattr(o.contract, 'r0'):                       # contract.py:43-50
+        if hasattr(o.contract, 'contract_points'):          # contract.py:43-50
             oc = self._contract_points(r[:, :3])
             points = self._contract_points(points)
             dists = torch.norm(points - oc[:, None], dim=-1, keepdim=True)
@@ -243,6 +275,8 @@ class TorchPort:
         out = (weight[..., None] * rgb).sum(-2)
         if o.white_bg if white_bg is None else white_bg:
             out = out + (1.0 - weight.sum(-1)[:, None])
+        if 'color_scale_global' in x:                       # scale_shift_color_one, tensorf_utils.py:275-281
+            out = out * (x['color_scale_global'][:, 0, :] + 1.0) + x['color_shift_global'][:, 0, :]
         return out if train else out.clamp(0, 1)
 
     @torch.no_grad()

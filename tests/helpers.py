@@ -55,3 +55,19 @@ class Golden:
 
 def linf(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0
+
+
+def trainable_sweep_cases():
+    """Sweep fixtures whose model the training path differentiates (mirror of hr_train_unsupported, csrc/hr_train.h) --
+    which are also the ones oracle/torch_port.py restates."""
+    from hyperreel_amd import plan
+    out = []
+    for c in sweep_cases():
+        g = Golden(c)
+        if plan.is_cascade(g.cfg):
+            continue
+        hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+        if hc.isect_type in (3, 4, 7) or hc.color_table_views > 0 or (hc.isect_type in (1, 2) and hc.origin_scale != 0):
+            continue
+        out.append(c)
+    return out

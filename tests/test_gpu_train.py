@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
          # inside the EaseValue / WindowedPE warm-up windows: the derivative carries the schedule weights
-         'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000']
+         'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000',
+         # voxel-grid and closest-point intersections, per-ray colour scale, z-depth contraction
+         'sweep/donerf_voxel', 'sweep/catacaustics_distance', 'sweep/variant_z_depth_contract']
 
 
 def _reference_grads(g, rays, G, white):

@@ -3,7 +3,7 @@ made by oracle/refgen/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import Golden, golden_cases, linf, sweep_cases, sweep_coverage
+from helpers import Golden, trainable_sweep_cases, golden_cases, linf, sweep_cases, sweep_coverage
 from hyperreel_oracle import HyperReelOracle
 
 
@@ -73,3 +73,13 @@ def test_schedule_fixtures_sit_inside_their_windows(case):
     assert g.iteration is not None
     converged = HyperReelOracle(g.cfg, g.dataset, g.state_dict).render(g.rays)['rgb']
     assert linf(converged, g.rgb) > 1.5e-4          # 10x what the oracle itself is held to
+
+
+@pytest.mark.parametrize('case', trainable_sweep_cases())
+def test_torch_port_matches_reference_on_the_trainable_shipped_yamls(case):
+    """oracle/torch_port.py is the autograd reference of the training path's gradient checks: its forward is pinned here
+    against what the reference itself rendered for every model family those checks use."""
+    from torch_port import TorchPort
+    g = Golden(case)
+    out = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(g.rays)
+    assert linf(out['rgb'], g.rgb) <= 2e-5

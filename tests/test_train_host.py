@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden
+from helpers import Golden, trainable_sweep_cases
 from hyperreel_amd import plan
 from torch_port import TorchPort
 
@@ -67,9 +67,12 @@ def pack_grids(port, video):
     return planes, packed, app_off
 
 
-CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
-         # inside the EaseValue warm-up windows: eased activations (outer * w, + (1 - w) * start_value) in forward and derivative
-         'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_ease_iter0']
+# the five benchmark families, then every shipped model YAML (and variant) the training path accepts: z-plane / sphere /
+# cylinder / voxel-grid / closest-point intersections, mip-NeRF-360 / bbox / z-depth / no contraction, static and keyframe
+# grids, RGB and SH shading, per-sample and per-ray colour scale, ZeroMLP, unsorted / unmasked samples, and the
+# activation / encoding / mask schedules inside their windows
+CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small'] \
+    + trainable_sweep_cases()
 
 
 @pytest.mark.parametrize('white', [0, 1])
@@ -84,13 +87,32 @@ def test_backward_matches_autograd(ht, case, white):
     grids = [t for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp]
     for t in grids + [port.basis]:
         t.requires_grad_(True)
-    with torch.no_grad():
-        head0 = port._mlp(port._param_pe(rays))
-    head = head0.clone().requires_grad_(True)
-    rgb_ref = port.color(port.embed(rays, head=head), train=True, white_bg=bool(white))
-    gen = torch.Generator().manual_seed(3)
-    G = torch.randn(rgb_ref.shape, generator=gen)
-    (rgb_ref * G).sum().backward()
+
+    def reference(rays):
+        for t in grids + [port.basis]:
+            t.grad = None
+        with torch.no_grad():
+            if port.o.zero_net:                               # ZeroMLP (nlf/nets/mlp.py:14-33): the head is all zeros
+                head0 = torch.zeros(rays.shape[0], hc.z_channels * hc.preds_per_z)
+            else:
+                head0 = port._mlp(port._param_pe(rays))
+        head = head0.clone().requires_grad_(True)
+        rgb_ref = port.color(port.embed(rays, head=head), train=True, white_bg=bool(white))
+        G = torch.randn(rgb_ref.shape, generator=torch.Generator().manual_seed(3))
+        (rgb_ref * G).sum().backward()
+        return head0, head, rgb_ref, G
+
+    head0, head, rgb_ref, G = reference(rays)
+    ok = torch.isfinite(head.grad).all(-1)
+    if not bool(ok.all()):
+        # torch.autograd returns NaN where a masked-out branch divides by zero (a ray along the cylinder axis: a == 0 in
+        # intersect_utils.py:86-125; `torch.where` does not stop the NaN in backward).  The reference's own training step
+        # would be poisoned by such a ray; the kernel's derivative of the taken branch is finite.  Compare on the others.
+        assert int((~ok).sum()) <= 4
+        rays = rays[ok]
+        n = rays.shape[0]
+        head0, head, rgb_ref, G = reference(rays)
+        assert bool(torch.isfinite(head.grad).all())
 
     planes, packed, ca_total = pack_grids(port, port.o.video)
     gbuf = [(np.zeros_like(pa), np.zeros_like(pb)) for pa, pb, *_ in packed]
@@ -113,7 +135,8 @@ def test_backward_matches_autograd(ht, case, white):
         assert scale > 0, f'{what}: reference gradient is identically zero'
         assert err <= 2e-4 * scale + 1e-7, f'{what}: |err| {err:.3e} vs scale {scale:.3e}'
 
-    assert np.abs(rgb - rgb_ref.detach().numpy()).max() <= 1e-5
+    ref_np = rgb_ref.detach().numpy()
+    assert (np.abs(rgb - ref_np) <= 1e-5 * np.maximum(1.0, np.abs(ref_np))).all()      # unsorted / unmasked variants reach 1e5
     close(d_head, head.grad.numpy(), 'd head')
     P, ref_h = hc.preds_per_z, head.grad.numpy().reshape(n, hc.z_channels, -1)
     live = 0
@@ -123,7 +146,7 @@ def test_backward_matches_autograd(ht, case, white):
             live += 1
         else:
             assert not d_head.reshape(ref_h.shape)[..., col].any()
-    assert live >= 5
+    assert live >= 3
     close(d_basis, port.basis.grad.numpy(), 'd basis_mat')
     for j, (pa, pb, nd, na, aoff) in enumerate(packed):
         ga, gb = gbuf[j]
