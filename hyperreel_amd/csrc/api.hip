@@ -804,6 +804,15 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
     return HR_OK;
 }
 
+int hr_pack_display(const float* rgb_dev, int32_t h, int32_t w, int32_t transpose, int32_t flip, int32_t rgba8, void* out_dev, void* stream)
+{
+    if (h < 1 || w < 1) return fail(HR_E_INVALID, "bad image shape");
+    if (!rgb_dev || !out_dev) return fail(HR_E_INVALID, "null argument");
+    hr_launch_pack_display(rgb_dev, h, w, transpose ? 1 : 0, flip ? 1 : 0, rgba8 ? 1 : 0, out_dev, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 int hr_plane_reg_forward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, float* sums_dev, void* stream)
 {
     if (channels < 0 || h < 1 || w < 1) return fail(HR_E_INVALID, "bad plane shape");

@@ -89,6 +89,7 @@ void hr_launch_head_export(const float* head, float* out, int64_t n_rays, int Z,
                            const HrColMap& map,
                            hipStream_t stream);
 void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst, int H2, int W2, hipStream_t stream);
+void hr_launch_pack_display(const float* rgb, int h, int w, int transpose, int flip, int rgba8, void* out, hipStream_t stream);
 void hr_launch_plane_reg_forward(const float* p, int C, int H, int W, float* sums, hipStream_t stream);
 void hr_launch_plane_reg_backward(const float* p, int C, int H, int W, const float* coef, float* grad, hipStream_t stream);
 void hr_launch_deinterleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);

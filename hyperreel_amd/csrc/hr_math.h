@@ -536,4 +536,22 @@ HR_FN hr_axis_tap hr_make_tap(float g, int n)
     return t;
 }
 
+// ---------------------------------------------------------------- display pack
+// to8b (utils/__init__.py:47): (255 * clip(x, 0, 1)).astype(uint8) -- the product is formed in fp32 and truncated
+HR_FN uint8_t hr_to8b(float x)
+{
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    return (uint8_t)(255.0f * x);
+}
+
+// Source pixel of output pixel (y, x) of the viewer's buffer: NeRFGUI.test_step optionally transposes the (H, W) image
+// and then flips it vertically (utils/gui_utils.py:199-205).  (h, w): the RENDERED image; the output is (w, h) when
+// transposed.  Returns the row-major pixel index into the rendered image.
+HR_FN int64_t hr_display_src_pixel(int y, int x, int h, int w, int transpose, int flip)
+{
+    const int oh = transpose ? w : h;
+    if (flip) y = oh - 1 - y;
+    return transpose ? (int64_t)x * w + y : (int64_t)y * w + x;
+}
+
 #endif  // HR_MATH_H

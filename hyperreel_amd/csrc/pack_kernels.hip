@@ -1,5 +1,6 @@
 // One-time layout transforms run by hr_model_finalize (not on the render path).
 #include "hr_kernels.h"
+#include "hr_math.h"
 
 // Reference planes are channel-first (1, C, H, W) (nlf/nets/tensorf_base.py:911-948,
 // nlf/nets/tensorf_dynamic.py:126-173).  The sample kernel wants channel-last texels with
@@ -187,4 +188,34 @@ void hr_launch_plane_reg_backward(const float* p, int C, int H, int W, const flo
     const int64_t n = (int64_t)C * H * W;
     if (n <= 0) return;
     hipLaunchKernelGGL(hr_plane_reg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n, H, W, coef, grad);
+}
+
+// ---------------------------------------------------------------- display pack
+// rgb (h * w, 3) fp32 -> the viewer's buffer: optional transpose + vertical flip (utils/gui_utils.py:199-205) and either
+// 8-bit RGBA (to8b, utils/__init__.py:47; alpha 255) or fp32 RGB (what dearpygui's raw texture takes).  One pass on the
+// device instead of `.cpu().numpy()` + numpy transpose / flip / ascontiguousarray on the host; a quarter of the bytes
+// cross PCIe when the consumer wants 8-bit pixels.
+__global__ __launch_bounds__(256) void hr_pack_display_kernel(const float* __restrict__ rgb, int h, int w, int transpose, int flip, int rgba8,
+                                                              void* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)h * w) return;
+    const int ow = transpose ? h : w;
+    const int64_t src = hr_display_src_pixel((int)(i / ow), (int)(i % ow), h, w, transpose, flip);
+    const float r = rgb[src * 3 + 0], g = rgb[src * 3 + 1], b = rgb[src * 3 + 2];
+    if (rgba8) {
+        uchar4 px;
+        px.x = hr_to8b(r); px.y = hr_to8b(g); px.z = hr_to8b(b); px.w = 255;
+        reinterpret_cast<uchar4*>(out)[i] = px;
+    } else {
+        float* o = reinterpret_cast<float*>(out) + i * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+}
+
+void hr_launch_pack_display(const float* rgb, int h, int w, int transpose, int flip, int rgba8, void* out, hipStream_t stream)
+{
+    const int64_t n = (int64_t)h * w;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(hr_pack_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rgb, h, w, transpose, flip, rgba8, out);
 }

@@ -475,6 +475,22 @@ class HipLightfieldModel(nn.Module):
         its host round trips: pose -> rays -> rgb, all on the device and on the current stream."""
         return self.render(self.generate_rays(pose, K, width, height, time, cam_id, pixel_range))['rgb']
 
+    def pack_display(self, rgb, height, width, transpose=False, flip=False, rgba8=True):
+        """The viewer's hand-over (utils/gui_utils.py:174-205) on the device: rgb (H*W, 3) as rendered -> the displayed
+        buffer, transposed / flipped as NeRFGUI does on the host, as 8-bit RGBA (to8b, utils/__init__.py:47) or fp32 RGB."""
+        import ctypes as C
+        oh, ow = (width, height) if transpose else (height, width)
+        rgb = rgb.contiguous().float()
+        if rgb.device.type != 'cuda' or rgb.numel() != height * width * 3:
+            raise ValueError('rgb must be a (H*W, 3) tensor on the HIP device')
+        out = torch.empty((oh, ow, 4), dtype=torch.uint8, device=rgb.device) if rgba8 else \
+            torch.empty((oh, ow, 3), dtype=torch.float32, device=rgb.device)
+        with torch.cuda.device(rgb.device):
+            _lib.check(_lib.load().hr_pack_display(C.c_void_p(rgb.data_ptr()), int(height), int(width), int(bool(transpose)), int(bool(flip)),
+                                                   int(bool(rgba8)), C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(rgb.device).cuda_stream)), 'hr_pack_display')
+        return out
+
     def forward_train(self, rays, white_bg=None):
         """One differentiable forward of the training step (nlf/__init__.py:634-709 calls `self(coords)` in train mode):
         rgb (B, 3) WITHOUT the eval-mode clamp, with autograd history to the MLP, the planes / lines and basis_mat.

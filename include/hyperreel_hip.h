@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 12
+#define HR_ABI_VERSION 13
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -312,6 +312,12 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
  * not accumulated), for the parameter values of the last hr_train_forward / hr_model_finalize. */
 int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
                       int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream);
+
+/* Viewer hand-over: rgb_dev (h * w, 3) float32 as hr_render wrote it -> out_dev, the buffer NeRFGUI.test_step
+ * builds on the host (utils/gui_utils.py:174-205): transposed to (w, h) if `transpose`, then flipped vertically if `flip`;
+ * rgba8 != 0: 4 bytes per pixel, to8b(x) = (uint8)(255 * clip(x, 0, 1)) (utils/__init__.py:47) and alpha 255;
+ * rgba8 == 0: 3 floats per pixel, values unchanged. */
+int hr_pack_display(const float* rgb_dev, int32_t h, int32_t w, int32_t transpose, int32_t flip, int32_t rgba8, void* out_dev, void* stream);
 
 /* TensoRF regularisers of one (1, C, H, W) float32 plane (TVLoss, nlf/regularizers/tensorf.py:14-34; density_L1,
  * nlf/nets/tensorf_base.py:1024-1035), no model involved.  Forward ADDS to sums_dev[3] =

@@ -84,4 +84,17 @@ void hm_inverse_contract_distance(const hr_config* c, const float* d, int n, flo
     for (int i = 0; i < n; ++i) out[i] = hr_inverse_contract_distance(*c, d[i]);
 }
 
+// display pack: to8b and the viewer's transpose / flip index map
+void hm_to8b(const float* x, int n, unsigned char* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = hr_to8b(x[i]);
+}
+
+void hm_display_map(int h, int w, int transpose, int flip, long long* src)
+{
+    const int oh = transpose ? w : h, ow = transpose ? h : w;
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < ow; ++x) src[(long long)y * ow + x] = hr_display_src_pixel(y, x, h, w, transpose, flip);
+}
+
 }  // extern "C"

@@ -137,3 +137,26 @@ def test_contraction_properties(hm):
     cf = np.asarray([contract.contract_distance(v) for v in far], np.float32)
     hm.hm_inverse_contract_distance(C.byref(hc), fp(cf), cf.size, fp(far))
     assert np.allclose(far, d1, rtol=1e-5)
+
+
+def test_display_pack_matches_the_viewer_host_code(hm):
+    """hr_to8b == utils/__init__.py:47 to8b; hr_display_src_pixel == NeRFGUI.test_step's transpose(1, 0, 2) then
+    np.flip(axis=0) (utils/gui_utils.py:199-205).  The device kernel is these two functions per output pixel."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-0.2, 1.2, 20000), np.arange(256) / 255.0, np.nextafter(np.arange(256) / 255.0, 2),
+                        [0.0, 1.0, -0.0, 0.5, 1e-9, 0.999999, np.float32(1) - np.float32(2 ** -24)]]).astype(np.float32)
+    got = np.zeros(x.shape, np.uint8)
+    hm.hm_to8b(fp(x), x.size, got.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert np.array_equal(got, (255 * np.clip(x, 0, 1)).astype(np.uint8))
+    h, w = 5, 7
+    img = np.arange(h * w).reshape(h, w)
+    for transpose in (0, 1):
+        for flip in (0, 1):
+            ref = img
+            if transpose:
+                ref = ref.transpose(1, 0)
+            if flip:
+                ref = np.flip(ref, axis=0)
+            src = np.zeros(h * w, np.int64)
+            hm.hm_display_map(h, w, transpose, flip, src.ctypes.data_as(C.POINTER(C.c_longlong)))
+            assert np.array_equal(src.reshape(ref.shape), ref)
