@@ -149,6 +149,182 @@ HR_FN float hr_quadratic_t_grad_radius(float oo, float dd, float od, float radiu
     return ((t2 < 0.0f) || (radius < 0.0f)) ? g : -g;
 }
 
+// ---------------------------------------------------------------- forward-mode duals for the long intersections
+// sphere_new / cylinder_new (primitive.py:305-363, 490-545: primitive frame from 6 head channels, sample recycling),
+// deformable_voxel_grid (voxel.py:178-213: learned plane normals) and sphere / cylinder with learned origins
+// (primitive.py:410-431) map up to 8 activated head channels of a sample to one distance.  Their derivative is taken
+// by carrying the 8 partials through the same arithmetic as hr_sample_distance (value part identical), not by a
+// hand-derived adjoint.
+#define HR_DN 8
+struct hr_dual {
+    float v;
+    float d[HR_DN];
+};
+HR_FN hr_dual hr_dconst(float v)
+{
+    hr_dual r;
+    r.v = v;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = 0.0f;
+    return r;
+}
+HR_FN hr_dual hr_dvar(float v, int i)
+{
+    hr_dual r = hr_dconst(v);
+    r.d[i] = 1.0f;
+    return r;
+}
+// r = f(x) with known f(x.v) and f'(x.v)
+HR_FN hr_dual hr_dchain(const hr_dual& x, float fv, float fp)
+{
+    hr_dual r;
+    r.v = fv;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = fp * x.d[i];
+    return r;
+}
+HR_FN hr_dual operator+(const hr_dual& a, const hr_dual& b)
+{
+    hr_dual r;
+    r.v = a.v + b.v;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+HR_FN hr_dual operator-(const hr_dual& a, const hr_dual& b)
+{
+    hr_dual r;
+    r.v = a.v - b.v;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+HR_FN hr_dual operator*(const hr_dual& a, const hr_dual& b)
+{
+    hr_dual r;
+    r.v = a.v * b.v;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+HR_FN hr_dual operator/(const hr_dual& a, const hr_dual& b)
+{
+    hr_dual r;
+    r.v = a.v / b.v;
+    for (int i = 0; i < HR_DN; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+    return r;
+}
+HR_FN hr_dual operator+(const hr_dual& a, float b) { hr_dual r = a; r.v = a.v + b; return r; }
+HR_FN hr_dual operator-(const hr_dual& a, float b) { hr_dual r = a; r.v = a.v - b; return r; }
+HR_FN hr_dual operator-(float a, const hr_dual& b) { return hr_dconst(a) - b; }
+HR_FN hr_dual operator*(const hr_dual& a, float b) { return hr_dchain(a, a.v * b, b); }
+HR_FN hr_dual operator*(float a, const hr_dual& b) { return hr_dchain(b, a * b.v, a); }
+HR_FN hr_dual operator-(const hr_dual& a) { return hr_dchain(a, -a.v, -1.0f); }
+HR_FN hr_dual hr_dsqrt(const hr_dual& a)
+{
+    const float s = sqrtf(a.v);
+    return hr_dchain(a, s, 0.5f / s);
+}
+HR_FN hr_dual hr_ddot3(const hr_dual* a, const hr_dual* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+// torch.norm of a 3-vector: the sub-gradient at 0 is 0
+HR_FN hr_dual hr_dnorm3(const hr_dual* a)
+{
+    const hr_dual ss = hr_ddot3(a, a);
+    const float n = sqrtf(ss.v);
+    return hr_dchain(ss, n, n > 0.0f ? 0.5f / n : 0.0f);
+}
+// F.normalize(p=2, eps=1e-12)
+HR_FN void hr_dnormalize3(const hr_dual* a, hr_dual* r)
+{
+    const hr_dual n = hr_dnorm3(a);
+    if (n.v > 1e-12f) { r[0] = a[0] / n; r[1] = a[1] / n; r[2] = a[2] / n; }
+    else { r[0] = a[0] * 1e12f; r[1] = a[1] * 1e12f; r[2] = a[2] * 1e12f; }
+}
+HR_FN void hr_dcross3(const hr_dual* a, const hr_dual* b, hr_dual* r)
+{
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+HR_FN void hr_dpluecker_pos(const hr_dual* o, const hr_dual* d, hr_dual* pos)
+{
+    hr_dual dn[3], m[3];
+    hr_dnormalize3(d, dn);
+    hr_dcross3(o, dn, m);
+    hr_dcross3(dn, m, pos);
+}
+HR_FN hr_dual hr_dsigned_base_distance(const hr_dual* d, const hr_dual* diff)
+{
+    return hr_dnorm3(diff) * hr_sign(hr_ddot3(d, diff).v);
+}
+HR_FN hr_dual hr_dquadratic_t(const hr_dual& oo, const hr_dual& dd, const hr_dual& od, const hr_dual& radius)
+{
+    const hr_dual a = dd, b = od * 2.0f, cc = oo - radius * radius;
+    const hr_dual disc = b * b - (a * cc) * 4.0f;
+    if (disc.v <= 0.0f) return hr_dconst(0.0f);             // clamped, and t replaced by the constant 0
+    const hr_dual sq = hr_dsqrt(disc + 1e-8f);
+    const hr_dual t1 = (sq - b) / (a * 2.0f), t2 = (-b - sq) / (a * 2.0f);
+    return ((t2.v < 0.0f) || (radius.v < 0.0f)) ? t1 : t2;
+}
+HR_FN hr_dual hr_dprocess_z(const hr_config& c, const hr_dual& z, float scale, float anchor)
+{
+    const hr_dual x = z * scale + anchor;
+    if (!c.contract_samples) return x;
+    return hr_dchain(x, hr_inverse_contract_distance(c, x.v), hr_inverse_contract_distance_grad(c, x.v));
+}
+// hr_sample_distance before the mask for the intersections above; zv[ch]: activated z_vals channel ch times (1 - sigma)
+HR_FN hr_dual hr_sample_distance_dual(const hr_config& c, const hr_dual* zv, int k, const float* ro, const float* rd)
+{
+    if (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) {        // primitive.py:410-431
+        hr_dual o[3], d[3];
+        for (int i = 0; i < 3; ++i) {
+            const hr_dual s = zv[i] * c.origin_scale + c.origin_initial[i];
+            o[i] = s * ro[i];
+            d[i] = s * rd[i];
+        }
+        const hr_dual radius = hr_dprocess_z(c, zv[3], c.z_scale, c.samples[k]);
+        if (c.isect_type == HR_ISECT_SPHERE) return hr_dquadratic_t(hr_ddot3(o, o), hr_ddot3(d, d), hr_ddot3(o, d), radius);
+        return hr_dquadratic_t(o[0] * o[0] + o[2] * o[2], d[0] * d[0] + d[2] * d[2], o[0] * d[0] + o[2] * d[2], radius);
+    }
+    if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) {                               // voxel.py:184-213
+        const int axis = k % c.dvg_axes;
+        hr_dual n0[3], n[3];
+        for (int i = 0; i < 3; ++i) n0[i] = zv[i] * c.dvg_normal_scale + c.dvg_normals[3 * axis + i];
+        hr_dnormalize3(n0, n);
+        const hr_dual dplane = hr_dprocess_z(c, zv[3], c.z_scale, c.samples[k]);
+        const hr_dual o_n = (n[0] * ro[0] + n[1] * ro[1]) + n[2] * ro[2];
+        hr_dual d_n = (n[0] * rd[0] + n[1] * rd[1]) + n[2] * rd[2];
+        if (fabsf(d_n.v) < 1e-5f) d_n = hr_dconst(1e12f);
+        return (dplane - o_n) / d_n;
+    }
+    // sphere_new / cylinder_new, primitive.py:498-545, :313-363 (hr_isect_new)
+    hr_dual o[3], d[3], dn[3];
+    for (int i = 0; i < 3; ++i) {
+        const hr_dual org = zv[i] * c.origin_scale;
+        const hr_dual rs = zv[3 + i] * c.resize_scale + c.resize_initial[i];
+        o[i] = (ro[i] - org) * rs;
+        d[i] = rs * rd[i];
+    }
+    const hr_dual raw = hr_dprocess_z(c, zv[6], c.z_scale, c.samples[k]);
+    const hr_dual radius = hr_dprocess_z(c, zv[7], c.z_scale, c.samples[k]);
+    const hr_dual dnorm = hr_dnorm3(d);
+    hr_dnormalize3(d, dn);
+    hr_dual t, min_radius, base_distance;
+    if (c.isect_type == HR_ISECT_SPHERE_NEW) {
+        t = hr_dquadratic_t(hr_ddot3(o, o), hr_ddot3(dn, dn), hr_ddot3(o, dn), radius);
+        hr_dual pos[3];
+        hr_dpluecker_pos(o, dn, pos);
+        min_radius = hr_dnorm3(pos);
+        const hr_dual diff[3] = {pos[0] - o[0], pos[1] - o[1], pos[2] - o[2]};
+        base_distance = hr_dsigned_base_distance(dn, diff);
+    } else {
+        t = hr_dquadratic_t(o[0] * o[0] + o[2] * o[2], dn[0] * dn[0] + dn[2] * dn[2], o[0] * dn[0] + o[2] * dn[2], radius);
+        const hr_dual oc[3] = {o[0], hr_dconst(0.0f), o[2]}, dc[3] = {dn[0], hr_dconst(0.0f), dn[2]};
+        hr_dual pos[3];
+        hr_dpluecker_pos(oc, dc, pos);
+        min_radius = hr_dnorm3(pos);
+        const hr_dual diff[3] = {pos[0] - oc[0], pos[1] - oc[1], pos[2] - oc[2]};
+        base_distance = hr_dsigned_base_distance(dc, diff) / hr_dnorm3(dc);
+    }
+    if (fabsf(radius.v) < min_radius.v + 4.0f * c.z_scale) t = raw + base_distance;
+    return t / (dnorm + 1e-5f);
+}
+
 // Which models the training path differentiates.  Returns NULL when supported, else the reason.
 #if defined(__HIPCC__)
 __host__ __device__ inline
@@ -160,9 +336,6 @@ const char* hr_train_unsupported(const hr_config& c)
     if (c.casc_in_z != 0) return "point_prediction cascades";
     if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";
     if (c.color_table_views > 0) return "color_transform tables";
-    if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) return "sphere_new / cylinder_new intersections";
-    if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) return "deformable_voxel_grid";
-    if ((c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) && c.origin_scale != 0.0f) return "origin_scale_factor != 0";
     return nullptr;
 }
 
@@ -178,6 +351,29 @@ HR_FN void hr_sample_distance_bwd(const hr_config& c, const float* hk, int k, co
     float sigma = 0.0f;
     if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
     const float one_m = 1.0f - sigma;
+    const bool origins = (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) && c.origin_scale != 0.0f;
+    if (origins || c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW ||
+        c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) {
+        // several head channels per sample: partials carried through the forward arithmetic (hr_sample_distance_dual)
+        const int nch = (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) ? 8 : 4;
+        float zact[HR_DN];
+        hr_dual zv[HR_DN];
+        for (int i = 0; i < HR_DN; ++i) {
+            zact[i] = (i < nch) ? hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + i])) : 0.0f;
+            zv[i] = hr_dvar(zact[i] * one_m, i);
+        }
+        const hr_dual dist = hr_sample_distance_dual(c, zv, k, ro, rd);
+        float dsum = 0.0f;                       // dL / d (1 - sigma)
+        for (int i = 0; i < nch; ++i) {
+            const float g = dt * dist.d[i];
+            if (g == 0.0f) continue;
+            dhk[c.f_z_vals.offset + i] += g * one_m * hr_act2_grad(c.z_act, c.f_z_vals.act, hk[c.f_z_vals.offset + i]);
+            dsum += g * zact[i];
+        }
+        if (c.f_isect_sigma.offset >= 0)
+            dhk[c.f_isect_sigma.offset] += -dsum * hr_act_grad(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
+        return;
+    }
     int ch = 0;
     float scale = c.z_scale;
     float dzp;                                   // dL / d processed z (or radius)

@@ -170,6 +170,60 @@ class TorchPort:
             d = r[:, None, 3:6]
             d = torch.where(d.abs() < 1e-5, torch.full_like(d, 1e12), d)
             dists = (z - r[:, None, 2]) / d[..., 2]
+        elif o.isect_type in ('sphere_new', 'cylinder_new'):     # primitive.py:305-363, 490-545
+            def nrm(v):
+                return torch.norm(v, dim=-1)
+
+            def ppos(oo, dd):                                     # param.py:297-307
+                dn_ = F.normalize(dd, p=2.0, dim=-1)
+                return torch.cross(dn_, torch.cross(oo, dn_, dim=-1), dim=-1)
+
+            def quad(oo, dd, radii):
+                a = (dd * dd).sum(-1)
+                b = 2 * (oo * dd).sum(-1)
+                c = (oo * oo).sum(-1) - radii * radii
+                disc = b * b - 4 * a * c
+                disc = torch.where(disc < 0, torch.zeros_like(disc), disc)
+                sq = torch.sqrt(disc + 1e-8)
+                t1, t2 = (-b + sq) / (2 * a), (-b - sq) / (2 * a)
+                t1 = torch.where(disc <= 0, torch.zeros_like(t1), t1)
+                t2 = torch.where(disc <= 0, torch.zeros_like(t2), t2)
+                return torch.where((t2 < 0) | (radii < 0), t1, t2)
+
+            tn = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(self.dev)
+            origins = zv[..., :3] * float(o.origin_scale)
+            resize = zv[..., 3:6] * float(o.resize_scale) + tn(o.resize_initial)[None, None]
+            raw_offsets, radii = proc(zv[..., 6]), proc(zv[..., 7])
+            ro = (r[:, None, 0:3] - origins) * resize
+            rd = r[:, None, 3:6] * resize
+            rn = F.normalize(rd, p=2.0, dim=-1)
+            if o.isect_type == 'sphere_new':
+                tt = quad(ro, rn, radii)
+                base_pos = ppos(ro, rn)
+                min_radius = nrm(base_pos)
+                diff = base_pos - ro
+                base_distance = torch.sign((rn * diff).sum(-1)) * nrm(diff)
+            else:
+                xz = lambda v: torch.stack([v[..., 0], torch.zeros_like(v[..., 1]), v[..., 2]], -1)
+                tt = quad(ro[..., [0, 2]], rn[..., [0, 2]], radii)
+                o_c, d_c = xz(ro), xz(rn)
+                base_pos = ppos(o_c, d_c)
+                min_radius = nrm(base_pos)
+                diff = base_pos - o_c
+                base_distance = torch.sign((d_c * diff).sum(-1)) * nrm(diff) / nrm(d_c)
+            recycle = radii.abs() < min_radius + 4.0 * float(o.z_scale)
+            tt = torch.where(recycle, raw_offsets + base_distance, tt)
+            dists = tt / (nrm(rd) + 1e-5)
+        elif o.isect_type == 'deformable_voxel_grid':            # voxel.py:178-213, intersect_utils.py:210-236
+            normals0 = torch.from_numpy(o.dvg_normals).to(self.dev)
+            na = normals0.shape[0]
+            dpl = proc(zv[..., 3])
+            normal = zv[..., :3].reshape(-1, na, 3) * float(o.dvg_scale) + normals0[None]
+            normal = F.normalize(normal.reshape(B, -1, 3), p=2.0, dim=-1)
+            o_n = (r[:, None, :3] * normal).sum(-1)
+            d_n = (r[:, None, 3:6] * normal).sum(-1)
+            d_n = torch.where(d_n.abs() < 1e-5, torch.full_like(d_n, 1e12), d_n)
+            dists = (dpl - o_n) / d_n
         elif o.isect_type not in ('sphere', 'cylinder'):
             raise NotImplementedError(o.isect_type)
         else:                                               # primitive.py:420-438 / 235-253

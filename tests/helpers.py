@@ -67,7 +67,7 @@ def trainable_sweep_cases():
         if plan.is_cascade(g.cfg):
             continue
         hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
-        if hc.isect_type in (3, 4, 7) or hc.color_table_views > 0 or (hc.isect_type in (1, 2) and hc.origin_scale != 0):
+        if hc.color_table_views > 0:
             continue
         out.append(c)
     return out
