@@ -288,9 +288,9 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
  * caller's column order, and hr_train_backward returns dL/d head for it.
  * All tensors are device memory, float32, in the reference's parameter layouts (same shapes as the hr_model_upload
  * names): a[j] = density_plane.j | density_plane_space.j, b[j] = density_line.j | density_plane_time.j, likewise app_*.
- * Supported: single-level models with z_plane / sphere / cylinder (origin_scale_factor 0) / voxel_grid /
- * euclidean_distance_unified intersections and float32 grids; anything else returns HR_E_INVALID and names the feature.
- * Activation schedules are those of the compiled configuration (the converged EaseValue / WindowedPE weights). */
+ * Supported: every single-level model hr_model_create accepts, with float32 grids and without a color_transform table;
+ * point_prediction cascades, color_transform tables and float16 grids return HR_E_INVALID naming the feature.
+ * Activation / encoding / mask schedules are those of the model's current configuration (hr_model_update_config). */
 typedef struct hr_train_tensors {
     float* density_a[3];
     float* density_b[3];
