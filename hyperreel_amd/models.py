@@ -267,6 +267,7 @@ class HipLightfieldModel(nn.Module):
         self._native_key = None
         self._native_cfg = None        # bytes of the hr_config the native handle currently holds
         self._sched_built = None       # cur_iter that configuration was compiled at
+        self._native_box = None        # (data_ptr, version) of the net's aabb buffer the handle was created for
         # fail on configurations outside the supported path now, not at the first render
         self._compile(grid)
 
@@ -278,7 +279,9 @@ class HipLightfieldModel(nn.Module):
 
     def _compile(self, grid):
         """-> (coarse hr_config or None, hr_config of the level that renders), schedules evaluated at cur_iter."""
-        return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype, iteration=self.cur_iter)
+        # the box is the net's buffer, not the YAML's value: `shrink` replaces it during training and checkpoints carry it
+        aabb = self.color_model.net.aabb.detach().cpu().numpy() if hasattr(self, 'color_model') else None
+        return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype, iteration=self.cur_iter, aabb=aabb)
 
     # -- reference surface ---------------------------------------------------------
     def set_iter(self, i):
@@ -328,7 +331,9 @@ class HipLightfieldModel(nn.Module):
     def _param_key(self):
         # cheap fingerprint of everything the native model was built from: in-place
         # updates bump ._version, re-allocations change data_ptr/shape
-        return (self.mlp_precision, self.grid_dtype) + tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
+        net = self.color_model.net
+        return (self.mlp_precision, self.grid_dtype, net.aabb.data_ptr(), net.aabb._version) + \
+            tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in self.parameters())
 
     def _sync_schedule(self, hc=None, coarse=None):
         """Hands the configuration compiled at cur_iter to an existing native handle if it differs from what it holds."""
@@ -368,13 +373,14 @@ class HipLightfieldModel(nn.Module):
                 _lib.check(L.hr_model_create_cascade(C.byref(coarse), C.byref(hc), C.byref(h)), 'hr_model_create_cascade')
             self._native = h
             self._native_grid = self.grid_size
+            self._native_box = (self.color_model.net.aabb.data_ptr(), self.color_model.net.aabb._version)
             self._native_cfg = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
 
         with torch.cuda.device(dev):
             if self._native is None:
                 create()
             elif self._native_grid != self.grid_size or self._hc.mlp_precision != hc.mlp_precision \
-                    or self._hc.grid_dtype != hc.grid_dtype:
+                    or self._hc.grid_dtype != hc.grid_dtype or list(self._hc.aabb) != list(hc.aabb):
                 L.hr_model_destroy(self._native)
                 create()
             torch.cuda.current_stream().synchronize()
@@ -497,7 +503,8 @@ class HipLightfieldModel(nn.Module):
         white_bg: this step's background; default = the reference's draw `white_bg or rand() < 0.5` unless black_bg
         (tensorf_no_sample.py:236).  The activation schedules are the converged ones (see set_iter)."""
         from . import train as T
-        if self._native is None or self._native_grid != self.grid_size:
+        box = self.color_model.net.aabb
+        if self._native is None or self._native_grid != self.grid_size or self._native_box != (box.data_ptr(), box._version):
             self.native()
         elif self._sched_built != self.cur_iter:
             self._sync_schedule()

@@ -101,6 +101,9 @@ class hr_fields(C.Structure):
 # --------------------------------------------------------------------------- small helpers
 # Training iteration the schedules are evaluated at while compile_config runs (None: converged, every weight 1)
 _ITERATION = None
+# Bounding box of the feature grids when it is not the YAML's: TensorBase keeps `aabb` as a buffer that `shrink`
+# replaces during training (nlf/nets/tensorf_base.py:1191-1232) and that checkpoints therefore carry
+_AABB = None
 
 
 def ease_weight(cfg, iteration):
@@ -151,17 +154,20 @@ class at_iteration:
     """with at_iteration(i): compile_* evaluates the EaseValue / WindowedPE schedules at training iteration i
     (None: converged).  INRSystem.set_train_iter (nlf/__init__.py:608-614) is the reference's equivalent."""
 
-    def __init__(self, iteration):
-        self.iteration = iteration
+    def __init__(self, iteration, aabb='inherit'):
+        self.iteration, self.aabb = iteration, aabb
 
     def __enter__(self):
-        global _ITERATION
-        self.prev, _ITERATION = _ITERATION, self.iteration
+        global _ITERATION, _AABB
+        self.prev = (_ITERATION, _AABB)
+        _ITERATION = self.iteration
+        if not isinstance(self.aabb, str):
+            _AABB = self.aabb
         return self
 
     def __exit__(self, *exc):
-        global _ITERATION
-        _ITERATION = self.prev
+        global _ITERATION, _AABB
+        _ITERATION, _AABB = self.prev
         return False
 
 
@@ -644,7 +650,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     hc.video = int(n['type'] == 'tensor_vm_split_time')
     if 'filter' in n:
         raise NotImplementedError('net.filter (apply_filter_weights)')
-    aabb = np.asarray(n['aabb'], F32)
+    aabb = np.asarray(n['aabb'] if _AABB is None else _AABB, F32).reshape(2, 3)
     for k in range(3):
         hc.aabb[k], hc.aabb[3 + k] = float(aabb[0][k]), float(aabb[1][k])
     inv = F32(2.0) / (aabb[1] - aabb[0])      # tensorf_base.py:296-297
@@ -760,10 +766,11 @@ def compile_cascade(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='f
     return hc0, hc1
 
 
-def compile_model(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', iteration=None):
+def compile_model(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp32', iteration=None, aabb=None):
     """-> (coarse hr_config or None, hr_config of the rendering level): cascade-aware front door.
-    iteration: training iteration of the activation / PE schedules (None: converged, what render and test use)."""
-    with at_iteration(iteration):
+    iteration: training iteration of the activation / PE schedules (None: converged, what render and test use).
+    aabb: the colour net's `aabb` buffer ((2, 3); None: the YAML's `color.net.aabb`)."""
+    with at_iteration(iteration, aabb):
         if is_cascade(cfg):
             return compile_cascade(cfg, dataset, grid_size, mlp_precision, grid_dtype)
         return None, compile_config(cfg, dataset, grid_size, mlp_precision, grid_dtype)

@@ -27,3 +27,20 @@ def test_pack_display_matches_the_viewer_host_path(transpose, flip):
     assert np.array_equal(f32, ref)
     u8 = fn.model.pack_display(rgb, h, w, transpose, flip, rgba8=True).cpu().numpy()
     assert np.array_equal(u8[..., :3], (255 * np.clip(ref, 0, 1)).astype(np.uint8)) and (u8[..., 3] == 255).all()
+
+
+def test_a_checkpoint_with_a_shrunk_box_renders_in_that_box():
+    """`aabb` is a buffer of the colour net that training shrinks (tensorf_base.py:1191-1232); a checkpoint's value, not
+    the YAML's, is what the reference renders with (the oracle takes it from the state_dict too)."""
+    from gpu_common import make_render_fn, render_np
+    from hyperreel_oracle import HyperReelOracle
+    g = Golden('donerf_sphere_small')
+    sd = dict(g.state_dict)
+    box = np.asarray(sd['model.color_model.net.aabb'], np.float32).copy()
+    box[0] *= 0.8
+    box[1] *= 0.7
+    sd['model.color_model.net.aabb'] = box
+    fn = make_render_fn(g.cfg, g.dataset, sd)
+    ref = HyperReelOracle(g.cfg, g.dataset, sd).render(g.rays)['rgb']
+    assert np.abs(ref - g.rgb).max() > 1e-3                          # the box matters on these rays
+    assert np.abs(render_np(fn, g.rays)['rgb'] - ref).max() <= 1e-4

@@ -193,3 +193,20 @@ def test_ease_value_and_windowed_pe_weights():
     cfg, ds = C.epoch_to_iter(C.model_config('donerf_sphere'), 4000), C.dataset_scalars('donerf_sphere')
     a = bytes(plan.compile_config(cfg, ds, [8, 8, 8]))
     assert a == bytes(plan.compile_config(cfg, ds, [8, 8, 8], iteration=10**7)) != bytes(plan.compile_config(cfg, ds, [8, 8, 8], iteration=2000))
+
+
+def test_the_models_aabb_buffer_not_the_yaml_drives_the_compiled_box():
+    """TensorBase keeps `aabb` as a buffer that `shrink` replaces during training (nlf/nets/tensorf_base.py:1191-1232);
+    checkpoints carry it, and the reference renders with the loaded value.  So does the compiled configuration."""
+    import torch
+    from hyperreel_amd.models import HipLightfieldModel
+    cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf_sphere')
+    m = HipLightfieldModel(cfg, dataset=ds, grid_size=[8, 8, 8])
+    yaml_box = [v for row in C.to_plain(cfg.color.net.aabb) for v in row]
+    assert list(m._compile([8, 8, 8])[1].aabb) == pytest.approx(yaml_box)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['color_model.net.aabb'] = torch.tensor([[-1.5, -1.0, -0.5], [1.0, 1.5, 2.0]])
+    m.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    hc = m._compile([8, 8, 8])[1]
+    assert list(hc.aabb) == [-1.5, -1.0, -0.5, 1.0, 1.5, 2.0]
+    assert list(hc.inv_size) == pytest.approx([2 / 2.5, 2 / 2.5, 2 / 2.5])
