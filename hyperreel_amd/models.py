@@ -308,6 +308,11 @@ class HipLightfieldModel(nn.Module):
                     k = k[len(pre):]
                     break
             sd[k] = v
+        # the alpha mask a trained checkpoint carries (nlf/__init__.py:437-447,472-479) is kept but not read: the colour
+        # net's forward never consults it (`if self.alphaMask is not None and False`, tensorf_no_sample.py:171)
+        mask = {k: sd.pop(k) for k in list(sd) if 'alpha_aabb' in k or 'alpha_volume' in k}
+        if mask:
+            self.color_model.net.alpha_mask_state = mask
         gs = sd.get('color_model.net.gridSize')
         if gs is not None and [int(x) for x in gs.tolist()] != self.grid_size:
             self.color_model.net.init_svd_volume([int(x) for x in gs.tolist()])

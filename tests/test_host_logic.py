@@ -207,6 +207,11 @@ def test_the_models_aabb_buffer_not_the_yaml_drives_the_compiled_box():
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     sd['color_model.net.aabb'] = torch.tensor([[-1.5, -1.0, -0.5], [1.0, 1.5, 2.0]])
     m.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    # ... together with the alpha mask of a trained checkpoint, which this path never reads (tensorf_no_sample.py:171)
+    sd['color_model.net.alphaMask.alpha_aabb'] = sd['color_model.net.aabb'].clone()
+    sd['color_model.net.alphaMask.alpha_volume'] = torch.ones(1, 1, 4, 4, 4)
+    m.load_state_dict({'model.' + k: v for k, v in sd.items()}, strict=True)
+    assert set(m.color_model.net.alpha_mask_state) == {'color_model.net.alphaMask.alpha_aabb', 'color_model.net.alphaMask.alpha_volume'}
     hc = m._compile([8, 8, 8])[1]
     assert list(hc.aabb) == [-1.5, -1.0, -0.5, 1.0, 1.5, 2.0]
     assert list(hc.inv_size) == pytest.approx([2 / 2.5, 2 / 2.5, 2 / 2.5])
