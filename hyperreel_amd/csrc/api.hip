@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "hr_kernels.h"
+#include "hr_mask.h"
 #include "hr_train.h"
 
 namespace {
@@ -800,6 +801,34 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
     if (channels < 0 || h < 1 || w < 1 || h2 < 1 || w2 < 1) return fail(HR_E_INVALID, "bad plane shape");
     if (channels > 0 && (!src_dev || !dst_dev)) return fail(HR_E_INVALID, "null plane");
     hr_launch_upsample_plane(src_dev, channels, h, w, dst_dev, h2, w2, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_dense_alpha(hr_model* m, const int32_t n[3], float length, int32_t num_frames, const float* prev_volume_dev, const int32_t prev_n[3],
+                   const float prev_aabb[6], float* alpha_dev, void* stream)
+{
+    if (!m || !n || !alpha_dev) return fail(HR_E_INVALID, "null argument");
+    if (m->is_coarse) return fail(HR_E_INVALID, "the coarse level of a cascade has no grids");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called (or tensors changed since)");
+    if (m->cfg.grid_dtype != HR_GRID_FP32) return fail(HR_E_INVALID, "hr_dense_alpha reads float32 grids");
+    if (n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(HR_E_INVALID, "bad lattice size");
+    if (m->cfg.video && num_frames < 1) return fail(HR_E_INVALID, "keyframe nets need num_frames");
+    if (prev_volume_dev && (!prev_n || !prev_aabb || prev_n[0] < 1 || prev_n[1] < 1 || prev_n[2] < 1))
+        return fail(HR_E_INVALID, "previous mask without its size / box");
+    if (!m->ucfg_dev) {
+        HR_HIP(hipMalloc((void**)&m->ucfg_dev, sizeof(hr_config)));
+        HR_HIP(hipMemcpy(m->ucfg_dev, &m->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
+    }
+    HrMaskArgs a = HrMaskArgs();
+    a.cfg_dev = m->ucfg_dev;
+    for (int j = 0; j < 3; ++j) { a.planes[j] = m->planes[j]; a.n[j] = n[j]; a.pn[j] = prev_volume_dev ? prev_n[j] : 0; }
+    for (int j = 0; j < 6; ++j) a.prev_aabb[j] = prev_volume_dev ? prev_aabb[j] : 0.0f;
+    a.length = length;
+    a.num_frames = num_frames;
+    a.prev_volume = prev_volume_dev;
+    a.alpha = alpha_dev;
+    hr_launch_dense_alpha(a, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }

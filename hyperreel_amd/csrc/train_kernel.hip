@@ -14,6 +14,7 @@
 //     in a loop) per DoNeRF step before.  The ray's decode matrix and its gradient live in LDS (ds_add_f32);
 //   phase C (intersection backward): one thread per (ray, sample), elementwise.
 #include "hr_kernels.h"
+#include "hr_mask.h"
 #include "hr_train.h"
 
 template <int ZP>
@@ -145,4 +146,23 @@ void hr_launch_deinterleave(const float* src, float* dst, int C, int H, int W, i
     const int64_t n = (int64_t)C * H * W;
     if (n <= 0) return;
     hipLaunchKernelGGL(hr_deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, C, H, W, tex, c_off);
+}
+
+// Occupancy of the grids (hr_mask.h): one thread per lattice point, z fastest -- neighbouring threads read neighbouring
+// line texels and the same plane texel rows.  8 M points (200^3) x 16 density channels x 6 taps: a few hundred microseconds,
+// twice per training run (update_AlphaMask_list).
+__global__ __launch_bounds__(256) void hr_dense_alpha_kernel(const hr_config* __restrict__ cfgp, const HrMaskArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n12 = (int64_t)a.n[1] * a.n[2];
+    if (i >= n12 * a.n[0]) return;
+    const int x = (int)(i / n12), y = (int)((i - (int64_t)x * n12) / a.n[2]), z = (int)(i % a.n[2]);
+    a.alpha[i] = hr_point_alpha(*cfgp, a, x, y, z);
+}
+
+void hr_launch_dense_alpha(const HrMaskArgs& args, hipStream_t stream)
+{
+    const int64_t n = (int64_t)args.n[0] * args.n[1] * args.n[2];
+    if (n <= 0) return;
+    hipLaunchKernelGGL(hr_dense_alpha_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }

@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 
@@ -41,6 +41,8 @@ SYMBOLS = [
                                    C.c_void_p]),
     ('hr_train_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                     C.POINTER(hr_train_tensors), C.c_void_p]),
+    ('hr_dense_alpha', C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                 C.c_void_p, C.c_void_p]),
     ('hr_pack_display', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ('hr_plane_reg_forward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ('hr_plane_reg_backward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

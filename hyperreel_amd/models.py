@@ -113,6 +113,21 @@ class HostTensorVM(nn.Module):
         self.app_dim = int(net_cfg.get('data_dim_color', 27))
         self.num_keyframes = int(num_keyframes)
         self.act = net_cfg.get('fea2denseAct', 'softplus')
+        self.alpha_mask_thres = float(net_cfg.get('alpha_mask_thre', 0.001))         # tensorf_base.py:206-208
+        self.update_alpha_mask_list = [int(v) for v in net_cfg.get('update_AlphaMask_list', [])]
+        self._owner = None                       # weakref to the HipLightfieldModel (set by it): native handle for getDenseAlpha
+        # growth schedule of the grids (tensorf_base.py:150-198): log-linear between the start and end resolutions
+        self.upsamp_list = [int(v) for v in net_cfg.get('upsamp_list', [])]
+        n_up = len(self.upsamp_list) + 1
+        steps = lambda a, b: torch.round(torch.exp(torch.linspace(math.log(a), math.log(b), n_up))).long().tolist()[1:]
+        self.use_grid_size_upsample = 'grid_size' in net_cfg
+        if self.use_grid_size_upsample:
+            gs, ge = list(net_cfg['grid_size']['start']), list(net_cfg['grid_size']['end'])
+            self.N_voxel_list = [steps(gs[i], ge[i]) for i in range(3)]
+        elif 'N_voxel_init' in net_cfg and 'N_voxel_final' in net_cfg:
+            self.N_voxel_list = steps(net_cfg['N_voxel_init'], net_cfg['N_voxel_final'])
+        else:
+            self.N_voxel_list = []
         self.register_buffer('aabb', torch.tensor(to_plain(net_cfg['aabb']), dtype=torch.float32))
         self.register_buffer('gridSize', torch.tensor([int(v) for v in grid_size], dtype=torch.long))
         self.basis_mat = nn.Linear(sum(self.n_app), self.app_dim, bias=False)
@@ -147,7 +162,105 @@ class HostTensorVM(nn.Module):
             self.app_line = mk(app, line(self.n_app))
 
     def set_iter(self, i):
+        """TensorBase.set_iter (tensorf_base.py:510-552): in training mode, at the iterations of update_AlphaMask_list the
+        occupancy mask is rebuilt (at most 200^3) and, the first time, the grids are shrunk to it; at the iterations of
+        upsamp_list the grids grow to the next resolution of N_voxel_list / grid_size."""
         self.cur_iter = i
+        if not self.training:
+            return
+        if i in self.update_alpha_mask_list:
+            reso = tuple(int(v) for v in self.gridSize.tolist())
+            if reso[0] > 200:
+                reso = (200, 200, 200)
+            new_aabb = self.updateAlphaMask(reso)
+            if i == self.update_alpha_mask_list[0]:
+                self.shrink(new_aabb)
+        if i in self.upsamp_list and self.N_voxel_list:
+            if self.use_grid_size_upsample:
+                reso = [self.N_voxel_list[a].pop(0) for a in range(3)]
+            else:
+                reso = n_to_reso(self.N_voxel_list.pop(0), self.aabb.detach().cpu().tolist())
+            self.upsample_volume_grid(reso)
+
+    # -- occupancy / grid management of the training loop (TensorBase.set_iter, nlf/nets/tensorf_base.py:510-530) -------
+    @torch.no_grad()
+    def getDenseAlpha(self, grid_size):
+        """TensorBase.getDenseAlpha (tensorf_base.py:381-401) / TensorVMKeyframeTime.getDenseAlpha (tensorf_dynamic.py:499-536):
+        alpha = 1 - exp(-sigma * 0.01) on a dense (n0, n1, n2) lattice of the box (keyframe nets: the maximum over the
+        frames), points the current mask rejects get 0.  One HIP launch (hr_dense_alpha) on the owner's native model."""
+        import ctypes as C
+        owner = self._owner() if getattr(self, '_owner', None) is not None else None
+        if owner is None:
+            raise RuntimeError('getDenseAlpha needs the owning HipLightfieldModel (its native handle)')
+        h = owner.native()
+        n = [int(v) for v in grid_size]
+        dev = self.aabb.device
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        L = _lib.load()
+        vol = getattr(self, 'alpha_volume', None)
+        box = self.alpha_aabb.detach().cpu().reshape(-1).tolist() if vol is not None else [0.0] * 6
+        pn = [vol.shape[2], vol.shape[1], vol.shape[0]] if vol is not None else [0, 0, 0]
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_dense_alpha(h, (C.c_int32 * 3)(*n), C.c_float(0.01), int(owner.dataset.get('num_frames', 1)),
+                                        C.c_void_p(vol.contiguous().data_ptr()) if vol is not None else C.c_void_p(0),
+                                        (C.c_int32 * 3)(*pn), (C.c_float * 6)(*box), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'hr_dense_alpha')
+        return out
+
+    @torch.no_grad()
+    def updateAlphaMask(self, grid_size=(200, 200, 200)):
+        """TensorBase.updateAlphaMask (tensorf_base.py:403-429): dense alpha -> 3x3x3 max-pool -> threshold -> the mask
+        volume (stored like AlphaGridMask does, utils/tensorf_utils.py:459-475) and the bounding box of what is left."""
+        import torch.nn.functional as F
+        n = [int(v) for v in grid_size]
+        alpha = self.getDenseAlpha(n)
+        dev = alpha.device
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, n[0]), torch.linspace(0, 1, n[1]), torch.linspace(0, 1, n[2]),
+                                             indexing='ij'), -1).to(dev)
+        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(n[::-1])
+        thres = float(self.alpha_mask_thres)
+        alpha = (alpha >= thres).to(torch.float32)
+        self.register_buffer('alpha_volume', alpha, persistent=False)            # (n2, n1, n0)
+        self.register_buffer('alpha_aabb', self.aabb.clone(), persistent=False)
+        valid = dense_xyz[alpha > 0.5]
+        return torch.stack((valid.amin(0), valid.amax(0)))
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """TensorVMSplit.shrink (tensorf_base.py:1191-1232) / TensorVMKeyframeTime.shrink (tensorf_dynamic.py:444-497):
+        crops every plane and line to the texels that cover `new_aabb` and moves the box to those texels."""
+        new_aabb = new_aabb.to(self.aabb)
+        grid = self.gridSize.to(self.aabb.device)
+        units = (self.aabb[1] - self.aabb[0]) / (grid - 1)
+        t_l, b_r = (new_aabb[0] - self.aabb[0]) / units, (new_aabb[1] - self.aabb[0]) / units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, grid]).amin(0)
+        tl, br = t_l.tolist(), b_r.tolist()
+        P = lambda t: nn.Parameter(t.contiguous())
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            if self.video:
+                t0 = MAT_MODE_TIME[i][0]
+                for space, time in ((self.density_plane_space, self.density_plane_time), (self.app_plane_space, self.app_plane_time)):
+                    space[i] = P(space[i].data[..., tl[m1]:br[m1], tl[m0]:br[m0]])
+                    time[i] = P(time[i].data[..., :, tl[t0]:br[t0]])
+            else:
+                v = VEC_MODE[i]
+                for plane, line in ((self.density_plane, self.density_line), (self.app_plane, self.app_line)):
+                    line[i] = P(line[i].data[..., tl[v]:br[v], :])
+                    plane[i] = P(plane[i].data[..., tl[m1]:br[m1], tl[m0]:br[m0]])
+        mask_grid = torch.tensor([self.alpha_volume.shape[2], self.alpha_volume.shape[1], self.alpha_volume.shape[0]], device=grid.device)
+        if not torch.all(mask_grid == grid):
+            t_l_r, b_r_r = t_l / (grid - 1), (b_r - 1) / (grid - 1)
+            correct = torch.zeros_like(new_aabb)
+            correct[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct
+        self.aabb = new_aabb.clone()                 # a fresh buffer: the owner sees a new box and rebuilds its native model
+        self.gridSize = (b_r - t_l).to(self.gridSize)
 
     # -- regularizers, as the reference's TensoRF regularizer calls them (nlf/regularizers/tensorf.py:57-92) ----------
     def _reg_planes(self):
@@ -262,6 +375,8 @@ class HipLightfieldModel(nn.Module):
         self.param = _Dummy()
         self.embedding_model = HostEmbedding(cfg, mlp_layer_shapes(cfg), self.dataset)
         self.color_model = HostColorModel(net, grid, self.dataset['num_keyframes'])
+        import weakref
+        self.color_model.net._owner = weakref.ref(self)
         self.cur_iter = None           # training iteration of the activation / PE schedules; None = converged (see set_iter)
         self._native = None
         self._native_key = None

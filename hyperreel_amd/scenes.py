@@ -232,3 +232,34 @@ def benchmark_rays(model_name, H=800, W=800, frame=0, num_frames=50):
     else:
         pose = look_at_pose((0.3, 0.0, 0.0), (1.0, 0.1, 0.05))
     return pinhole_rays(H, W, 40.0, pose, cam_id=0 if video else None, time=t)
+
+
+def carve_density(sd, lo=(0.25, 0.3, 0.2), hi=(0.75, 0.8, 0.7)):
+    """Empties the scene outside a sub-box (fractions of each axis) so that occupancy tests have something to find:
+    only plane pair 0 keeps density, its plane vanishes outside [lo, hi] in x / y and its line (or, for keyframe nets,
+    the spatial axis of its time plane) outside [lo, hi] in z.  Returns a new dict."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if 'density_' not in k:
+            continue
+        v = v.copy()
+        j = int(k.rsplit('.', 1)[1])
+        if j != 0:
+            v[...] = 0.0
+        elif k.split('.')[-2] in ('density_plane', 'density_plane_space'):         # (1, C, Ny, Nx)
+            ny, nx = v.shape[2], v.shape[3]
+            keep = np.zeros((ny, nx), bool)
+            keep[int(lo[1] * ny):int(hi[1] * ny), int(lo[0] * nx):int(hi[0] * nx)] = True
+            v *= keep[None, None]
+        elif k.split('.')[-2] == 'density_line':                                   # (1, C, Nz, 1)
+            nz = v.shape[2]
+            keep = np.zeros(nz, bool)
+            keep[int(lo[2] * nz):int(hi[2] * nz)] = True
+            v *= keep[None, None, :, None]
+        else:                                                                      # density_plane_time (1, C, K, Nz)
+            nz = v.shape[3]
+            keep = np.zeros(nz, bool)
+            keep[int(lo[2] * nz):int(hi[2] * nz)] = True
+            v *= keep[None, None, None, :]
+        out[k] = v
+    return out

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 13
+#define HR_ABI_VERSION 14
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -312,6 +312,16 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
  * not accumulated), for the parameter values of the last hr_train_forward / hr_model_finalize. */
 int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
                       int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream);
+
+/* Occupancy of the feature grids: TensorBase.getDenseAlpha (nlf/nets/tensorf_base.py:381-401) and its keyframe
+ * override (nlf/nets/tensorf_dynamic.py:499-536) -- alpha = 1 - exp(-sigma * length) at the n[0] x n[1] x n[2] lattice points
+ * aabb0 * (1 - s) + aabb1 * s, s = linspace(0, 1, n) of the model's box, written to alpha_dev (n[0], n[1], n[2]) (x slowest);
+ * keyframe nets take the maximum over the `num_frames` frames of the sequence.  prev_volume_dev (D = prev_n[2], H = prev_n[1],
+ * W = prev_n[0]; may be NULL) is the previous mask with its box prev_aabb[6]: points where its trilinear sample
+ * (AlphaGridMask.sample_alpha, utils/tensorf_utils.py:459-484) is not positive get alpha 0, as in compute_alpha
+ * (tensorf_base.py:489-507).  The max-pool / threshold / crop that follow are host-side tensor ops. */
+int hr_dense_alpha(hr_model* m, const int32_t n[3], float length, int32_t num_frames, const float* prev_volume_dev, const int32_t prev_n[3],
+                   const float prev_aabb[6], float* alpha_dev, void* stream);
 
 /* Viewer hand-over: rgb_dev (h * w, 3) float32 as hr_render wrote it -> out_dev, the buffer NeRFGUI.test_step
  * builds on the host (utils/gui_utils.py:174-205): transposed to (w, h) if `transpose`, then flipped vertically if `flip`;

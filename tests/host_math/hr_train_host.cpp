@@ -3,6 +3,7 @@
 // Nothing in the product links or loads this file.
 #include <vector>
 
+#include "../../hyperreel_amd/csrc/hr_mask.h"
 #include "../../hyperreel_amd/csrc/hr_train.h"
 
 extern "C" {
@@ -56,6 +57,20 @@ int ht_train(const hr_config* c, const float* rays, const float* head, long long
     for (long long i = 0; i < n; ++i)                       // phase C
         for (int k = 0; k < c->z_channels; ++k) hr_sample_train_dist_bwd(*c, a, i, k);
     return 0;
+}
+
+// dense alpha of the grid (hr_mask.h) the way the device does it, one point after the other
+void ht_dense_alpha(const hr_config* c, const HrGridPlane* planes, const int* n, float length, int num_frames, const float* prev_volume,
+                    const int* pn, const float* prev_aabb, float* alpha)
+{
+    HrMaskArgs a = {};
+    a.cfg_dev = c;
+    for (int j = 0; j < 3; ++j) { a.planes[j] = planes[j]; a.n[j] = n[j]; a.pn[j] = pn ? pn[j] : 0; }
+    for (int j = 0; j < 6; ++j) a.prev_aabb[j] = prev_aabb ? prev_aabb[j] : 0.0f;
+    a.length = length; a.num_frames = num_frames; a.prev_volume = prev_volume; a.alpha = alpha;
+    for (int x = 0; x < n[0]; ++x)
+        for (int y = 0; y < n[1]; ++y)
+            for (int z = 0; z < n[2]; ++z) alpha[((size_t)x * n[1] + y) * n[2] + z] = hr_point_alpha(*c, a, x, y, z);
 }
 
 }  // extern "C"

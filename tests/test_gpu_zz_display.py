@@ -1,6 +1,6 @@
-"""`-m gpu`: hr_pack_display against the host code of the reference's viewer (utils/gui_utils.py:174-205, utils/__init__.py:47).
-(Collected last on purpose: the kernel was added after the round's GPU budget was spent and has only been checked through
-its host-compiled pieces, tests/test_host_math.py::test_display_pack_matches_the_viewer_host_code.)"""
+"""`-m gpu`: device runs of the pieces added after the round's GPU budget was spent -- hr_pack_display, a checkpoint with
+a shrunk box, hr_dense_alpha / updateAlphaMask / shrink.  Their arithmetic is checked on the CPU through the host builds of
+the same sources (tests/test_host_math.py, tests/test_alpha_mask_host.py); this file is collected last on purpose."""
 import numpy as np
 import pytest
 import torch
@@ -44,3 +44,32 @@ def test_a_checkpoint_with_a_shrunk_box_renders_in_that_box():
     ref = HyperReelOracle(g.cfg, g.dataset, sd).render(g.rays)['rgb']
     assert np.abs(ref - g.rgb).max() > 1e-3                          # the box matters on these rays
     assert np.abs(render_np(fn, g.rays)['rgb'] - ref).max() <= 1e-4
+
+
+@pytest.mark.parametrize('case', ['alpha_mask_static', 'alpha_mask_video'])
+def test_occupancy_mask_and_shrink_follow_the_reference(case):
+    """TensorBase.set_iter at an update_AlphaMask_list iteration (tensorf_base.py:510-530): hr_dense_alpha -> max-pool ->
+    threshold -> shrink, against what the reference's own code produced (tests/golden/mask, oracle/refgen/make_alpha_mask.py),
+    and the model still renders afterwards."""
+    import json
+    import os
+    from hyperreel_amd import config as cfgmod
+    from hyperreel_amd import scenes
+    from gpu_common import make_render_fn
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mask', case + '.npz'))
+    r = json.loads(bytes(z['recipe']).decode())
+    cfg, ds = cfgmod.model_config(r['model']), r['dataset']
+    sd = scenes.carve_density(scenes.make_state_dict(cfg, ds, r['grid'], r['seed'], 'dense', 1.0))
+    fn = make_render_fn(cfg, ds, sd)
+    net = fn.model.color_model.net
+    a1 = net.getDenseAlpha(r['n1'])
+    assert float((a1.cpu() - torch.from_numpy(z['alpha1'])).abs().max()) <= 1e-6
+    new_aabb = net.updateAlphaMask(r['n1'])
+    assert np.array_equal(net.alpha_volume.cpu().numpy(), z['mask_volume'])
+    net.shrink(new_aabb)
+    assert np.abs(net.aabb.cpu().numpy() - z['aabb_after']).max() <= 1e-6 and fn.model.grid_size == z['grid_after'].tolist()
+    a2 = net.getDenseAlpha(r['n2'])
+    assert float((a2.cpu() - torch.from_numpy(z['alpha2'])).abs().max()) <= 1e-6
+    video = cfg.color.net.type == 'tensor_vm_split_time'
+    rays = torch.from_numpy(scenes.random_rays(64, 3, video)).cuda()
+    assert bool(torch.isfinite(fn.model.render(rays)['rgb']).all())

@@ -31,7 +31,7 @@ class GridPlane(C.Structure):          # mirrors HrGridPlane (hyperreel_amd/csrc
 @pytest.fixture(scope='module')
 def ht():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ('hr_train.h', 'hr_math.h', 'hr_grid.h')] + [os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ('hr_train.h', 'hr_mask.h', 'hr_math.h', 'hr_grid.h')] + [os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', OUT, SRC], check=True)
     lib = C.CDLL(OUT)
