@@ -21,5 +21,25 @@ int main(void)
     printf("error text: %s\n", hr_last_error());
     hr_model_destroy(NULL);                                           /* no-op by contract */
     if (hr_render(NULL, NULL, 0, NULL, NULL) != HR_E_INVALID) return 5;
+    /* every other entry point refuses bad arguments before it touches the device */
+    {
+        hr_train_tensors t;
+        int32_t n3[3] = {2, 2, 2};
+        float box[6] = {0, 0, 0, 1, 1, 1}, x = 0.0f;
+        unsigned char px[4];
+        memset(&t, 0, sizeof(t));
+        if (hr_model_update_config(NULL, &cfg, NULL) != HR_E_INVALID) return 6;
+        if (hr_train_features(NULL, NULL, 0, NULL, NULL) != HR_E_INVALID) return 7;
+        if (hr_train_forward(NULL, &t, NULL, NULL, 0, 0, NULL, NULL) != HR_E_INVALID) return 8;
+        if (hr_train_backward(NULL, NULL, NULL, NULL, 0, 0, NULL, &t, NULL) != HR_E_INVALID) return 9;
+        if (hr_plane_reg_forward(&x, 1, 0, 4, &x, NULL) != HR_E_INVALID) return 10;         /* h < 1 */
+        if (hr_plane_reg_backward(&x, 1, 4, 4, NULL, &x, NULL) != HR_E_INVALID) return 11;  /* no coefficients */
+        if (hr_upsample_plane(&x, 1, 0, 1, &x, 1, 1, NULL) != HR_E_INVALID) return 12;
+        if (hr_pack_display(&x, 0, 4, 0, 0, 1, px, NULL) != HR_E_INVALID) return 13;
+        if (hr_pack_display(NULL, 4, 4, 0, 0, 1, px, NULL) != HR_E_INVALID) return 14;
+        if (hr_dense_alpha(NULL, n3, 0.01f, 1, NULL, NULL, box, &x, NULL) != HR_E_INVALID) return 15;
+        if (hr_generate_rays(NULL, 6, 0, 0, NULL, NULL) != HR_E_INVALID) return 16;
+        if (hr_model_create_cascade(NULL, &cfg, &m) != HR_E_INVALID || m != NULL) return 17;
+    }
     return 0;
 }
