@@ -395,7 +395,11 @@ class HipLightfieldModel(nn.Module):
     def _compile(self, grid):
         """-> (coarse hr_config or None, hr_config of the level that renders), schedules evaluated at cur_iter."""
         # the box is the net's buffer, not the YAML's value: `shrink` replaces it during training and checkpoints carry it
-        aabb = self.color_model.net.aabb.detach().cpu().numpy() if hasattr(self, 'color_model') else None
+        box = self.color_model.net.aabb
+        key = (box.data_ptr(), box._version)
+        if getattr(self, '_box_host', (None, None))[0] != key:        # one device->host copy per change of the box, not per call
+            self._box_host = (key, box.detach().cpu().numpy())
+        aabb = self._box_host[1]
         return compile_model(self.cfg, self.dataset, grid, self.mlp_precision, self.grid_dtype, iteration=self.cur_iter, aabb=aabb)
 
     # -- reference surface ---------------------------------------------------------
