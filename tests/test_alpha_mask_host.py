@@ -96,3 +96,46 @@ def test_dense_alpha_update_and_shrink_match_the_reference(ht, case):
     a2 = dense_alpha(ht, hc2, planes2, r['n2'], F, prev=net.alpha_volume.numpy(), prev_aabb=net.alpha_aabb.numpy())
     assert np.abs(a2 - z['alpha2']).max() <= 2e-7
     assert ((a2 > 0) == (z['alpha2'] > 0)).all() and 0.2 < (a2 > 0).mean() < 0.8
+
+
+def test_set_iter_schedules_mask_shrink_and_growth_in_train_mode():
+    """TensorBase.set_iter (tensorf_base.py:510-552): nothing in eval mode; in train mode the mask is rebuilt at the
+    update_AlphaMask_list iterations (shrink at the first only) and the grids grow at the upsamp_list iterations to the
+    log-linear N_voxel_list resolutions."""
+    from hyperreel_amd.models import HipLightfieldModel
+    cfg, ds = cfgmod.model_config('donerf_sphere'), cfgmod.dataset_scalars('donerf_sphere')
+    m = HipLightfieldModel(cfg, dataset=ds)
+    net = m.color_model.net
+    assert net.update_alpha_mask_list == [4000, 8000] and net.upsamp_list == [4000, 6000, 8000, 10000, 12000]
+    calls = []
+    net.updateAlphaMask = lambda reso: calls.append(('mask', tuple(reso))) or torch.zeros(2, 3)
+    net.shrink = lambda box: calls.append(('shrink',))
+    net.upsample_volume_grid = lambda reso: calls.append(('grow', tuple(reso)))
+    m.eval()
+    m.set_iter(4000)
+    assert calls == []
+    m.train()
+    for it in (3999, 4000, 4001, 6000, 8000):
+        m.set_iter(it)
+    g0 = tuple(m.grid_size)
+    kinds = [c[0] for c in calls]
+    assert kinds == ['mask', 'shrink', 'grow', 'grow', 'mask', 'grow']
+    assert calls[0][1] == g0 and calls[4][1] == g0            # below 200 per axis: the mask lattice is the grid itself
+    grown = [c[1] for c in calls if c[0] == 'grow']
+    assert all(a[i] <= b[i] for a, b in zip(grown, grown[1:]) for i in range(3)) and grown[0][0] > g0[0]
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize('name', ['donerf_sphere', 'technicolor_z_plane'])
+def test_growth_schedule_equals_the_reference(name):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, '..', 'oracle', 'refgen'))
+    import ref_shim
+    from hyperreel_amd.models import HipLightfieldModel
+    ds = cfgmod.dataset_scalars(name)
+    ref = ref_shim.build_reference(ref_shim.load_model_cfg(name), ds).model.color_model.net
+    m = HipLightfieldModel(cfgmod.model_config(name), dataset=ds)
+    net = m.color_model.net
+    assert net.N_voxel_list == ref.N_voxel_list and net.upsamp_list == list(ref.upsamp_list)
+    assert net.update_alpha_mask_list == list(ref.update_AlphaMask_list)
+    assert m.grid_size == [int(v) for v in ref.gridSize.tolist()]
