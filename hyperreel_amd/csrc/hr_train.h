@@ -333,7 +333,6 @@ static inline
 #endif
 const char* hr_train_unsupported(const hr_config& c)
 {
-    if (c.casc_in_z != 0) return "point_prediction cascades";
     if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";
     if (c.color_table_views > 0) return "color_transform tables";
     return nullptr;
@@ -850,6 +849,85 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
         a.tape.dpre[s] = pre[k][0]; a.tape.dpre[NS + s] = pre[k][1]; a.tape.dpre[2 * NS + s] = pre[k][2];
         a.tape.ddc[s] = ddc[k];
     }
+}
+
+// ---------------------------------------------------------------- coarse level of a point_prediction cascade
+// PointPredictionEmbedding (nlf/embedding/point.py:137-203) feeds its MLP one row per (ray, coarse sample): the sample's
+// point after the first intersect (sorted, contracted, advected / offset) next to ray constants.  Forward: those rows;
+// backward: dL/d rows -> dL/d (raw head of the ray MLP), through hr_sample_point_bwd and hr_sample_distance_bwd -- no
+// gather and no compositing at this level.  The fine level is the ordinary sample stage: its head, one row of M samples
+// per coarse point, is laid out exactly like (n_rays, Z * P).
+struct HrRowsArgs {
+    const hr_config* cfg_dev;   // the COARSE level's configuration, caller's column order
+    const float* rays;
+    const float* head;          // (n, Zc * Pc) raw output of the ray MLP
+    int64_t n_rays;
+    float* rows;                // (n * Zc, row_dim), written by the forward
+    const float* d_rows;        // NULL: forward only
+    float* d_head;              // (n, Zc * Pc), written by the backward
+    int row_dim, n_inputs;
+    int kind[4], len[4];        // HR_PIN_* and columns of each input of the row
+    HrTrainTape tape;           // ds, src, dts (n * Zc each)
+};
+
+template <int ZP>
+HR_FN void hr_ray_rows(const hr_config& c, const HrRowsArgs& a, int64_t ray)
+{
+    const int Z = c.z_channels, P = c.preds_per_z;
+    const float* r = a.rays + ray * c.ray_dim;
+    const float* head = a.head + ray * (int64_t)Z * P;
+    const HrTrainRay q = hr_train_ray(c, r);
+    float ds[ZP];
+    int src[ZP];
+    for (int k = 0; k < Z; ++k) { ds[k] = hr_sample_distance(c, head + k * P, k, q.ro, q.rd); src[k] = k; }
+    if (c.sort)
+        for (int i = 1; i < Z; ++i) {
+            const float v = ds[i];
+            const int s = src[i];
+            int j = i - 1;
+            while (j >= 0 && ds[j] > v) { ds[j + 1] = ds[j]; src[j + 1] = src[j]; --j; }
+            ds[j + 1] = v; src[j + 1] = s;
+        }
+    for (int k = 0; k < Z; ++k) {
+        float p[3], dc;
+        hr_sample_point(c, head + k * P, ds[k], q.ro, q.rd, q.oc, q.time_off, p, &dc);
+        float* row = a.rows + (ray * Z + k) * a.row_dim;
+        int col = 0;
+        for (int i = 0; i < a.n_inputs; ++i)
+            for (int j = 0; j < a.len[i]; ++j)
+                row[col++] = (a.kind[i] == HR_PIN_POINTS) ? p[j] : (a.kind[i] == HR_PIN_VIEWDIRS) ? r[3 + j]
+                             : (a.kind[i] == HR_PIN_ORIGINS) ? r[j] : r[c.ray_dim - 1];
+    }
+    if (!a.d_rows) return;
+    float* dhead = a.d_head + ray * (int64_t)Z * P;
+    for (int i = 0; i < Z * P; ++i) dhead[i] = 0.0f;
+    for (int k = 0; k < Z; ++k) { a.tape.ds[ray * Z + k] = ds[k]; a.tape.src[ray * Z + k] = src[k]; }
+}
+
+// backward of one coarse sample (sorted rank k): the point columns of its row
+HR_FN void hr_sample_rows_bwd(const hr_config& c, const HrRowsArgs& a, int64_t ray, int k)
+{
+    const int Z = c.z_channels, P = c.preds_per_z;
+    const int64_t s = ray * Z + k;
+    const HrTrainRay q = hr_train_ray(c, a.rays + ray * c.ray_dim);
+    const float* drow = a.d_rows + s * a.row_dim;
+    float dp[3] = {0.f, 0.f, 0.f};
+    int col = 0;
+    for (int i = 0; i < a.n_inputs; ++i)
+        for (int j = 0; j < a.len[i]; ++j, ++col)
+            if (a.kind[i] == HR_PIN_POINTS) dp[j] += drow[col];
+    const float dt = hr_sample_point_bwd(c, a.head + s * P, a.tape.ds[s], q.ro, q.rd, q.oc, q.time_off, dp, 0.0f, a.d_head + s * P);
+    a.tape.dts[ray * Z + a.tape.src[s]] = dt;
+}
+
+// backward of one coarse sample (ORIGINAL index k): intersection and head activations
+HR_FN void hr_sample_rows_dist_bwd(const hr_config& c, const HrRowsArgs& a, int64_t ray, int k)
+{
+    const int64_t s = ray * c.z_channels + k;
+    const float* r = a.rays + ray * c.ray_dim;
+    const float ro[3] = {r[0] - c.isect_origin[0], r[1] - c.isect_origin[1], r[2] - c.isect_origin[2]};
+    const float rd[3] = {r[3], r[4], r[5]};
+    hr_sample_distance_bwd(c, a.head + s * c.preds_per_z, k, ro, rd, a.tape.dts[s], a.d_head + s * c.preds_per_z);
 }
 
 #endif  // HR_TRAIN_H

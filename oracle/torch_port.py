@@ -61,8 +61,8 @@ class TorchPort:
                 x = F.leaky_relu(x, 0.01)
         return x
 
-    def _contract_points(self, p):                          # nlf/contract.py:178-192 (mipnerf), :84-85 / :110-111 (affine)
-        c = self.o.contract
+    def _contract_points(self, p, c=None):                  # nlf/contract.py:178-192 (mipnerf), :84-85 / :110-111 (affine)
+        c = self.o.contract if c is None else c
         if hasattr(c, 'bbox_min'):
             lo = torch.from_numpy(c.bbox_min).to(self.dev)
             return (p - lo) / (torch.from_numpy(c.bbox_max).to(self.dev) - lo)
@@ -74,8 +74,8 @@ class TorchPort:
         t = (1.0 / d.abs() - inv_end) * (1.0 / (1.0 - inv_end))
         return torch.where(d < 1, p, (p / d) * (2.0 - t))
 
-    def _inv_contract_distance(self, z):                    # nlf/contract.py:143-158 (mipnerf), :78-79 / :104-105 (affine)
-        c = self.o.contract
+    def _inv_contract_distance(self, z, c=None):            # nlf/contract.py:143-158 (mipnerf), :78-79 / :104-105 (affine)
+        c = self.o.contract if c is None else c
         if not hasattr(c, 'r0'):
             return z * float(c.fac) if hasattr(c, 'fac') else z
         inv_end = c.d0 / c.d1
@@ -84,9 +84,9 @@ class TorchPort:
         inv = (2.0 - z.abs()) / (1.0 / (1.0 - inv_end)) + inv_end
         return torch.where(z.abs() < 1, z, torch.sign(z) * (1.0 / inv)) * c.d0
 
-    def _param_pe(self, rays):                              # nlf/param.py:87-115,244-253; nlf/pe.py:210-221,53-66
+    def _param_pe(self, rays, params=None):                 # nlf/param.py:87-115,244-253; nlf/pe.py:210-221,53-66
         cols = []
-        for pcfg in self.o.pred_cfg['params'].values():
+        for pcfg in (self.o.pred_cfg['params'] if params is None else params).values():
             x = rays[:, pcfg['start']:pcfg['end']]
             p = pcfg['param']
             if p['fn'] == 'pluecker':
@@ -121,32 +121,92 @@ class TorchPort:
             cols.append(y)
         return torch.cat(cols, -1)
 
-    def embed(self, rays, head=None):
-        """`head`: optional (B, Z*P) raw MLP output to use instead of running the MLP (gradient checks of the training
-        path differentiate with respect to it)."""
+    def embed(self, rays, head=None, point_head=None):
+        """`head`: optional (B, Z*P) raw output of the ray MLP to use instead of running it; `point_head`: the same for the
+        point MLP of a cascade, (B*Zc, M*P) (gradient checks of the training path differentiate with respect to them)."""
         import hyperreel_oracle as H
+        from hyperreel_oracle import Act
         o = self.o
         H.ITERATION = o.iteration                           # stages build their activations while they run
-        B, Z = rays.shape[0], o.Z
+        B = rays.shape[0]
         x = {}
-        if head is not None:
-            h = head
-        elif o.zero_net:                                    # ZeroMLP, nlf/nets/mlp.py:14-33
-            h = torch.zeros(B, Z * sum(o.out_shapes), device=self.dev)
-        else:
-            h = self._mlp(self._param_pe(rays))
-        h = h.view(B, Z, -1)
-        off = 0
-        for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
-            x[name] = _act(act, h[..., off:off + n])
-            off += n
+        for idx, typ, ecfg in o.stages:
+            if typ == 'ray_prediction':                     # ray.py:316-347
+                Z = o.Z
+                if head is not None:
+                    h = head
+                elif o.zero_net:                            # ZeroMLP, nlf/nets/mlp.py:14-33
+                    h = torch.zeros(B, Z * sum(o.out_shapes), device=self.dev)
+                else:
+                    h = self._mlp(self._param_pe(rays))
+                h = h.view(B, Z, -1)
+                off = 0
+                for name, n, act in zip(o.out_names, o.out_shapes, o.out_acts):
+                    x[name] = _act(act, h[..., off:off + n])
+                    off += n
+            elif typ == 'ray_intersect':
+                self._intersect(o._isects[idx], rays, x)
+            elif typ == 'point_prediction':                 # point.py:137-203
+                pp = o._pp[idx]
+                Zi = x['points'].shape[1]
+                cols = []
+                for name, n in pp['cfg']['inputs'].items():
+                    if name == 'viewdirs':
+                        cols.append(rays[:, None, 3:6].expand(B, Zi, 3))
+                    elif name == 'origins':
+                        cols.append(rays[:, None, 0:3].expand(B, Zi, 3))
+                    elif name == 'times':
+                        cols.append(rays[:, None, -1:].expand(B, Zi, 1))
+                    else:
+                        cols.append(x[name][..., :int(n)])
+                inp = torch.cat(cols, -1).reshape(B * Zi, -1)
+                x['_rows'] = inp
+                if point_head is not None:
+                    h = point_head
+                else:
+                    layers = [(torch.from_numpy(w).to(self.dev), torch.from_numpy(b).to(self.dev)) for w, b in pp['layers']]
+                    h = self._run_layers(self._param_pe(inp, pp['cfg']['params']), layers, pp['skips'], pp['D'])
+                h = h.view(B, -1, sum(pp['shapes']))
+                off = 0
+                for name, n, act in zip(pp['names'], pp['shapes'], pp['acts']):
+                    x[name] = _act(act, h[..., off:off + n])
+                    off += n
+            elif typ == 'advect_points':                      # point.py:780-831, flow_utils.py:10-35
+                t = rays[:, -1:]
+                K, Fr = o.ds['num_keyframes'], o.ds['num_frames']
+                fac = K * (Fr - 1) / Fr
+                base = torch.round((t * fac).clamp(0.0, K - 1.0) - 1e-5) * (1.0 / fac)
+                if ecfg.get('use_spatial_flow', False):
+                    x['points'] = x['points'] + _act(Act(ecfg.get('spatial_flow_activation')), x['spatial_flow']) * (t - base)[:, None, :]
+                x['base_times'] = base[:, None, :].expand(B, x['points'].shape[1], 1)
+            elif typ == 'point_offset':                     # point.py:371-396
+                fld = ecfg.get('in_density_field', 'sigma')
+                sg = x[fld] if (ecfg.get('use_sigma', True) and fld in x) else torch.zeros(B, x['points'].shape[1], 1, device=self.dev)
+                x['points'] = x['points'] + _act(Act(ecfg.get('activation')), x['point_offset']) * (1 - sg)
+        Z = x['points'].shape[1]
+        x['viewdirs'] = rays[:, None, 3:6].expand(B, Z, 3)
+        return x
+
+    def _run_layers(self, x, layers, skips, D):             # nlf/nets/mlp.py:159-172
+        inp = x
+        for i, (w, b) in enumerate(layers):
+            if i in skips:
+                x = torch.cat([inp, x], -1)
+            x = F.linear(x, w, b)
+            if i < D + 1:
+                x = F.leaky_relu(x, 0.01)
+        return x
+
+    def _intersect(self, o, rays, x):                       # Intersect.forward, nlf/intersect/base.py:142-259
+        """`o`: the stage's _Isect (anchors, scales, contraction ... of hyperreel_oracle)."""
+        B, Z = rays.shape[0], o.Z
         r = torch.cat([rays[:, :3] - torch.from_numpy(o.origin).to(self.dev)[None], rays[:, 3:6]], -1)
         sigma = x[o.in_density_field].reshape(B, -1) if (o.use_sigma and o.in_density_field in x) else torch.zeros(B, Z, device=self.dev)
         zv = _act(o.z_act, x['z_vals'].reshape(B, Z, -1)) * (1 - sigma[..., None])
 
         def proc(z):                                        # intersect/base.py:128-140
-            z = z * float(o.z_scale) + self.samples[None]
-            return self._inv_contract_distance(z) if o.contract.contract_samples else z
+            z = z * float(o.z_scale) + torch.from_numpy(o.samples).to(self.dev)[None]
+            return self._inv_contract_distance(z, o.contract) if o.contract.contract_samples else z
 
         if o.isect_type == 'euclidean_distance_unified':    # primitive.py:162-176, param.py:297-307
             z = proc(zv.reshape(B, Z))
@@ -159,7 +219,7 @@ class TorchPort:
             z = zv.reshape(B, nz, 3) * torch.from_numpy(o.voxel_scale).to(self.dev)[None, None] \
                 + torch.from_numpy(o.voxel_samples).to(self.dev)[None]
             if o.contract.contract_samples:
-                z = self._inv_contract_distance(z)
+                z = self._inv_contract_distance(z, o.contract)
             if o.outward_facing:
                 z = z * torch.sign(r[:, None, 3:6])
             d = r[:, None, 3:6]
@@ -251,28 +311,11 @@ class TorchPort:
         mask = dists == 0
         points = r[:, None, :3] + r[:, None, 3:6] * dists
         if hasattr(o.contract, 'contract_points'):          # contract.py:43-50
-            oc = self._contract_points(r[:, :3])
-            points = self._contract_points(points)
+            oc = self._contract_points(r[:, :3], o.contract)
+            points = self._contract_points(points, o.contract)
             dists = torch.norm(points - oc[:, None], dim=-1, keepdim=True)
         dists = torch.where(mask, torch.zeros_like(dists), dists)
         x['points'], x['distances'] = points, dists
-        for idx, typ, ecfg in o.stages:
-            if typ == 'advect_points':                      # point.py:780-831, flow_utils.py:10-35
-                t = rays[:, -1:]
-                K, Fr = o.ds['num_keyframes'], o.ds['num_frames']
-                fac = K * (Fr - 1) / Fr
-                base = torch.round((t * fac).clamp(0.0, K - 1.0) - 1e-5) * (1.0 / fac)
-                if ecfg.get('use_spatial_flow', False):
-                    from hyperreel_oracle import Act
-                    x['points'] = x['points'] + _act(Act(ecfg.get('spatial_flow_activation')), x['spatial_flow']) * (t - base)[:, None, :]
-                x['base_times'] = base[:, None, :].expand(B, Z, 1)
-            elif typ == 'point_offset':                     # point.py:371-396
-                from hyperreel_oracle import Act
-                fld = ecfg.get('in_density_field', 'sigma')
-                sg = x[fld] if (ecfg.get('use_sigma', True) and fld in x) else torch.zeros(B, Z, 1, device=self.dev)
-                x['points'] = x['points'] + _act(Act(ecfg.get('activation')), x['point_offset']) * (1 - sg)
-        x['viewdirs'] = rays[:, None, 3:6].expand(B, Z, 3)
-        return x
 
     # ---- colour -------------------------------------------------------------------------
     def _feat(self, planes_a, planes_b, pn):                # tensorf_no_sample.py:47-126, tensorf_dynamic.py:287-371

@@ -57,16 +57,18 @@ def linf(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0
 
 
-def trainable_sweep_cases():
+def trainable_sweep_cases(cascades=False):
     """Sweep fixtures whose model the training path differentiates (mirror of hr_train_unsupported, csrc/hr_train.h) --
-    which are also the ones oracle/torch_port.py restates."""
+    which are also the ones oracle/torch_port.py restates.  cascades: the point_prediction models instead of the
+    single-level ones (their coarse and fine stages are checked separately)."""
     from hyperreel_amd import plan
     out = []
     for c in sweep_cases():
         g = Golden(c)
-        if plan.is_cascade(g.cfg):
+        if plan.is_cascade(g.cfg) != bool(cascades):
             continue
-        hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+        with plan.at_iteration(g.iteration):
+            hc = plan.compile_model(g.cfg, g.dataset, g.grid, iteration=g.iteration)[1]
         if hc.color_table_views > 0:
             continue
         out.append(c)

@@ -73,4 +73,37 @@ void ht_dense_alpha(const hr_config* c, const HrGridPlane* planes, const int* n,
             for (int z = 0; z < n[2]; ++z) alpha[((size_t)x * n[1] + y) * n[2] + z] = hr_point_alpha(*c, a, x, y, z);
 }
 
+// coarse level of a cascade: rows forward and (d_rows != NULL) backward
+int ht_rows(const hr_config* c, const float* rays, const float* head, long long n, const float* d_rows, float* rows, float* d_head, int row_dim,
+            int n_inputs, const int* kind, const int* len)
+{
+    if (c->z_channels > 256 || n_inputs > 4) return -1;
+    HrRowsArgs a = {};
+    a.cfg_dev = c; a.rays = rays; a.head = head; a.n_rays = n; a.rows = rows; a.d_rows = d_rows; a.d_head = d_head;
+    a.row_dim = row_dim; a.n_inputs = n_inputs;
+    for (int i = 0; i < n_inputs; ++i) { a.kind[i] = kind[i]; a.len[i] = len[i]; }
+    const size_t NS = (size_t)n * c->z_channels;
+    std::vector<float> ds(NS), dts(NS);
+    std::vector<int> src(NS);
+    a.tape.ds = ds.data(); a.tape.src = src.data(); a.tape.dts = dts.data();
+    int ZP = 8;
+    while (ZP < c->z_channels) ZP <<= 1;
+    for (long long i = 0; i < n; ++i) {
+        switch (ZP) {
+            case 8: hr_ray_rows<8>(*c, a, i); break;
+            case 16: hr_ray_rows<16>(*c, a, i); break;
+            case 32: hr_ray_rows<32>(*c, a, i); break;
+            case 64: hr_ray_rows<64>(*c, a, i); break;
+            case 128: hr_ray_rows<128>(*c, a, i); break;
+            default: hr_ray_rows<256>(*c, a, i); break;
+        }
+    }
+    if (!d_rows) return 0;
+    for (long long i = 0; i < n; ++i)
+        for (int k = 0; k < c->z_channels; ++k) hr_sample_rows_bwd(*c, a, i, k);
+    for (long long i = 0; i < n; ++i)
+        for (int k = 0; k < c->z_channels; ++k) hr_sample_rows_dist_bwd(*c, a, i, k);
+    return 0;
+}
+
 }  // extern "C"

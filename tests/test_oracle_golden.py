@@ -75,7 +75,7 @@ def test_schedule_fixtures_sit_inside_their_windows(case):
     assert linf(converged, g.rgb) > 1.5e-4          # 10x what the oracle itself is held to
 
 
-@pytest.mark.parametrize('case', trainable_sweep_cases())
+@pytest.mark.parametrize('case', trainable_sweep_cases() + trainable_sweep_cases(cascades=True))
 def test_torch_port_matches_reference_on_the_trainable_shipped_yamls(case):
     """oracle/torch_port.py is the autograd reference of the training path's gradient checks: its forward is pinned here
     against what the reference itself rendered for every model family those checks use."""

@@ -75,11 +75,17 @@ CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_sm
     + trainable_sweep_cases()
 
 
+CASCADES = trainable_sweep_cases(cascades=True)
+
+
 @pytest.mark.parametrize('white', [0, 1])
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('case', CASES + CASCADES)
 def test_backward_matches_autograd(ht, case, white):
+    """Single-level models: the whole sample stage.  point_prediction cascades: their fine level, i.e. the same stage fed
+    by the point MLP's head (one row of M samples per coarse point == (n, Z * P)), the coarse level held fixed."""
     g = Golden(case)
-    hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+    cascade = plan.is_cascade(g.cfg)
+    coarse_hc, hc = plan.compile_model(g.cfg, g.dataset, g.grid, iteration=g.iteration)
     assert ht.ht_unsupported(C.byref(hc)) is None
     port = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
     n = min(192, g.rays.shape[0])
@@ -92,12 +98,20 @@ def test_backward_matches_autograd(ht, case, white):
         for t in grids + [port.basis]:
             t.grad = None
         with torch.no_grad():
-            if port.o.zero_net:                               # ZeroMLP (nlf/nets/mlp.py:14-33): the head is all zeros
+            if cascade:                                       # the point MLP's own output, run once without a graph
+                rec = {}
+                orig = port._run_layers
+                port._run_layers = lambda *a: rec.setdefault('h', orig(*a))
+                port.embed(rays)
+                port._run_layers = orig
+                head0 = rec['h'].reshape(rays.shape[0], -1)
+            elif port.o.zero_net:                             # ZeroMLP (nlf/nets/mlp.py:14-33): the head is all zeros
                 head0 = torch.zeros(rays.shape[0], hc.z_channels * hc.preds_per_z)
             else:
                 head0 = port._mlp(port._param_pe(rays))
         head = head0.clone().requires_grad_(True)
-        rgb_ref = port.color(port.embed(rays, head=head), train=True, white_bg=bool(white))
+        x = port.embed(rays, point_head=head.view(rays.shape[0] * coarse_hc.z_channels, -1)) if cascade else port.embed(rays, head=head)
+        rgb_ref = port.color(x, train=True, white_bg=bool(white))
         G = torch.randn(rgb_ref.shape, generator=torch.Generator().manual_seed(3))
         (rgb_ref * G).sum().backward()
         return head0, head, rgb_ref, G
@@ -163,6 +177,54 @@ def test_backward_matches_autograd(ht, case, white):
 
 
 def test_unsupported_models_are_named(ht):
-    g = Golden('sweep/technicolor_cascaded')
-    _, fine = plan.compile_cascade(g.cfg, g.dataset, g.grid)
-    assert b'cascade' in ht.ht_unsupported(C.byref(fine))
+    g = Golden('sweep/immersive_z_plane')                 # per-camera colour table (only read with dataset.val_all)
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
+    assert hc.color_table_views > 0 and b'color_transform' in ht.ht_unsupported(C.byref(hc))
+    hc = plan.compile_config(Golden('donerf_sphere_small').cfg, g.dataset, g.grid, grid_dtype='fp16')
+    assert b'float16' in ht.ht_unsupported(C.byref(hc))
+
+
+PIN = {'points': 0, 'viewdirs': 1, 'origins': 2, 'times': 3}      # HR_PIN_* (include/hyperreel_hip.h)
+
+
+@pytest.mark.parametrize('case', CASCADES)
+def test_cascade_rows_forward_and_backward_match_autograd(ht, case):
+    """Coarse level of a point_prediction cascade (nlf/embedding/point.py:137-203): the rows handed to the point MLP and
+    the gradient they send back to the ray MLP's raw head."""
+    g = Golden(case)
+    coarse, fine = plan.compile_model(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+    port = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    n = min(96, g.rays.shape[0])
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:n], np.float32))
+    with torch.no_grad():
+        head0 = torch.zeros(n, coarse.z_channels * coarse.preds_per_z) if port.o.zero_net else port._mlp(port._param_pe(rays))
+    head = head0.clone().requires_grad_(True)
+    rows_ref = port.embed(rays, head=head)['_rows']
+    G = torch.randn(rows_ref.shape, generator=torch.Generator().manual_seed(5))
+    (rows_ref * G).sum().backward()
+    assert rows_ref.shape == (n * coarse.z_channels, fine.casc_row_dim)
+
+    kinds = (C.c_int * 4)(*[fine.casc_input_kind[i] for i in range(4)])
+    lens = (C.c_int * 4)(*[fine.casc_input_dim[i] for i in range(4)])
+    rows = np.zeros(tuple(rows_ref.shape), np.float32)
+    d_head = np.zeros_like(head0.numpy())
+    f = lambda a: a.ctypes.data_as(FP)
+    rnp, hnp, Gnp = np.ascontiguousarray(rays.numpy()), np.ascontiguousarray(head0.numpy()), np.ascontiguousarray(G.numpy())
+    rc = ht.ht_rows(C.byref(coarse), f(rnp), f(hnp), C.c_longlong(n), f(Gnp), f(rows), f(d_head), fine.casc_row_dim, fine.casc_n_inputs, kinds, lens)
+    assert rc == 0
+    assert np.abs(rows - rows_ref.detach().numpy()).max() <= 2e-6
+    ref = head.grad.numpy()
+    if np.abs(ref).max() == 0:                   # a ZeroMLP ray level has a head nobody reads back
+        assert not d_head.any()
+        return
+    P = coarse.preds_per_z
+    ref_c, got_c = ref.reshape(n, coarse.z_channels, P), d_head.reshape(n, coarse.z_channels, P)
+    live = 0
+    for col in range(P):
+        scale = np.abs(ref_c[..., col]).max()
+        if scale > 0:
+            assert np.abs(got_c[..., col] - ref_c[..., col]).max() <= 2e-4 * scale + 1e-7, col
+            live += 1
+        else:
+            assert not got_c[..., col].any()
+    assert live >= 1
