@@ -864,15 +864,28 @@ int hr_plane_reg_backward(const float* plane_dev, int32_t channels, int32_t h, i
 static int check_train(hr_model* m, const float* rays, int64_t n)
 {
     if (!m) return fail(HR_E_INVALID, "null model");
-    if (m->is_coarse || m->coarse) return fail(HR_E_INVALID, "training path: point_prediction cascades are not differentiated");
+    if (m->is_coarse) return fail(HR_E_INVALID, "training path: pass the cascade's handle, not its coarse level");
     if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called (or tensors changed since)");
     if (const char* why = hr_train_unsupported(m->cfg)) return fail(HR_E_INVALID, "training path: %s not differentiated", why);
     if (m->ca_total > HR_TRAIN_MAX_CA) return fail(HR_E_INVALID, "training path: more than %d appearance components", HR_TRAIN_MAX_CA);
     if (n < 0 || (n > 0 && !rays)) return fail(HR_E_INVALID, "bad ray buffer");
-    if (!m->ucfg_dev) {
-        HR_HIP(hipMalloc((void**)&m->ucfg_dev, sizeof(hr_config)));
-        HR_HIP(hipMemcpy(m->ucfg_dev, &m->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
+    for (hr_model* lvl : {m, m->coarse}) {
+        if (!lvl || lvl->ucfg_dev) continue;
+        HR_HIP(hipMalloc((void**)&lvl->ucfg_dev, sizeof(hr_config)));
+        HR_HIP(hipMemcpy(lvl->ucfg_dev, &lvl->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
     }
+    return HR_OK;
+}
+
+// per-sample workspace of the backward's phases (8 words per sample); grows on the first step and if the batch grows
+static int ensure_tape(hr_model* m, int64_t ns, hipStream_t st)
+{
+    if (ns <= m->tape_samples) return HR_OK;
+    HR_HIP(hipStreamSynchronize(st));
+    free_dev(m->tape);
+    m->tape_samples = 0;
+    HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 8 * (size_t)ns));
+    m->tape_samples = ns;
     return HR_OK;
 }
 
@@ -894,7 +907,8 @@ int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float*
     int rc = check_train(m, rays_dev, n_rays);
     if (rc != HR_OK) return rc;
     if (n_rays > 0 && !feats_dev) return fail(HR_E_INVALID, "null feature buffer");
-    hr_launch_features(m->ucfg_dev, rays_dev, n_rays, feats_dev, (hipStream_t)stream);
+    // a cascade's ray MLP belongs to its coarse level
+    hr_launch_features(m->coarse ? m->coarse->ucfg_dev : m->ucfg_dev, rays_dev, n_rays, feats_dev, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -970,13 +984,8 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     if (!d_basis) return fail(HR_E_INVALID, "hr_train_backward: grads->basis is NULL");
     if (basis_bytes > 0) HR_HIP(hipMemsetAsync(d_basis, 0, basis_bytes, st));
     const int64_t ns = n_rays * m->cfg.z_channels;
-    if (ns > m->tape_samples) {          // grows on the first step (and if the batch grows): not in steady state
-        HR_HIP(hipStreamSynchronize(st));
-        free_dev(m->tape);
-        m->tape_samples = 0;
-        HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 8 * (size_t)ns));
-        m->tape_samples = ns;
-    }
+    rc = ensure_tape(m, ns, st);
+    if (rc != HR_OK) return rc;
     HrTrainArgs a;
     fill_train_args(m, a, rays_dev, head_dev, n_rays, white_bg);
     a.tape.ds = m->tape;
@@ -1000,6 +1009,57 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
                                    (t & 1) ? 4 * g.cd4 : 0, st);
         }
     }
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+static int fill_rows_args(hr_model* m, HrRowsArgs& a, const float* rays, const float* head, int64_t n)
+{
+    if (!m->coarse) return fail(HR_E_INVALID, "hr_train_rows_*: the model is not a point_prediction cascade");
+    a = HrRowsArgs();
+    a.cfg_dev = m->coarse->ucfg_dev;
+    a.rays = rays;
+    a.head = head;
+    a.n_rays = n;
+    a.row_dim = m->cfg.casc_row_dim;
+    a.n_inputs = m->cfg.casc_n_inputs;
+    for (int i = 0; i < 4; ++i) { a.kind[i] = m->cfg.casc_input_kind[i]; a.len[i] = m->cfg.casc_input_dim[i]; }
+    return HR_OK;
+}
+
+int hr_train_rows_forward(hr_model* m, const float* rays_dev, const float* head_dev, int64_t n_rays, float* rows_dev, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (n_rays > 0 && (!head_dev || !rows_dev)) return fail(HR_E_INVALID, "null head / rows buffer");
+    HrRowsArgs a;
+    rc = fill_rows_args(m, a, rays_dev, head_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    a.rows = rows_dev;
+    hr_launch_rows(m->coarse->cfg, a, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_train_rows_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rows_dev, int64_t n_rays,
+                           float* rows_scratch_dev, float* d_head_dev, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (n_rays > 0 && (!head_dev || !d_rows_dev || !rows_scratch_dev || !d_head_dev)) return fail(HR_E_INVALID, "null buffer");
+    HrRowsArgs a;
+    rc = fill_rows_args(m, a, rays_dev, head_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    const int64_t ns = n_rays * m->coarse->cfg.z_channels;
+    rc = ensure_tape(m, ns, (hipStream_t)stream);
+    if (rc != HR_OK) return rc;
+    a.rows = rows_scratch_dev;
+    a.d_rows = d_rows_dev;
+    a.d_head = d_head_dev;
+    a.tape.ds = m->tape;
+    a.tape.src = reinterpret_cast<int*>(m->tape + ns);
+    a.tape.dts = m->tape + 2 * ns;
+    hr_launch_rows(m->coarse->cfg, a, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }

@@ -99,6 +99,8 @@ void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, i
 // ---------------------------------------------------------------- training path (train_kernel.hip, hr_train.h)
 struct HrTrainArgs;
 struct HrMaskArgs;
+struct HrRowsArgs;
+void hr_launch_rows(const hr_config& cfg, const HrRowsArgs& args, hipStream_t stream);
 void hr_launch_dense_alpha(const HrMaskArgs& args, hipStream_t stream);
 void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream);
 void hr_launch_features(const hr_config* cfg_dev, const float* rays, int64_t n, float* out, hipStream_t stream);

@@ -110,6 +110,47 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t 
     hipLaunchKernelGGL(hr_train_dist_bwd_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }
 
+// Coarse level of a point_prediction cascade (hr_ray_rows ... in hr_train.h): rows forward per ray, then per sample the
+// point backward and the intersection backward.  Elementwise work, no gather.
+template <int ZP>
+__global__ __launch_bounds__(64) void hr_rows_kernel(const hr_config* __restrict__ cfgp, const HrRowsArgs a)
+{
+    const int64_t ray = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    hr_ray_rows<ZP>(*cfgp, a, ray);
+}
+
+__global__ __launch_bounds__(256) void hr_rows_bwd_kernel(const hr_config* __restrict__ cfgp, const HrRowsArgs a, int phase)
+{
+    const hr_config& c = *cfgp;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_rays * c.z_channels) return;
+    if (phase == 0) hr_sample_rows_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
+    else hr_sample_rows_dist_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
+}
+
+void hr_launch_rows(const hr_config& cfg, const HrRowsArgs& args, hipStream_t stream)
+{
+    if (args.n_rays <= 0) return;
+    int ZP = 8;
+    while (ZP < cfg.z_channels) ZP <<= 1;
+    const unsigned blocks = (unsigned)((args.n_rays + 63) / 64);
+    switch (ZP) {
+        case 8: hipLaunchKernelGGL(hr_rows_kernel<8>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        case 16: hipLaunchKernelGGL(hr_rows_kernel<16>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        case 32: hipLaunchKernelGGL(hr_rows_kernel<32>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        case 64: hipLaunchKernelGGL(hr_rows_kernel<64>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        case 128: hipLaunchKernelGGL(hr_rows_kernel<128>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        case 256: hipLaunchKernelGGL(hr_rows_kernel<256>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+        default: break;
+    }
+    if (!args.d_rows) return;
+    const int64_t ns = args.n_rays * cfg.z_channels;
+    const unsigned sb = (unsigned)((ns + 255) / 256);
+    hipLaunchKernelGGL(hr_rows_bwd_kernel, dim3(sb), dim3(256), 0, stream, args.cfg_dev, args, 0);
+    hipLaunchKernelGGL(hr_rows_bwd_kernel, dim3(sb), dim3(256), 0, stream, args.cfg_dev, args, 1);
+}
+
 // rays (n, ray_dim) -> MLP input features (n, mlp_in): ray parameterisation + positional encoding
 // (nlf/param.py:87-115,244-253; nlf/pe.py:53-66,210-221), what RayPredictionEmbedding feeds its net (embedding/ray.py:316-330)
 __global__ __launch_bounds__(256) void hr_features_kernel(const hr_config* __restrict__ cfgp, const float* __restrict__ rays, int64_t n,

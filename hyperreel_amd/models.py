@@ -383,6 +383,7 @@ class HipLightfieldModel(nn.Module):
         self._native_cfg = None        # bytes of the hr_config the native handle currently holds
         self._sched_built = None       # cur_iter that configuration was compiled at
         self._native_box = None        # (data_ptr, version) of the net's aabb buffer the handle was created for
+        self._coarse_hc = None         # hr_config of a cascade's coarse level (None for single-level models)
         # fail on configurations outside the supported path now, not at the first render
         self._compile(grid)
 
@@ -515,6 +516,7 @@ class HipLightfieldModel(nn.Module):
             _lib.check(L.hr_model_finalize(self._native), 'hr_model_finalize')
         self._native_key = key
         self._hc = hc
+        self._coarse_hc = coarse
         self._sync_schedule(hc, coarse)          # an existing handle may still hold another iteration's constants
         return self._native
 
@@ -639,10 +641,15 @@ class HipLightfieldModel(nn.Module):
             white_bg = (bool(net_cfg.get('white_bg', False)) or bool(torch.rand(()) < 0.5)) and not bool(net_cfg.get('black_bg', False))
         types = [e['type'] for e in self.cfg['embedding']['embeddings'].values()]
         pred = self.embedding_model.embeddings[types.index('ray_prediction')]
-        if hc.mlp_layers == 0:                                  # ZeroMLP, nlf/nets/mlp.py:14-33
-            head = torch.zeros((rays.shape[0], hc.z_channels * hc.preds_per_z), dtype=torch.float32, device=rays.device)
+        lvl0 = self._coarse_hc if self._coarse_hc is not None else hc       # the level the ray MLP belongs to
+        if lvl0.mlp_layers == 0:                                # ZeroMLP, nlf/nets/mlp.py:14-33
+            head = torch.zeros((rays.shape[0], lvl0.z_channels * lvl0.preds_per_z), dtype=torch.float32, device=rays.device)
         else:
-            head = T.mlp_forward(pred.net, T.ray_features(h, rays, hc.mlp_in), hc.mlp_skip_mask)
+            head = T.mlp_forward(pred.net, T.ray_features(h, rays, lvl0.mlp_in), lvl0.mlp_skip_mask)
+        if self._coarse_hc is not None:                         # point_prediction cascade (point.py:137-203)
+            rows = T.CoarseRows.apply(h, rays, head, lvl0.z_channels, hc.casc_row_dim)
+            point = self.embedding_model.embeddings[types.index('point_prediction')]
+            head = T.mlp_forward(point.net, T.row_features(hc, rows), hc.mlp_skip_mask).reshape(rays.shape[0], -1)
         vm = self.color_model.net
         return T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm))
 

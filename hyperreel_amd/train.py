@@ -79,6 +79,63 @@ class SampleStage(torch.autograd.Function):
         return (None, None, d_head, None, g_basis, *g_grids)
 
 
+class CoarseRows(torch.autograd.Function):
+    """Coarse level of a point_prediction cascade (nlf/embedding/point.py:137-203): raw head of the ray MLP (B, Zc * Pc) ->
+    the point MLP's input rows (B * Zc, row_dim), and the gradient back (hr_train_rows_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, handle, rays, head, n_rows_per_ray, row_dim):
+        L = _lib.load()
+        dev = rays.device
+        if dev.type != 'cuda' or head.device != dev:
+            raise RuntimeError('CoarseRows runs on the HIP device; there is no CPU path')
+        rays, head = rays.contiguous().float(), head.contiguous().float()
+        rows = torch.empty((rays.shape[0] * int(n_rows_per_ray), int(row_dim)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_train_rows_forward(handle, _ptr(rays), _ptr(head), rays.shape[0], _ptr(rows), _stream(dev)), 'hr_train_rows_forward')
+        ctx.handle = handle
+        ctx.save_for_backward(rays, head)
+        ctx.shape = tuple(rows.shape)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        L = _lib.load()
+        rays, head = ctx.saved_tensors
+        dev = rays.device
+        d_rows = d_rows.contiguous().float()
+        scratch = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+        d_head = torch.empty_like(head)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_train_rows_backward(ctx.handle, _ptr(rays), _ptr(head), _ptr(d_rows), rays.shape[0], _ptr(scratch), _ptr(d_head),
+                                                _stream(dev)), 'hr_train_rows_backward')
+        return None, None, d_head, None, None
+
+
+def row_features(hc, rows):
+    """Input of a cascade's point MLP: the identity parameterisation + positional encoding of its rows (nlf/pe.py:53-66,
+    210-221), the arithmetic of hr_ray_features in torch ops because the rows carry a gradient (their point columns)."""
+    cols = []
+    for g in range(hc.n_groups):
+        pg = hc.groups[g]
+        if pg.fn != 0:
+            raise NotImplementedError('point_prediction with a non-identity parameterisation of its inputs')
+        x = rows[:, pg.start:pg.end]
+        out = [x] if (pg.pe_type in (0, 2) or not pg.pe_exclude_identity) else []
+        if pg.pe_type == 1:                                   # windowed: [sin(all), cos(all)] per frequency
+            f = 1.0
+            for j in range(pg.pe_n_freqs):
+                f = f * pg.pe_freq_mult
+                w = float(pg.pe_weight[j])
+                out += [w * torch.sin(pg.pe_base_mult * f * x), w * torch.cos(pg.pe_base_mult * f * x)]
+        elif pg.pe_type == 2:                                 # basic: [x, sin(f_j x_i) (i-major), cos(f_j x_i)]
+            fr = torch.tensor([pg.pe_freq_mult ** (j + 1) for j in range(pg.pe_n_freqs)], dtype=x.dtype, device=x.device)
+            cur = (fr[None, None] * x[..., None]).reshape(x.shape[0], -1)
+            out += [torch.sin(cur), torch.cos(cur)]
+        cols.append(torch.cat(out, -1))
+    return torch.cat(cols, -1)
+
+
 def ray_features(handle, rays, mlp_in):
     """rays (B, ray_dim) -> MLP input (B, mlp_in): RayParam + positional encoding on the device."""
     L = _lib.load()

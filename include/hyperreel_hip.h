@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 14
+#define HR_ABI_VERSION 15
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -288,8 +288,8 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
  * caller's column order, and hr_train_backward returns dL/d head for it.
  * All tensors are device memory, float32, in the reference's parameter layouts (same shapes as the hr_model_upload
  * names): a[j] = density_plane.j | density_plane_space.j, b[j] = density_line.j | density_plane_time.j, likewise app_*.
- * Supported: every single-level model hr_model_create accepts, with float32 grids and without a color_transform table;
- * point_prediction cascades, color_transform tables and float16 grids return HR_E_INVALID naming the feature.
+ * Supported: every model hr_model_create / hr_model_create_cascade accepts, with float32 grids and without a
+ * color_transform table (those two return HR_E_INVALID naming the feature).
  * Activation / encoding / mask schedules are those of the model's current configuration (hr_model_update_config). */
 typedef struct hr_train_tensors {
     float* density_a[3];
@@ -298,6 +298,17 @@ typedef struct hr_train_tensors {
     float* app_b[3];
     float* basis;                        /* basis_mat.weight (app_dim, sum n_app) */
 } hr_train_tensors;
+
+/* point_prediction cascades (nlf/embedding/point.py:137-203): the same three calls serve their fine level -- head_dev is then
+ * the point MLP's raw output, one row of z_channels / casc_in_z samples per coarse point, which is (n_rays, z_channels *
+ * preds_per_z) in memory -- and hr_train_features gives the input of the cascade's RAY MLP.  Between the two MLPs:
+ *   hr_train_rows_forward   ray MLP head (n, Zc * Pc) -> rows_dev (n * Zc, casc_row_dim): per coarse sample the point after
+ *                           the first intersect next to the ray constants the YAML lists, i.e. the point MLP's input row
+ *                           (before its own positional encoding, which stays with the caller's autograd);
+ *   hr_train_rows_backward  d_rows_dev -> d_head_dev (n, Zc * Pc); rows_scratch_dev: (n * Zc, casc_row_dim) workspace. */
+int hr_train_rows_forward(hr_model* m, const float* rays_dev, const float* head_dev, int64_t n_rays, float* rows_dev, void* stream);
+int hr_train_rows_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rows_dev, int64_t n_rays,
+                           float* rows_scratch_dev, float* d_head_dev, void* stream);
 
 /* rays (n, ray_dim) -> feats_dev (n, mlp_in): ray parameterisation + positional encoding (nlf/param.py, nlf/pe.py) */
 int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float* feats_dev, void* stream);

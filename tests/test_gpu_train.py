@@ -107,10 +107,10 @@ def test_a_few_adam_steps_reduce_the_image_loss():
 
 def test_unsupported_models_raise_by_name():
     from gpu_common import make_render_fn
-    g = Golden('sweep/technicolor_cascaded')
-    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    g = Golden('donerf_sphere_small')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, grid_dtype='fp16')
     rays = torch.from_numpy(np.ascontiguousarray(g.rays[:64], np.float32)).cuda()
-    with pytest.raises((RuntimeError, NotImplementedError), match='cascade'):
+    with pytest.raises((RuntimeError, NotImplementedError), match='float16'):
         fn.model.forward_train(rays, white_bg=False)
 
 

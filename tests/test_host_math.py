@@ -160,3 +160,20 @@ def test_display_pack_matches_the_viewer_host_code(hm):
             src = np.zeros(h * w, np.int64)
             hm.hm_display_map(h, w, transpose, flip, src.ctypes.data_as(C.POINTER(C.c_longlong)))
             assert np.array_equal(src.reshape(ref.shape), ref)
+
+
+def test_row_features_equal_the_kernel_encoding(hm):
+    """hyperreel_amd.train.row_features (torch ops, because a cascade's rows carry a gradient) == hr_ray_features of the
+    point MLP's configuration on the same rows."""
+    import torch
+    from helpers import trainable_sweep_cases
+    from hyperreel_amd.train import row_features
+    for case in trainable_sweep_cases(cascades=True):
+        g = Golden(case)
+        _, fine = plan.compile_model(g.cfg, g.dataset, g.grid)
+        rows = np.random.default_rng(0).standard_normal((64, fine.casc_row_dim)).astype(np.float32)
+        kc = plan.hr_config.from_buffer_copy(fine)
+        kc.ray_dim = fine.casc_row_dim                     # the point MLP's "rays" are the rows (api.hip launch_cascade_front)
+        want = np.zeros((64, fine.mlp_in), np.float32)
+        hm.hm_features(C.byref(kc), fp(rows), 64, fp(want))
+        assert np.abs(row_features(fine, torch.from_numpy(rows)).numpy() - want).max() <= 2e-7, case
