@@ -925,6 +925,11 @@ static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays
     a.n_basis_cols = m->n_basis_cols;
     a.ca_total = m->ca_total;
     a.white_bg = white_bg ? 1 : 0;
+    a.color_table = nullptr;
+    if (m->cfg.color_table_views > 0) {
+        auto it = m->raw.find("color_embedding");
+        if (it != m->raw.end()) a.color_table = it->second.p;
+    }
 }
 
 int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
@@ -951,6 +956,11 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
         if (bytes > 0) {
             if (!params->basis) return fail(HR_E_INVALID, "hr_train_forward: params->basis is NULL");
             HR_HIP(hipMemcpyAsync(m->basis, params->basis, bytes, hipMemcpyDeviceToDevice, st));
+        }
+        if (m->cfg.color_table_views > 0) {       // read in place from the uploaded copy: refresh it
+            if (!params->color_table) return fail(HR_E_INVALID, "hr_train_forward: params->color_table is NULL");
+            DevBuf& b = m->raw["color_embedding"];
+            HR_HIP(hipMemcpyAsync(b.p, params->color_table, b.bytes, hipMemcpyDeviceToDevice, st));
         }
     }
     HrTrainArgs a;
@@ -997,6 +1007,11 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     a.d_rgb = d_rgb_dev;
     a.d_head = d_head_dev;
     a.d_basis = d_basis;
+    if (m->cfg.color_table_views > 0) {
+        if (!grads->color_table) return fail(HR_E_INVALID, "hr_train_backward: grads->color_table is NULL");
+        HR_HIP(hipMemsetAsync(grads->color_table, 0, sizeof(float) * 12 * (size_t)m->cfg.color_table_views, st));
+        a.d_color_table = grads->color_table;
+    }
     hr_launch_train(m->cfg, a, st);
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = m->planes[j];

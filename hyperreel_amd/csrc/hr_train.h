@@ -69,6 +69,8 @@ struct HrTrainArgs {
     int n_basis_cols;
     int ca_total;
     int white_bg;               // this step's background decision: white_bg or (training and rand < 0.5), :236
+    const float* color_table;   // (color_table_views, 12) per-camera [3x3 | shift] (ColorTransformEmbedding) or NULL
+    float* d_color_table;       // accumulated
     HrTrainTape tape;
 };
 
@@ -334,7 +336,6 @@ static inline
 const char* hr_train_unsupported(const hr_config& c)
 {
     if (c.grid_dtype != HR_GRID_FP32) return "float16 grids";
-    if (c.color_table_views > 0) return "color_transform tables";
     return nullptr;
 }
 
@@ -775,6 +776,19 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
         c1 = c1 * gscale[1] + hr_apply_act(fh.act, head[fh.offset + 1]);
         c2 = c2 * gscale[2] + hr_apply_act(fh.act, head[fh.offset + 2]);
     }
+    else if (a.color_table) {                    // transform_color_one (tensorf_utils.py:308-320, point.py:588-594)
+        int id = (int)rintf(r[c.ray_dim - 2]);
+        id = id < 0 ? 0 : (id > c.color_table_views - 1 ? c.color_table_views - 1 : id);
+        const float* e = a.color_table + 12 * id;
+        float t[9];
+        for (int i = 0; i < 9; ++i) t[i] = hr_apply_act(c.color_table_t_act, e[i]);
+        const float n0 = c0 + ((c0 * t[0] + c1 * t[1]) + c2 * t[2]);
+        const float n1 = c1 + ((c0 * t[3] + c1 * t[4]) + c2 * t[5]);
+        const float n2 = c2 + ((c0 * t[6] + c1 * t[7]) + c2 * t[8]);
+        c0 = n0 + hr_apply_act(c.color_table_s_act, e[9]);
+        c1 = n1 + hr_apply_act(c.color_table_s_act, e[10]);
+        c2 = n2 + hr_apply_act(c.color_table_s_act, e[11]);
+    }
     if (a.rgb) { a.rgb[ray * 3 + 0] = c0; a.rgb[ray * 3 + 1] = c1; a.rgb[ray * 3 + 2] = c2; }
     if (!a.d_rgb) return;
 
@@ -790,6 +804,21 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
             dhead[fh.offset + i] += g[i] * hr_act_grad(fh.act, head[fh.offset + i]);
             g[i] = g[i] * gscale[i];             // everything below sees the gradient of the un-scaled colour
         }
+    }
+    else if (a.color_table) {
+        int id = (int)rintf(r[c.ray_dim - 2]);
+        id = id < 0 ? 0 : (id > c.color_table_views - 1 ? c.color_table_views - 1 : id);
+        const float* e = a.color_table + 12 * id;
+        float* de = a.d_color_table + 12 * id;
+        float gn[3] = {g[0], g[1], g[2]};
+        for (int i = 0; i < 3; ++i) {
+            HR_ATOMIC_ADD(de + 9 + i, g[i] * hr_act_grad(c.color_table_s_act, e[9 + i]));
+            for (int j = 0; j < 3; ++j) {
+                HR_ATOMIC_ADD(de + 3 * i + j, g[i] * cpre[j] * hr_act_grad(c.color_table_t_act, e[3 * i + j]));
+                gn[j] += g[i] * hr_apply_act(c.color_table_t_act, e[3 * i + j]);
+            }
+        }
+        g[0] = gn[0]; g[1] = gn[1]; g[2] = gn[2];
     }
     const float gsum = a.white_bg ? (g[0] + g[1] + g[2]) : 0.0f;
     float ddc[ZP];                // dL / d final distance

@@ -11,14 +11,14 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 
 class hr_train_tensors(C.Structure):
     """Device pointers of the trainable tensors (or of their gradients), reference layouts (include/hyperreel_hip.h)."""
     _fields_ = [('density_a', C.c_void_p * 3), ('density_b', C.c_void_p * 3), ('app_a', C.c_void_p * 3), ('app_b', C.c_void_p * 3),
-                ('basis', C.c_void_p)]
+                ('basis', C.c_void_p), ('color_table', C.c_void_p)]
 
 
 # every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)

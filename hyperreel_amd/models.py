@@ -651,7 +651,10 @@ class HipLightfieldModel(nn.Module):
             point = self.embedding_model.embeddings[types.index('point_prediction')]
             head = T.mlp_forward(point.net, T.row_features(hc, rows), hc.mlp_skip_mask).reshape(rays.shape[0], -1)
         vm = self.color_model.net
-        return T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm))
+        extra = ()
+        if hc.color_table_views > 0:                            # ColorTransformEmbedding's table (point.py:558-602)
+            extra = (self.embedding_model.embeddings[types.index('color_transform')].color_embedding,)
+        return T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm), *extra)
 
     def forward(self, rays, render_kwargs=None):
         """LightfieldModel.forward (models.py:135-138).  In train mode with autograd enabled this is the

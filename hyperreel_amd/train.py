@@ -27,7 +27,7 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _tensors_struct(groups, basis):
+def _tensors_struct(groups, basis, table=None):
     """groups: 4 lists of 3 tensors (density a, density b, app a, app b) -> hr_train_tensors."""
     t = _lib.hr_train_tensors()
     for name, grp in zip(('density_a', 'density_b', 'app_a', 'app_b'), groups):
@@ -35,16 +35,19 @@ def _tensors_struct(groups, basis):
         for j in range(3):
             arr[j] = grp[j].data_ptr() if grp[j].numel() > 0 else None
     t.basis = basis.data_ptr() if basis.numel() > 0 else None
+    t.color_table = table.data_ptr() if table is not None and table.numel() > 0 else None
     return t
 
 
 class SampleStage(torch.autograd.Function):
     """rgb = f(head; planes, lines, basis_mat), not clamped (training mode, tensorf_no_sample.py:246).
     Inputs after `white_bg`: basis_mat.weight, then the 12 grid tensors in the order density a[0..2], density b[0..2],
-    app a[0..2], app b[0..2] (a = plane | plane_space, b = line | plane_time)."""
+    app a[0..2], app b[0..2] (a = plane | plane_space, b = line | plane_time), then -- only for models with a per-camera
+    colour table (ColorTransformEmbedding, read with dataset.val_all) -- its `color_embedding`."""
 
     @staticmethod
-    def forward(ctx, handle, rays, head, white_bg, basis, *grids):
+    def forward(ctx, handle, rays, head, white_bg, basis, *tensors):
+        grids, table = tensors[:12], (tensors[12] if len(tensors) > 12 else None)
         L = _lib.load()
         dev = rays.device
         if dev.type != 'cuda' or head.device != dev:
@@ -52,31 +55,34 @@ class SampleStage(torch.autograd.Function):
         rays, head = rays.contiguous().float(), head.contiguous().float()
         vals = [g.detach().contiguous() for g in grids]
         groups = [vals[0:3], vals[3:6], vals[6:9], vals[9:12]]
-        params = _tensors_struct(groups, basis.detach().contiguous())
+        params = _tensors_struct(groups, basis.detach().contiguous(), None if table is None else table.detach().contiguous())
         rgb = torch.empty((rays.shape[0], 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.hr_train_forward(handle, C.byref(params), _ptr(rays), _ptr(head), rays.shape[0], int(bool(white_bg)), _ptr(rgb),
                                           _stream(dev)), 'hr_train_forward')
         ctx.handle, ctx.white_bg = handle, int(bool(white_bg))
-        ctx.save_for_backward(rays, head, basis, *grids)
+        ctx.has_table = table is not None
+        ctx.save_for_backward(rays, head, basis, *tensors)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
         L = _lib.load()
-        rays, head, basis, *grids = ctx.saved_tensors
+        rays, head, basis, *tensors = ctx.saved_tensors
+        grids, table = tensors[:12], (tensors[12] if ctx.has_table else None)
         dev = rays.device
         d_rgb = d_rgb.contiguous().float()
         d_head = torch.empty_like(head)
         g_grids = [torch.zeros_like(g, memory_format=torch.contiguous_format) for g in grids]
         g_basis = torch.zeros_like(basis, memory_format=torch.contiguous_format)
-        gt = _tensors_struct([g_grids[0:3], g_grids[3:6], g_grids[6:9], g_grids[9:12]], g_basis)
+        g_table = None if table is None else torch.zeros_like(table, memory_format=torch.contiguous_format)
+        gt = _tensors_struct([g_grids[0:3], g_grids[3:6], g_grids[6:9], g_grids[9:12]], g_basis, g_table)
         if g_basis.numel() == 0:
             raise RuntimeError('basis_mat has no columns')
         with torch.cuda.device(dev):
             _lib.check(L.hr_train_backward(ctx.handle, _ptr(rays), _ptr(head), _ptr(d_rgb), rays.shape[0], ctx.white_bg, _ptr(d_head),
                                            C.byref(gt), _stream(dev)), 'hr_train_backward')
-        return (None, None, d_head, None, g_basis, *g_grids)
+        return (None, None, d_head, None, g_basis, *g_grids) + (() if table is None else (g_table,))
 
 
 class CoarseRows(torch.autograd.Function):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 15
+#define HR_ABI_VERSION 16
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -288,8 +288,8 @@ int hr_upsample_plane(const float* src_dev, int32_t channels, int32_t h, int32_t
  * caller's column order, and hr_train_backward returns dL/d head for it.
  * All tensors are device memory, float32, in the reference's parameter layouts (same shapes as the hr_model_upload
  * names): a[j] = density_plane.j | density_plane_space.j, b[j] = density_line.j | density_plane_time.j, likewise app_*.
- * Supported: every model hr_model_create / hr_model_create_cascade accepts, with float32 grids and without a
- * color_transform table (those two return HR_E_INVALID naming the feature).
+ * Supported: every model hr_model_create / hr_model_create_cascade accepts, with float32 grids (float16 grids return
+ * HR_E_INVALID naming the feature).
  * Activation / encoding / mask schedules are those of the model's current configuration (hr_model_update_config). */
 typedef struct hr_train_tensors {
     float* density_a[3];
@@ -297,6 +297,7 @@ typedef struct hr_train_tensors {
     float* app_a[3];
     float* app_b[3];
     float* basis;                        /* basis_mat.weight (app_dim, sum n_app) */
+    float* color_table;                  /* color_embedding (color_table_views, 12); NULL / ignored when the model has none */
 } hr_train_tensors;
 
 /* point_prediction cascades (nlf/embedding/point.py:137-203): the same three calls serve their fine level -- head_dev is then

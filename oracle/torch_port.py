@@ -171,6 +171,13 @@ class TorchPort:
                 for name, n, act in zip(pp['names'], pp['shapes'], pp['acts']):
                     x[name] = _act(act, h[..., off:off + n])
                     off += n
+            elif typ == 'color_transform':                  # point.py:585-596: a no-op unless dataset.val_all
+                if o.ds.get('val_all', False):
+                    if getattr(self, 'color_table', None) is None:
+                        self.color_table = torch.from_numpy(o.sd[f'{o.EMB}{idx}.color_embedding']).to(self.dev)
+                    row = self.color_table[torch.round(rays[:, -2]).long()]
+                    x['color_transform_global'] = _act(Act(ecfg.get('transform_activation')), row[:, :9])
+                    x['color_shift_global'] = _act(Act(ecfg.get('shift_activation')), row[:, -3:])
             elif typ == 'advect_points':                      # point.py:780-831, flow_utils.py:10-35
                 t = rays[:, -1:]
                 K, Fr = o.ds['num_keyframes'], o.ds['num_frames']
@@ -374,6 +381,9 @@ class TorchPort:
             out = out + (1.0 - weight.sum(-1)[:, None])
         if 'color_scale_global' in x:                       # scale_shift_color_one, tensorf_utils.py:275-281
             out = out * (x['color_scale_global'][:, 0, :] + 1.0) + x['color_shift_global'][:, 0, :]
+        elif 'color_transform_global' in x:                 # transform_color_one, tensorf_utils.py:308-320
+            T = x['color_transform_global'].reshape(B, 3, 3)
+            out = out + (T * out[:, None, :]).sum(-1) + x['color_shift_global']
         return out if train else out.clamp(0, 1)
 
     @torch.no_grad()

@@ -69,7 +69,5 @@ def trainable_sweep_cases(cascades=False):
             continue
         with plan.at_iteration(g.iteration):
             hc = plan.compile_model(g.cfg, g.dataset, g.grid, iteration=g.iteration)[1]
-        if hc.color_table_views > 0:
-            continue
         out.append(c)
     return out

@@ -16,7 +16,7 @@ const char* ht_unsupported(const hr_config* c) { return hr_train_unsupported(*c)
 // the caller); d_rgb == NULL runs the forward only.  Returns 0, or -1 when z_channels / ca_total exceed the bounds.
 int ht_train(const hr_config* c, const float* rays, const float* head, long long n, const float* d_rgb, float* rgb, float* d_head,
              const HrGridPlane* planes, float** g_a, float** g_b, const float* basis, float* d_basis, int n_basis_cols, int ca_total,
-             int white_bg)
+             int white_bg, const float* color_table, float* d_color_table)
 {
     if (c->z_channels > 256 || ca_total > HR_TRAIN_MAX_CA) return -1;
     HrTrainArgs a = {};
@@ -24,6 +24,7 @@ int ht_train(const hr_config* c, const float* rays, const float* head, long long
     a.rays = rays; a.head = head; a.n_rays = n; a.rgb = rgb; a.d_rgb = d_rgb; a.d_head = d_head;
     for (int j = 0; j < 3; ++j) { a.planes[j] = planes[j]; a.g_a[j] = g_a[j]; a.g_b[j] = g_b[j]; }
     a.basis = basis; a.d_basis = d_basis; a.n_basis_cols = n_basis_cols; a.ca_total = ca_total; a.white_bg = white_bg;
+    a.color_table = color_table; a.d_color_table = d_color_table;
     // the tape between the phases (the device keeps it in a workspace of the model)
     const size_t NS = (size_t)n * c->z_channels;
     std::vector<float> ds(NS), dfeat(NS), dpre(3 * NS), ddc(NS), dts(NS);

@@ -91,11 +91,16 @@ def test_backward_matches_autograd(ht, case, white):
     n = min(192, g.rays.shape[0])
     rays = torch.from_numpy(np.ascontiguousarray(g.rays[:n], np.float32))
     grids = [t for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp]
-    for t in grids + [port.basis]:
+    table = None
+    if hc.color_table_views > 0:                              # per-camera colour table (ColorTransformEmbedding, dataset.val_all)
+        key = [k for k in g.state_dict if k.endswith('color_embedding')][0]
+        table = port.color_table = torch.from_numpy(np.ascontiguousarray(g.state_dict[key], np.float32))
+    leaves = grids + [port.basis] + ([table] if table is not None else [])
+    for t in leaves:
         t.requires_grad_(True)
 
     def reference(rays):
-        for t in grids + [port.basis]:
+        for t in leaves:
             t.grad = None
         with torch.no_grad():
             if cascade:                                       # the point MLP's own output, run once without a graph
@@ -138,8 +143,10 @@ def test_backward_matches_autograd(ht, case, white):
     d_head = np.zeros_like(head0.numpy())
     hnp, rnp, Gnp = np.ascontiguousarray(head0.numpy()), np.ascontiguousarray(rays.numpy()), np.ascontiguousarray(G.numpy())
     f = lambda a: a.ctypes.data_as(FP)
+    tab = np.ascontiguousarray(table.detach().numpy()) if table is not None else None
+    d_tab = np.zeros_like(tab) if tab is not None else None
     rc = ht.ht_train(C.byref(hc), f(rnp), f(hnp), C.c_longlong(n), f(Gnp), f(rgb), f(d_head), planes, g_a, g_b, f(basis), f(d_basis),
-                     basis.shape[1], ca_total, white)
+                     basis.shape[1], ca_total, white, f(tab) if tab is not None else None, f(d_tab) if tab is not None else None)
     assert rc == 0
 
     def close(got, ref, what):
@@ -162,6 +169,8 @@ def test_backward_matches_autograd(ht, case, white):
             assert not d_head.reshape(ref_h.shape)[..., col].any()
     assert live >= 3
     close(d_basis, port.basis.grad.numpy(), 'd basis_mat')
+    if table is not None:
+        close(d_tab, table.grad.numpy(), 'd color_embedding')
     for j, (pa, pb, nd, na, aoff) in enumerate(packed):
         ga, gb = gbuf[j]
         for name, got, ref_t, cnt, off in (('density a', ga, port.d_a[j], nd, 0), ('density b', gb, port.d_b[j], nd, 0),
@@ -177,11 +186,10 @@ def test_backward_matches_autograd(ht, case, white):
 
 
 def test_unsupported_models_are_named(ht):
-    g = Golden('sweep/immersive_z_plane')                 # per-camera colour table (only read with dataset.val_all)
-    hc = plan.compile_config(g.cfg, g.dataset, g.grid)
-    assert hc.color_table_views > 0 and b'color_transform' in ht.ht_unsupported(C.byref(hc))
-    hc = plan.compile_config(Golden('donerf_sphere_small').cfg, g.dataset, g.grid, grid_dtype='fp16')
+    g = Golden('donerf_sphere_small')
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid, grid_dtype='fp16')
     assert b'float16' in ht.ht_unsupported(C.byref(hc))
+    assert ht.ht_unsupported(C.byref(plan.compile_config(g.cfg, g.dataset, g.grid))) is None
 
 
 PIN = {'points': 0, 'viewdirs': 1, 'origins': 2, 'times': 3}      # HR_PIN_* (include/hyperreel_hip.h)
