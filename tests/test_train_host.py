@@ -236,3 +236,48 @@ def test_cascade_rows_forward_and_backward_match_autograd(ht, case):
         else:
             assert not got_c[..., col].any()
     assert live >= 1
+
+
+@pytest.mark.parametrize('model,z', [('donerf_sphere', 96), ('technicolor_z_plane', 12), ('donerf_cylinder', 200)])
+def test_backward_at_other_sample_counts(ht, model, z):
+    """The per-ray arrays are sized by the next power of two of z_channels (8 ... 256): sample counts that are not powers
+    of two, below and above one wavefront, against autograd (forward, head and plane gradients)."""
+    from hyperreel_amd import config as cfgmod
+    from hyperreel_amd import scenes
+    cfg, ds = cfgmod.model_config(model, z_channels=z), cfgmod.dataset_scalars(model)
+    grid = [24, 20, 16]
+    sd = scenes.make_state_dict(cfg, ds, grid, seed=4, density='dense', app_scale=1.0)
+    video = cfg.color.net.type == 'tensor_vm_split_time'
+    if 'z_plane' in model:
+        rays_np = scenes.random_rays(48, 2, video, pos_mean=(0, 0, 1.0), pos_std=0.15, dir_mean=(0, 0, -1.2), dir_std=0.5)
+    else:
+        rays_np = scenes.random_rays(48, 2, video)
+    hc = plan.compile_config(cfg, ds, grid)
+    assert hc.z_channels == z
+    port = TorchPort(cfg, ds, sd)
+    rays = torch.from_numpy(rays_np)
+    grids = [t.requires_grad_(True) for grp in (port.d_a, port.d_b, port.a_a, port.a_b) for t in grp]
+    port.basis.requires_grad_(True)
+    with torch.no_grad():
+        head0 = port._mlp(port._param_pe(rays))
+    head = head0.clone().requires_grad_(True)
+    rgb_ref = port.color(port.embed(rays, head=head), train=True, white_bg=True)
+    G = torch.randn(rgb_ref.shape, generator=torch.Generator().manual_seed(1))
+    (rgb_ref * G).sum().backward()
+    planes, packed, ca_total = pack_grids(port, port.o.video)
+    gbuf = [(np.zeros_like(pa), np.zeros_like(pb)) for pa, pb, *_ in packed]
+    g_a = (FP * 3)(*[b[0].ctypes.data_as(FP) for b in gbuf])
+    g_b = (FP * 3)(*[b[1].ctypes.data_as(FP) for b in gbuf])
+    basis = np.ascontiguousarray(port.basis.detach().numpy())
+    d_basis, rgb, d_head = np.zeros_like(basis), np.zeros((48, 3), np.float32), np.zeros_like(head0.numpy())
+    f = lambda a: a.ctypes.data_as(FP)
+    hnp, Gnp = np.ascontiguousarray(head0.numpy()), np.ascontiguousarray(G.numpy())
+    assert ht.ht_train(C.byref(hc), f(rays_np), f(hnp), C.c_longlong(48), f(Gnp), f(rgb), f(d_head), planes, g_a, g_b, f(basis), f(d_basis),
+                       basis.shape[1], ca_total, 1, None, None) == 0
+    ref_np = rgb_ref.detach().numpy()
+    assert (np.abs(rgb - ref_np) <= 1e-5 * np.maximum(1.0, np.abs(ref_np))).all()
+    scale = np.abs(head.grad.numpy()).max()
+    assert scale > 0 and np.abs(d_head - head.grad.numpy()).max() <= 2e-4 * scale
+    ref_plane = port.d_a[0].grad.numpy()[0].transpose(1, 2, 0)
+    got = gbuf[0][0][..., :ref_plane.shape[-1]]
+    assert np.abs(got - ref_plane).max() <= 2e-4 * np.abs(ref_plane).max()
