@@ -177,3 +177,30 @@ def test_row_features_equal_the_kernel_encoding(hm):
         want = np.zeros((64, fine.mlp_in), np.float32)
         hm.hm_features(C.byref(kc), fp(rows), 64, fp(want))
         assert np.abs(row_features(fine, torch.from_numpy(rows)).numpy() - want).max() <= 2e-7, case
+
+
+def test_bilinear_taps_partition_unity_and_stay_in_range(hm):
+    """Property of hr_make_tap (one axis of F.grid_sample, align_corners=True, zeros padding) over random coordinates and
+    sizes: indices are valid texels, weights are non-negative, sum to 1 strictly inside the image and to at most 1 at
+    and beyond its border, and vanish entirely more than one texel outside."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(2, 1100), st.integers(0, 2 ** 31 - 1))
+    def prop(size, seed):
+        rng = np.random.default_rng(seed)
+        g = np.concatenate([rng.uniform(-1.6, 1.6, 256), [-1.0, 1.0, 0.0, -1.0 - 2.0 / (size - 1), 1.0 + 2.0 / (size - 1)]]).astype(np.float32)
+        n = g.size
+        i0, i1 = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        w0, w1 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        hm.hm_taps(fp(g), n, size, i0.ctypes.data_as(IP), i1.ctypes.data_as(IP), fp(w0), fp(w1))
+        assert ((0 <= i0) & (i0 < size) & (0 <= i1) & (i1 < size)).all()
+        assert (w0 >= 0).all() and (w1 >= 0).all() and (w0 + w1 <= 1 + 1e-6).all()
+        ix = (g.astype(np.float64) + 1) / 2 * (size - 1)
+        inside = (ix > 0.01) & (ix < size - 1.01)
+        assert np.abs((w0 + w1)[inside] - 1).max(initial=0) <= 1e-5
+        far = (ix < -1.01) | (ix > size + 0.01)
+        assert not (w0 + w1)[far].any()
+
+    prop()
