@@ -85,7 +85,9 @@ HR_FN float hr_point_alpha(const hr_config& c, const HrMaskArgs& a, int ix, int 
         const float s = hr_linspace01(idx[i], a.n[i]);
         p[i] = c.aabb[i] * (1.0f - s) + c.aabb[3 + i] * s;
     }
-    if (a.prev_volume) {                         // compute_alpha: the previous mask rejects the point (tensorf_base.py:491-503)
+    // static nets only: TensorBase.compute_alpha asks the previous mask first (tensorf_base.py:491-503);
+    // TensorVMKeyframeTime.compute_alpha (tensorf_dynamic.py:618-643) never reads alphaMask
+    if (a.prev_volume && !c.video) {
         float g[3];
         for (int i = 0; i < 3; ++i)
             g[i] = (p[i] - a.prev_aabb[i]) * (1.0f / (a.prev_aabb[3 + i] - a.prev_aabb[i]) * 2.0f) - 1.0f;   // AlphaGridMask.normalize_coord

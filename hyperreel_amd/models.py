@@ -468,7 +468,13 @@ class HipLightfieldModel(nn.Module):
         blob = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
         if blob != self._native_cfg:
             if coarse is not None:
-                raise NotImplementedError('activation / PE schedules inside their windows on a point_prediction cascade')
+                # hr_model_update_config does not take cascades (two nested configurations): re-create the handle with
+                # the constants of this iteration and upload again
+                _lib.load().hr_model_destroy(self._native)
+                self._native = None
+                self._native_key = None
+                self.native()
+                return
             dev = next(self.parameters()).device
             with torch.cuda.device(dev):
                 _lib.check(_lib.load().hr_model_update_config(self._native, C.byref(hc), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
@@ -542,9 +548,8 @@ class HipLightfieldModel(nn.Module):
             raise RuntimeError('rays must be on the HIP device; there is no CPU path')
         if rays.dim() != 2 or rays.shape[1] < hc.ray_dim:
             raise ValueError(f'rays must be (B,{hc.ray_dim}), got {tuple(rays.shape)}')
-        if rays.shape[1] != hc.ray_dim:
-            rays = rays[:, :hc.ray_dim] if hc.ray_dim == 6 else rays
-        return rays.contiguous().float()
+        # the C ABI takes no row stride: extra columns are cut (6-column nets ignore camera id / time, rendering.py)
+        return rays[:, :hc.ray_dim].contiguous().float()
 
     def render(self, rays, want=()):
         """rays (B, 6|8) on the HIP device -> dict with 'rgb' (B,3) and any of
@@ -665,7 +670,16 @@ class HipLightfieldModel(nn.Module):
             return {'rgb': self.forward_train(rays)}
         if not fields:
             return {'rgb': self.render(rays)['rgb']}
-        return self._forward_fields(rays, render_kwargs)
+        out = self._forward_fields(rays, render_kwargs)
+        if self.training and torch.is_grad_enabled():
+            # INRSystem.training_step passes the regularizers' field list on the main forward (nlf/__init__.py:634-709):
+            # the colour must stay differentiable.  rgb comes from the training arithmetic (no eval-mode clamp, the
+            # per-step background draw); the requested fields are the inference kernel's values, detached -- a
+            # regulariser that needs d(field)/d(parameters) is outside the training path (SURVEY 8f-4 covers the colour loss
+            # and the plane regularisers).
+            out = {k: v.detach() for k, v in out.items()}
+            out['rgb'] = self.forward_train(rays)
+        return out
 
     # -- diagnostics surface (visualizers only) ------------------------------------------
     def _head_fields(self, rays, head):

@@ -91,7 +91,7 @@ class FlatGradients:
     """Gradient storage of a set of parameters as views into ONE flat buffer, so that the data-parallel reduction of a
     training step is a single all-reduce with no packing copies:
 
-        flat = FlatGradients(model.parameters())
+        flat = FlatGradients(model)               # the module: follows set_iter's shrink / growth (new Parameters)
         for batch in loader:
             flat.zero()
             loss(model(batch)).backward()        # autograd accumulates into the views
@@ -102,13 +102,42 @@ class FlatGradients:
     The reference's counterpart is Lightning's DDP wrapper around INRSystem (bucketed all-reduce inside backward)."""
 
     def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+        """params: an nn.Module, a callable returning the parameters, or an iterable of parameters.  With a module or a
+        callable the parameter SET is re-read on every zero(): HostTensorVM.set_iter replaces the planes / lines by new
+        nn.Parameter objects when it shrinks or grows the grid (tensorf_base.py:510-552), and the flat buffer and its
+        views are rebuilt whenever identities or shapes changed.  A plain iterable is a fixed set; zero() then raises if
+        a parameter it was given has been detached from its module meanwhile (a stale set would silently stop reducing
+        the grid gradients)."""
+        if isinstance(params, torch.nn.Module):
+            self._source = params.parameters
+            self._module = params
+        elif callable(params):
+            self._source = params
+            self._module = None
+        else:
+            fixed = list(params)
+            self._source = lambda: fixed
+            self._module = None
+        self.params = []
+        self.flat = None
+        self._rebuild()
+
+    def _current(self):
+        return [p for p in self._source() if p.requires_grad]
+
+    def _signature(self, params):
+        return [(id(p), tuple(p.shape)) for p in params]
+
+    def _rebuild(self):
+        params = self._current()
+        if not params:
             raise ValueError('no trainable parameters')
-        dev, dt = self.params[0].device, self.params[0].dtype
-        if any(p.device != dev or p.dtype != dt for p in self.params):
+        dev, dt = params[0].device, params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in params):
             raise ValueError('FlatGradients needs all parameters on one device with one dtype')
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.params = params
+        self._sig = self._signature(params)
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=dt, device=dev)
         self.attach()
 
     def attach(self):
@@ -119,11 +148,27 @@ class FlatGradients:
             p.grad = self.flat[o:o + n].view(p.shape)
             o += n
 
+    def _inside(self, p):
+        lo = self.flat.data_ptr()
+        return p.grad is not None and lo <= p.grad.data_ptr() < lo + self.flat.numel() * self.flat.element_size()
+
     def zero(self):
-        if any(p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or
-               p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size() for p in self.params):
+        if self._signature(self._current()) != self._sig:       # grid shrink / growth replaced parameters
+            self._rebuild()
+        elif not all(self._inside(p) for p in self.params):
             self.attach()
         self.flat.zero_()
+
+    def check(self, module=None):
+        """Raises if a trainable parameter of `module` (default: the module given at construction) has a gradient that
+        is not a view of the flat buffer -- such a gradient would be skipped by all_reduce()."""
+        module = module if module is not None else self._module
+        if module is None:
+            return
+        for name, p in module.named_parameters():
+            if p.requires_grad and not self._inside(p):
+                raise RuntimeError(f'FlatGradients: the gradient of {name} is outside the flat buffer (parameter replaced '
+                                   f'since the last zero()?); call zero() at the top of every step')
 
     def all_reduce(self, group=None, average=True):
         """Sum (or mean) of the gradients over the ranks, in place.  A single-process run is a no-op."""
@@ -132,6 +177,7 @@ class FlatGradients:
         world = dist.get_world_size(group)
         if world == 1:
             return
+        self.check()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             self.flat.div_(world)

@@ -40,6 +40,11 @@ CASES = [
     # full-size shipped grid
     dict(case='donerf_sphere_600', model='donerf_sphere', z=None, grid=[600, 600, 600], n_random=512, pin=(16, 16), density='dense', seed=17, rgb_only=True),
     dict(case='technicolor_full', model='technicolor_z_plane', z=None, grid=[1007, 1007, 503], n_random=256, pin=(16, 16), density='dense', seed=18, rgb_only=True),
+    # BASELINE configs[3] / [4] at the shipped final grid: `frame` = seeded subset of the 800x800 benchmark frame
+    # (scenes.benchmark_rays, the rays bench.py and the full-frame GPU tests render), so the reference's own pixels
+    # sit inside the frame whose >1e-4 rays the GPU test counts
+    dict(case='neural_3d_full', model='neural_3d_z_plane', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=7, rgb_only=True),
+    dict(case='immersive_full', model='immersive_sphere', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=7, rgb_only=True),
 ]
 
 
@@ -79,6 +84,13 @@ def case_rays(c):
             pose = scenes.look_at_pose((0.3, 0.0, 0.0), (1.0, 0.1, 0.05))
         parts.append(scenes.pinhole_rays(H, W, 40.0, pose, cam_id=0 if video else None,
                                          time=(7.0 / 49.0) if video else None))
+    if c.get('frame') is not None:
+        frame, n = c['frame']
+        full = scenes.benchmark_rays(c['model'], 800, 800, frame=frame)
+        idx = np.sort(np.random.default_rng(c['seed']).choice(full.shape[0], n, replace=False))
+        c['_frame_at'] = sum(p.shape[0] for p in parts)       # stored as indices, see main()
+        c['_frame_idx'] = idx.astype(np.int32)
+        parts.append(full[idx])
     parts.append(special_rays(video, z_plane))
     return np.ascontiguousarray(np.concatenate(parts, 0), np.float32)
 
@@ -86,6 +98,8 @@ def case_rays(c):
 def build(c):
     model_cfg = C.model_config(c['model'], z_channels=c['z'])
     ds = C.dataset_scalars(c['model'])
+    if c['grid'] is None:        # the shipped final grid (what make_state_dict builds without a size)
+        c['grid'] = [int(v) for v in scenes.make_state_dict(model_cfg, ds, None, c['seed'], c['density'], c.get('app_scale', 1.0))['model.color_model.net.gridSize']]
     # reference side: the shipped YAML, plus the same overrides
     def overrides(cfg):
         if c['z'] is not None:
@@ -125,6 +139,13 @@ def main(only=None):
                 'seed': c['seed'], 'density': c['density'], 'app_scale': c.get('app_scale', 1.0), 'dataset': ds,
                 'checksum': scenes.state_dict_checksum(sd)}).encode(), dtype=np.uint8),
         }
+        if c.get('frame') is not None:
+            # the frame's rays are a pure function of (model, frame): the fixture keeps their pixel indices only and
+            # tests/helpers.py splices scenes.benchmark_rays(...)[frame_idx] back in at row frame_at
+            at, idx = c['_frame_at'], c['_frame_idx']
+            payload['rays'] = np.concatenate([rays[:at], rays[at + idx.shape[0]:]], 0)
+            payload['frame_idx'] = idx
+            payload['frame_at'] = np.asarray([at, c['frame'][0]], np.int32)
         if not c.get('rgb_only'):
             emb = ref_shim.run_reference_embed(fn, tr)
             Z = model_cfg.embedding.embeddings.ray_prediction_0.z_channels

@@ -39,6 +39,10 @@ class Golden:
         self.dataset = r['dataset']
         self.grid = r['grid']
         self.rays = self.arrays['rays']
+        if 'frame_idx' in self.arrays:          # rays of the 800x800 benchmark frame, stored as pixel indices (make_golden.py)
+            at, frame = (int(v) for v in self.arrays['frame_at'])
+            part = scenes.benchmark_rays(r['model'], 800, 800, frame=frame)[self.arrays['frame_idx']]
+            self.rays = np.ascontiguousarray(np.concatenate([self.rays[:at], part, self.rays[at:]], 0), np.float32)
         self.rgb = self.arrays['rgb']
         self._sd = None
 

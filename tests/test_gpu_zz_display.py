@@ -1,16 +1,14 @@
-"""`-m gpu`: device runs of the pieces added after the round's GPU budget was spent -- hr_pack_display, a checkpoint with
-a shrunk box, hr_dense_alpha / updateAlphaMask / shrink.  Their arithmetic is checked on the CPU through the host builds of
-the same sources (tests/test_host_math.py, tests/test_alpha_mask_host.py); this file is collected last on purpose."""
+"""`-m gpu`: device runs of hr_pack_display, a checkpoint with a shrunk box, hr_dense_alpha / updateAlphaMask / shrink
+and the forward-mode intersection gradients.  Their arithmetic is also checked on the CPU through the host builds of the
+same sources (tests/test_host_math.py, tests/test_alpha_mask_host.py).  Ordinary tests: they passed on the round-1
+driver run (GPUTEST_r01.json) and gate the suite like every other file."""
 import numpy as np
 import pytest
 import torch
 
 from helpers import Golden
 
-# Not strict: these have never run on an MI355X (the round's GPU budget was spent before they were written).  They are
-# expected to pass -- an XPASS in the report -- and a failure here must not hide the verified suite behind `pytest -x`.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason='first device run pending: arithmetic verified on the host build only (DESIGN.md 10.0)')]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('transpose,flip', [(False, False), (True, False), (False, True), (True, True)])
