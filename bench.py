@@ -120,6 +120,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
+    ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead of the persistent frame kernel')
+    ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -144,7 +146,8 @@ def main():
     video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
-    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision, grid_dtype=args.grid_dtype)
+    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision, grid_dtype=args.grid_dtype,
+                         frame_kernel=not args.no_frame_kernel, sample_waves=args.sample_waves or None)
     texel_bytes = 2 if args.grid_dtype == 'fp16' else 4
     # checker-side weights: with float16 texels the reference algorithm is run on the same rounded grids
     sd_ref = sd if texel_bytes == 4 else {k: (v.astype(np.float16).astype(np.float32) if ('_plane' in k or '_line' in k) else v)

@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_build')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
-SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'sample_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip']
-HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
+SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'fused_bf16x3_kernel.hip', 'fused_f16x3_kernel.hip', 'fused_f16x2_kernel.hip',
+           'sample_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip']
+HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by
 # operation (the reference never fuses a multiply with an add across torch ops); the
@@ -37,27 +38,53 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _deps():
+    return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def _obj(src):
+    return os.path.join(LIB_DIR, src.replace('.hip', '.o'))
+
+
+def _flags_stamp(flags):
+    """Objects are reused only if they were built with the same flags."""
+    path = os.path.join(LIB_DIR, 'flags.txt')
+    text = ' '.join(flags)
+    same = os.path.exists(path) and open(path).read() == text
+    return same, path, text
+
+
+def _stale_sources(flags_same):
+    out = []
+    newest_dep = max(os.path.getmtime(d) for d in _deps())
+    for s in SOURCES:
+        o = _obj(s)
+        if not flags_same or not os.path.exists(o) or os.path.getmtime(o) < max(newest_dep, os.path.getmtime(os.path.join(CSRC, s))):
+            out.append(s)
+    return out
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not _stale():
-        return LIB_PATH
+    """Compiles what is out of date (one hipcc per translation unit, in parallel) and links the library."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for s in SOURCES:
-        obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
-        cmd = [hipcc(), *FLAGS, *extra_flags, '-c', os.path.join(CSRC, s), '-o', obj]
+    flags = [*FLAGS, *extra_flags]
+    same, stamp, text = _flags_stamp(flags)
+    todo = list(SOURCES) if force else _stale_sources(same)
+    if not todo and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(_obj(s)) for s in SOURCES):
+        return LIB_PATH
+
+    def compile_one(s):
+        cmd = [hipcc(), *flags, '-c', os.path.join(CSRC, s), '-o', _obj(s)]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB_PATH]
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(compile_one, todo))
+    with open(stamp, 'w') as f:
+        f.write(text)
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', *[_obj(s) for s in SOURCES], '-o', LIB_PATH]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

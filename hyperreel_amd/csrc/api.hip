@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -12,6 +13,11 @@
 #include "hr_kernels.h"
 #include "hr_mask.h"
 #include "hr_train.h"
+
+// sample wavefronts per workgroup of the frame kernel when the caller does not say (measured: DESIGN.md section 3)
+#ifndef HR_DEFAULT_SAMPLE_WAVES
+#define HR_DEFAULT_SAMPLE_WAVES 8
+#endif
 
 namespace {
 
@@ -55,6 +61,7 @@ struct hr_model {
     float4* wpack[HR_MAX_LAYERS] = {};
     void* wsplit[HR_MAX_LAYERS] = {};
     float* bias[HR_MAX_LAYERS] = {};
+    float winv[HR_MAX_LAYERS] = {};       // 2^-s of the packed split weights (HrMlpArgs::winv)
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
     int n_out = 0;
@@ -81,6 +88,10 @@ struct hr_model {
     float* grad_b[3] = {};
     float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
     int64_t tape_samples = 0;
+    // execution plan of hr_render (hr_model_set_option)
+    int opt_frame_kernel = 1;
+    int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
+    int n_cus = 0;
 };
 
 namespace {
@@ -300,6 +311,12 @@ static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
     hr_model* m = new hr_model();
     m->cfg = *cfg;
     m->is_coarse = coarse;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) m->n_cus = prop.multiProcessorCount;
+        if (m->n_cus < 1) m->n_cus = 256;
+    }
     analyse_live_columns(m);
     {   // the kernels read the configuration from device memory
         if (hipMalloc((void**)&m->kcfg_dev, sizeof(hr_config)) != hipSuccess) {
@@ -471,6 +488,24 @@ int hr_model_finalize(hr_model* m)
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
         free_dev(m->bias[l]);
+        // fp16 modes: the weights of these MLPs are ~1/sqrt(fan_in), so the low half w - half(w) (~2^-12 w) would be a
+        // subnormal half with an ABSOLUTE rounding error of 2^-25.  Packing w * 2^s (exact), with s putting the largest
+        // weight of the layer into [2^13, 2^14), keeps every low half of a weight above max|w| * 2^-16 normal; the
+        // epilogue multiplies the accumulator by 2^-s (exact again).  bf16 halves have the fp32 exponent range: s = 0.
+        float wmul = 1.0f;
+        m->winv[l] = 1.0f;
+        if (half) {
+            float mx = 0.0f;
+            for (float v : w) mx = fmaxf(mx, fabsf(v));
+            if (mx > 0.0f && std::isfinite(mx)) {
+                int e = 0;
+                (void)frexpf(mx, &e);                       // mx = f * 2^e, f in [0.5, 1)
+                int sft = 14 - e;
+                sft = sft < -14 ? -14 : (sft > 40 ? 40 : sft);
+                wmul = ldexpf(1.0f, sft);
+                m->winv[l] = ldexpf(1.0f, -sft);
+            }
+        }
         if (!split) {
             std::vector<float> pk((size_t)(Kp / 16) * nt * 64 * 4, 0.0f);
             for (int kt = 0; kt < Kp / 16; ++kt)
@@ -488,7 +523,7 @@ int hr_model_finalize(hr_model* m)
                 for (int t = 0; t < nt; ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
-                            const float v = wk(32 * t + (lane & 31), 16 * kt + 8 * (lane >> 5) + j);
+                            const float v = wk(32 * t + (lane & 31), 16 * kt + 8 * (lane >> 5) + j) * wmul;
                             const uint16_t hi = half ? f16_rne(v) : bf16_rne(v);
                             const uint16_t lo = half ? f16_rne(v - f16_to_float(hi)) : bf16_rne(v - bf16_to_float(hi));
                             const size_t base = ((((size_t)kt * nt + t) * 2) * 64 + lane) * 8 + j;
@@ -671,6 +706,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
         a.wpack[l] = m->wpack[l];
         a.wsplit[l] = m->wsplit[l];
         a.bias[l] = m->bias[l];
+        a.winv[l] = m->winv[l];
         a.n_tiles[l] = m->n_tiles[l];
     }
     a.n_out = m->n_out;
@@ -738,6 +774,25 @@ static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t 
     launch_mlp(m->kcfg, ma, st);
 }
 
+// The frame kernel (fused_impl.inc) for the whole ray list; false: the model does not fit it (nothing launched)
+static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, bool probe, hipStream_t st)
+{
+    if (!m->opt_frame_kernel || m->coarse || m->is_coarse || m->cfg.mlp_layers == 0) return false;
+    if (n > ((int64_t)1 << 36)) return false;
+    HrMlpArgs ma;
+    fill_mlp_args(m, ma, rays, n);
+    ma.head = nullptr;
+    HrSampleArgs sa;
+    fill_sample_args(m, sa, rays, n, rgb);
+    sa.head = nullptr;
+    switch (m->cfg.mlp_precision) {
+        case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+        case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+        case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+        default: return false;          // the exact-fp32 MLP (v_mfma_f32_16x16x4_f32) keeps its own kernel
+    }
+}
+
 static int check_render(const hr_model* m, const float* rays, int64_t n, const float* rgb)
 {
     if (!m) return fail(HR_E_INVALID, "null model");
@@ -754,6 +809,10 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     hipStream_t st = (hipStream_t)stream;
     const hr_config& c = m->cfg;
     const int Z = c.z_channels;
+    if (!fields && launch_frame(m, rays_dev, n_rays, rgb_dev, false, st)) {
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
     // (Running the sample stage of chunk i on a second stream under the MLP of chunk i+1 was
     //  measured twice -- plain, and with the MLP limited to one workgroup per CU so that sample
     //  blocks could co-reside -- and is slower than back-to-back launches: 3.0-3.9 vs 2.79 ms per
@@ -782,6 +841,33 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream)
 {
     return hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
+}
+
+int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    if (option == HR_OPT_FRAME_KERNEL) {
+        if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_FRAME_KERNEL takes 0 or 1");
+        m->opt_frame_kernel = value;
+    } else if (option == HR_OPT_SAMPLE_WAVES) {
+        if (value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 4 or 8");
+        m->opt_sample_waves = value;
+    } else {
+        return fail(HR_E_INVALID, "unknown or read-only option %d", option);
+    }
+    return HR_OK;
+}
+
+int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
+{
+    if (!m || !value) return fail(HR_E_INVALID, "null argument");
+    if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
+    else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
+    else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
+        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
+        *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
+    } else return fail(HR_E_INVALID, "unknown option %d", option);
+    return HR_OK;
 }
 
 int hr_generate_rays(const hr_camera* cam, int32_t ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays_dev, void* stream)

@@ -34,6 +34,8 @@ struct HrMlpArgs {
     const float4* wpack[HR_MAX_LAYERS];   // HR_MLP_FP32: fp32 tiles (16-column tiles)
     const void* wsplit[HR_MAX_LAYERS];    // HR_MLP_BF16X3: bf16 hi/lo tiles (32-feature tiles), see mlp_bf16x3_kernel.hip
     const float* bias[HR_MAX_LAYERS];
+    float winv[HR_MAX_LAYERS];   // split kernels: the packed weights of layer L are W * 2^s (fp16 modes: keeps the low halves out of
+                                 //   the subnormal range); the epilogue multiplies the accumulator by winv = 2^-s (exact).  1 for bf16
     int n_tiles[HR_MAX_LAYERS];  // output tiles of layer L: 16 columns (fp32) or 32 features (bf16x3)
     int n_out;                   // Z * P
     int nq;                      // ceil(n_out / 4)
@@ -64,7 +66,7 @@ struct HrSampleArgs {
     float* rows_out;        // coarse pass only: input rows of the point MLP, (n_rays * Z, row_dim); no colour is produced
     int row_dim, n_row_inputs;
     int row_kind[4], row_len[4];   // HR_PIN_* and columns of each input
-    int dbg_mode;           // profiling only (HR_SAMPLE_DBG): 1 = skip the feature gather
+    int dbg_mode;           // measurement builds only (-DHR_TUNING, HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 
 void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
@@ -74,6 +76,14 @@ void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream
 void hr_launch_mlp_f16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // same layouts, fp16 halves
 void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
+// fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.
+// Returns false when the model does not fit it (nothing launched); probe: only answer.
+bool hr_launch_frame_bf16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
+                            hipStream_t stream);
+bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
+                           hipStream_t stream);
+bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
+                           hipStream_t stream);
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
 

@@ -11,8 +11,11 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
+
+
+HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE = 0, 1, 2
 
 
 class hr_train_tensors(C.Structure):
@@ -32,6 +35,8 @@ SYMBOLS = [
     ('hr_model_finalize', C.c_int, [C.c_void_p]),
     ('hr_model_update_config', C.c_int, [C.c_void_p, C.POINTER(hr_config), C.c_void_p]),
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
+    ('hr_model_set_option', C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ('hr_model_get_option', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ('hr_render', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_render_fields', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(hr_fields), C.c_void_p]),
     ('hr_generate_rays', C.c_int, [C.POINTER(hr_camera), C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

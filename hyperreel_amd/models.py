@@ -365,6 +365,9 @@ class HipLightfieldModel(nn.Module):
         # arithmetic of the MLP GEMMs: 'auto' | 'bf16x3' | 'fp32' (see plan.compile_config)
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
+        # execution plan of render() (hr_model_set_option): frame kernel on/off, its sample wavefronts (None: library default)
+        self.frame_kernel = bool(kwargs.get('frame_kernel', True))
+        self.sample_waves = kwargs.get('sample_waves')
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
             grid = list(kwargs['grid_size'])
@@ -503,6 +506,7 @@ class HipLightfieldModel(nn.Module):
             else:
                 _lib.check(L.hr_model_create_cascade(C.byref(coarse), C.byref(hc), C.byref(h)), 'hr_model_create_cascade')
             self._native = h
+            self._apply_options()
             self._native_grid = self.grid_size
             self._native_box = (self.color_model.net.aabb.data_ptr(), self.color_model.net.aabb._version)
             self._native_cfg = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
@@ -525,6 +529,29 @@ class HipLightfieldModel(nn.Module):
         self._coarse_hc = coarse
         self._sync_schedule(hc, coarse)          # an existing handle may still hold another iteration's constants
         return self._native
+
+    def _apply_options(self):
+        L = _lib.load()
+        _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_FRAME_KERNEL, int(self.frame_kernel)), 'hr_model_set_option')
+        if self.sample_waves is not None:
+            _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_SAMPLE_WAVES, int(self.sample_waves)), 'hr_model_set_option')
+
+    def set_execution(self, frame_kernel=None, sample_waves=None):
+        """Chooses how render() is laid out on the device (images are bit-identical under every setting):
+        frame_kernel False = always the two-kernel path through the HBM workspace; sample_waves 4 | 8."""
+        if frame_kernel is not None:
+            self.frame_kernel = bool(frame_kernel)
+        if sample_waves is not None:
+            self.sample_waves = int(sample_waves)
+        if self._native is not None:
+            self._apply_options()
+
+    def frame_kernel_active(self):
+        """True when render() of this model runs as the single persistent frame kernel (head tile in LDS)."""
+        import ctypes as C
+        v = C.c_int32(0)
+        _lib.check(_lib.load().hr_model_get_option(self.native(), _lib.HR_OPT_FRAME_KERNEL_ACTIVE, C.byref(v)), 'hr_model_get_option')
+        return bool(v.value)
 
     def reserve(self, rays_per_chunk):
         L = _lib.load()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 16
+#define HR_ABI_VERSION 17
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -259,6 +259,20 @@ int hr_model_update_config(hr_model* m, const hr_config* cfg, void* stream);
 
 /* Sizes the per-launch workspace (rays processed per internal chunk).  Optional. */
 int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
+
+/* Execution plan of hr_render.  The arithmetic is the same under every setting (bit-identical images); the options choose
+ * how it is laid out on the device.
+ *   HR_OPT_FRAME_KERNEL   1 (default): models whose head tile fits the CU's LDS are rendered by ONE persistent kernel in
+ *                         which the (B, Z*P) head that the reference materialises between RayPredictionEmbedding and
+ *                         Intersect (nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259) is handed from the MLP
+ *                         wavefronts to the sample wavefronts of the same workgroup through LDS; everything else -- and
+ *                         every hr_render_fields call with a non-NULL `fields` -- takes the two-kernel path through the
+ *                         HBM workspace.  0: always the two-kernel path.
+ *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8.
+ * hr_model_get_option(HR_OPT_FRAME_KERNEL_ACTIVE) answers whether hr_render currently takes the frame kernel (read-only). */
+enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2 };
+int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
+int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 
 /* rgb_dev[n,3] = render_fn(rays_dev[n,ray_dim])['rgb']  (eval mode: clamped to [0,1]). */
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);

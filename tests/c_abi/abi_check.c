@@ -40,6 +40,8 @@ int main(void)
         if (hr_dense_alpha(NULL, n3, 0.01f, 1, NULL, NULL, box, &x, NULL) != HR_E_INVALID) return 15;
         if (hr_generate_rays(NULL, 6, 0, 0, NULL, NULL) != HR_E_INVALID) return 16;
         if (hr_model_create_cascade(NULL, &cfg, &m) != HR_E_INVALID || m != NULL) return 17;
+        if (hr_model_set_option(NULL, HR_OPT_FRAME_KERNEL, 1) != HR_E_INVALID) return 18;
+        { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
     }
     return 0;
 }

@@ -1,0 +1,136 @@
+"""`-m gpu`: the persistent frame kernel (csrc/fused_impl.inc) -- MLP wavefronts and sample wavefronts of one workgroup,
+head tile handed over in LDS -- against the two-kernel path through the HBM workspace.  Both run the same arithmetic
+(mlp_split_core.inc, sample_core.inc), so the images must agree BIT FOR BIT; any difference is a hand-over bug
+(stale LDS, a counter race, an overlay written too early).  The hand-over is exercised under uneven load: whole 800x800
+frames (10 000 tiles over 256 persistent workgroups), ragged tails, every word compared, repeated launches.
+Reference path being fused: nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden
+from hyperreel_amd import config as C
+from hyperreel_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+FUSABLE = ['donerf_sphere_small', 'donerf_cylinder_small', 'config1_random_z16']
+
+
+def _fns(case, precision='auto', grid_dtype='fp32'):
+    from gpu_common import make_render_fn
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=precision, grid_dtype=grid_dtype, iteration=g.iteration)
+    return g, fn
+
+
+def _render(fn, rays_t, frame_kernel, sample_waves=None):
+    fn.model.set_execution(frame_kernel=frame_kernel, sample_waves=sample_waves)
+    out = fn.model.render(rays_t)['rgb']
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize('case', FUSABLE)
+def test_fusable_models_take_the_frame_kernel(case):
+    g, fn = _fns(case)
+    assert fn.model.frame_kernel_active()
+    fn.model.set_execution(frame_kernel=False)
+    assert not fn.model.frame_kernel_active()
+
+
+@pytest.mark.parametrize('case', ['technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
+                                  'sweep/shiny_z_plane_cascaded'])
+def test_wide_heads_and_cascades_keep_the_two_kernel_path(case):
+    """480 head columns x 64 rays (124 KB) + 67.6 KB of activations exceed the CU's 160 KB; cascades run two MLPs."""
+    g, fn = _fns(case)
+    assert not fn.model.frame_kernel_active()
+
+
+@pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
+@pytest.mark.parametrize('waves', [4, 8])
+@pytest.mark.parametrize('case', FUSABLE)
+def test_frame_kernel_equals_two_kernel_path_bit_for_bit(case, waves, precision, grid_dtype):
+    g, fn = _fns(case, precision, grid_dtype)
+    rays = torch.from_numpy(np.concatenate([g.rays] * 3, 0)).cuda()       # a few tiles per workgroup, ragged tail
+    two = _render(fn, rays, False)
+    one = _render(fn, rays, True, waves)
+    assert fn.model.frame_kernel_active()
+    assert torch.equal(one, two), f'{int((one != two).any(-1).sum())} rays differ'
+    if precision != 'f16x2' and grid_dtype == 'fp32':
+        err = (one[:g.rays.shape[0]].cpu().numpy() - g.rgb)
+        assert np.abs(err).max() <= 1e-4
+
+
+@pytest.mark.parametrize('n', [0, 1, 7, 63, 64, 65, 127, 129, 257])
+def test_frame_kernel_ragged_ray_counts(n):
+    g, fn = _fns('donerf_sphere_small')
+    rays = torch.from_numpy(g.rays).cuda()
+    full = _render(fn, rays, True)
+    part = _render(fn, rays[:n].contiguous(), True)
+    assert part.shape == (n, 3) and torch.equal(part, full[:n])
+
+
+@pytest.mark.parametrize('waves', [4, 8])
+def test_frame_kernel_full_frame_every_word_and_repeats(waves):
+    """BASELINE configs[1] at full size: 640 000 rays = 10 000 tiles, 39-40 per persistent workgroup.  Every rgb word equals
+    the two-kernel path; ten more launches (hand-over timing differs from run to run) reproduce it exactly; rays in a
+    different order (other tiles share a workgroup) give the same pixels."""
+    from gpu_common import make_render_fn
+    cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    fn = make_render_fn(cfg, ds, sd)
+    rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800, frame=7)).cuda()
+    two = _render(fn, rays, False)
+    one = _render(fn, rays, True, waves)
+    assert torch.equal(one, two), f'{int((one != two).any(-1).sum())} rays differ'
+    for _ in range(10):
+        assert torch.equal(_render(fn, rays, True, waves), two)
+    perm = torch.randperm(rays.shape[0], device='cuda', generator=torch.Generator('cuda').manual_seed(5))
+    assert torch.equal(_render(fn, rays[perm].contiguous(), True, waves), two[perm])
+    odd = rays[:555555].contiguous()                                  # 8680 tiles + a 35-ray tail
+    assert torch.equal(_render(fn, odd, True, waves), two[:555555])
+
+
+def test_frame_kernel_under_a_concurrent_stream():
+    """Uneven load: another stream keeps the CUs busy with a memory-bound kernel while the frame kernel runs."""
+    from gpu_common import make_render_fn
+    cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
+    sd = scenes.make_state_dict(cfg, ds, [96, 96, 96], seed=3, density='dense', app_scale=1.0)
+    fn = make_render_fn(cfg, ds, sd)
+    rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 400, 400, frame=3)).cuda()
+    two = _render(fn, rays, False)
+    fn.model.set_execution(frame_kernel=True)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device='cuda')
+    for _ in range(5):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                junk.add_(1.0)
+        out = fn.model.render(rays)['rgb']
+        torch.cuda.synchronize()
+        assert torch.equal(out, two)
+
+
+def test_frame_kernel_in_a_hipgraph():
+    g, fn = _fns('donerf_sphere_small')
+    rays = torch.from_numpy(np.concatenate([g.rays] * 8, 0)).cuda()
+    ref = _render(fn, rays, False)
+    fn.model.set_execution(frame_kernel=True)
+    fn.model.render(rays)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn.model.render(rays)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn.model.render(rays)['rgb']
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
