@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
+    ap.add_argument('--lib', default='', help='measurement builds only (tools/build_variant.py): load this library instead of the in-tree one')
     ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead of the persistent frame kernel')
     ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
@@ -140,6 +141,9 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
+    if args.lib:
+        from hyperreel_amd import lib as _hl
+        _hl.LIB_PATH = os.path.abspath(args.lib)
     from hyperreel_amd.render import build_render_fn
     cfg = C.model_config(args.model)
     ds = C.dataset_scalars(args.model)

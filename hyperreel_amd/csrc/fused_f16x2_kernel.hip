@@ -5,4 +5,6 @@
 #define HR_FUSED_KERNEL hr_frame_f16x2_kernel
 #define HR_FUSED_LAUNCH hr_launch_frame_f16x2
 #define HR_SPLIT_PRODUCTS 2
+#define HR_TUNING_SET hr_tuning_set_f16x2
+#define HR_TUNING_PHASES hr_tuning_phases_f16x2
 #include "fused_impl.inc"

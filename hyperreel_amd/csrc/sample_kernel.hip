@@ -56,10 +56,16 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     // ---- per-ray quantities (computed redundantly by the ray's lanes) and the ray's decode matrix
     const HrRayLane L = hr_load_ray(cfg, a, ray, ray_ok);
     float* M = s_M + rib * 3 * CA;
+#ifdef HR_TUNING
+    if (!(a.dbg_mode & 4))
+#endif
     hr_fill_decode<ZP>(cfg, a, L, k, M);
     __syncthreads();
 
-    hr_sample_body<ZP, HALF>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x);
+#ifdef HR_TUNING
+    unsigned long long sph__[12] = {};
+#endif
+    hr_sample_body<ZP, HALF, 1, 4>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
 }
 
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)

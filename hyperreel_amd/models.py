@@ -578,10 +578,10 @@ class HipLightfieldModel(nn.Module):
         # the C ABI takes no row stride: extra columns are cut (6-column nets ignore camera id / time, rendering.py)
         return rays[:, :hc.ray_dim].contiguous().float()
 
-    def render(self, rays, want=()):
+    def render(self, rays, want=(), out=None):
         """rays (B, 6|8) on the HIP device -> dict with 'rgb' (B,3) and any of
         'distances' (B,Z), 'points' (B,Z,3), 'sigma' (B,Z), 'render_weights' (B,Z),
-        'head' (B,Z*P) listed in `want`."""
+        'head' (B,Z*P) listed in `want`.  out: an existing (B,3) float32 device tensor to render into."""
         import ctypes as C
         h = self.native()
         L = _lib.load()
@@ -589,7 +589,9 @@ class HipLightfieldModel(nn.Module):
         B = rays.shape[0]
         hc = self._hc
         Z = hc.z_channels
-        out = {'rgb': torch.empty((B, 3), dtype=torch.float32, device=rays.device)}
+        if out is not None and (out.shape != (B, 3) or out.dtype != torch.float32 or out.device != rays.device or not out.is_contiguous()):
+            raise ValueError('out must be a contiguous (B, 3) float32 tensor on the rays\' device')
+        out = {'rgb': out if out is not None else torch.empty((B, 3), dtype=torch.float32, device=rays.device)}
         stream = C.c_void_p(torch.cuda.current_stream(rays.device).cuda_stream)
         with torch.cuda.device(rays.device):
             if not want:
