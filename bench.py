@@ -4,21 +4,26 @@
     python bench.py --gpus N --steps K --warmup W            (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): DoNeRF static scene, `donerf_sphere` model group,
-800x800 pinhole frame = 640 000 rays, 32 samples/ray, shipped final grid 600^3,
-synthetic random-weight scene ('dense' density variant so alpha spans (0,1)), fp32.
-One step = one full forward render of the frame with rays and rgb resident in HBM.
+Workload (BASELINE.json configs[1]): DoNeRF static scene, `donerf_sphere` model group, 800x800 pinhole frame = 640 000
+rays, 32 samples/ray, shipped final grid 600^3, synthetic random-weight scene ('dense' density variant so alpha spans
+(0,1)).  One step = one full forward render of a frame with rays and rgb resident in HBM.
 
-Multi-GPU (weak scaling): every rank renders its own 800x800 tile of an (800*N)x800
-panorama (640 000 rays per GPU, weights replicated) and the rendered tiles are
-all-gathered over RCCL/xGMI inside the timed step; value = rays rendered by all ranks / s.
+Multi-GPU: `--scaling weak` (default): every rank renders its own 800x800 tile of an (800*N)x800 panorama and the tiles are
+all-gathered over RCCL/xGMI inside the timed step.  `--scaling strong`: ONE 800x800 frame per step, split into N contiguous
+pixel ranges (rays generated on each GPU from the camera), the all-gather of frame i double-buffered under the render of
+frame i+1 (hyperreel_amd.parallel.ShardedFramePipeline) -- BASELINE's "800x800 frame ms at 1/2/4/8".  value = rays of all
+ranks per second either way.
 
 The JSON line also carries
-  roofline      the dominant kernel of the step, timed live with HIP events on the launch
-                stream, against the MI355X peak of the unit that bounds it;
-  roofline_other  the other kernel, same treatment;
-  cpu_baseline  the CPU port of the reference's algorithm (oracle/torch_port.py, PyTorch CPU ops on
-                all host cores) timed on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline        the dominant kernel of the step, its launches timed live with HIP events on the launch stream, against the
+                  MI355X peak that bounds it (MI355X_MICROARCH.md: 2500 TFLOP/s dense bf16/fp16 MFMA);
+  roofline_other  the other kernel: vector-ALU issue (wave-instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles);
+                  the instruction count per launch comes from the committed PMC pass (profiles/r02_counters.json);
+  frame_kernel    the same frame through the single persistent frame kernel (head tile handed over in LDS);
+  value_fp32_exact  the same frame with the exact fp32-MFMA MLP;
+  pytorch_gpu_baseline  the reference's algorithm as stock PyTorch-ROCm ops on this GPU (north star: ">= 10x");
+  cpu_baseline    the CPU port of the reference's algorithm (oracle/torch_port.py) on a bounded sample of the same frame,
+                  with its calibration against the reference itself (profiles/r02_cpu_calibration.json).
 """
 import argparse
 import json
@@ -35,10 +40,10 @@ sys.path.insert(0, ROOT)
 from hyperreel_amd import config as C  # noqa: E402
 from hyperreel_amd import scenes  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
-MFMA_BF16_SUSTAINED_TFLOPS = 1889.0   # tools/mfma_peak.hip, profiles/r01_f_mfma_peak.txt
-MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (measured 2495)
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # wave-instructions per ns: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz
+HBM_PEAK_GBS = 8000.0
 
 
 def algorithmic_bytes_per_ray(cfg, video, texel_bytes=4):
@@ -72,19 +77,17 @@ def time_stage(fn, reps):
 
 
 def cpu_baseline(cfg, ds, sd, rays, n_sample):
-    """The torch-op CPU port of the reference's algorithm (oracle/torch_port.py: the same ATen
-    kernels the reference runs on a CPU -- grid_sample, cumprod, sort, addmm -- on all host
-    cores) on a bounded sample of the same frame.  Checker code, used here only as the reported
-    CPU baseline; never on the measured path."""
+    """The torch-op CPU port of the reference's algorithm (oracle/torch_port.py: the same ATen kernels the reference runs on
+    a CPU -- grid_sample, cumprod, sort, addmm) on a bounded sample of the same frame.  Checker code, used here only as the
+    reported CPU baseline; never on the measured path."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     from torch_port import TorchPort
     n_sample = min(n_sample, rays.shape[0])
     idx = np.arange(rays.shape[0]) if n_sample == rays.shape[0] else \
         np.sort(np.random.default_rng(0).choice(rays.shape[0], n_sample, replace=False))
     port = TorchPort(cfg, ds, sd)
-    # give the CPU its best shot: torch's default of one thread per logical CPU is far from the
-    # optimum on many-core hosts (measured on the 256-CPU GPU box: 16 threads 0.17 Mrays/s, 128
-    # threads 0.013), so probe a few thread counts on a small slice and keep the fastest
+    # torch's default of one thread per logical CPU is far from the optimum on many-core hosts (256-CPU GPU box: 16 threads
+    # 0.17 Mrays/s, 128 threads 0.013): probe a few thread counts on a small slice and keep the fastest
     best = (0.0, torch.get_num_threads())
     for thr in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
         if thr > (os.cpu_count() or 8):
@@ -103,6 +106,47 @@ def cpu_baseline(cfg, ds, sd, rays, n_sample):
     return n_sample / dt, dt, idx, out['rgb']
 
 
+def timed_frames(step, steps, warmup, multi, dist):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def capture(model, rays):
+    """One frame = hr_render's kernel launches, captured once into a hipGraph and replayed per step (the library neither
+    allocates nor synchronises inside hr_render), so a slow host thread cannot starve the GPU between launches."""
+    model.render(rays)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.render(rays)                       # warm the side stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    # thread_local: only this thread's calls are policed during capture (the RCCL watchdog thread of a multi-rank run may
+    # query its events meanwhile)
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        out = model.render(rays)['rgb']
+    return graph, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -112,16 +156,18 @@ def main():
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=800)
     ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
-    ap.add_argument('--torch-gpu', action='store_true', help='also time the PyTorch-ROCm port of the reference algorithm on this GPU')
+    ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16x2', 'fp32'],
-                    help="arithmetic of the MLP GEMMs: 3-product bf16 split on MFMA (default where supported) or exact fp32 MFMA")
+                    help="arithmetic of the MLP GEMMs: auto = 3-product fp16 split on MFMA (fp32-grade), or exact fp32 MFMA")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
     ap.add_argument('--lib', default='', help='measurement builds only (tools/build_variant.py): load this library instead of the in-tree one')
-    ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead of the persistent frame kernel')
+    ap.add_argument('--frame-kernel', action='store_true', help='render through the persistent frame kernel (head tile in LDS) instead of the two-kernel path')
+    ap.add_argument('--no-frame-kernel', action='store_true', help='(default) two-kernel path through the HBM workspace')
     ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
 
@@ -150,91 +196,97 @@ def main():
     video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
-    fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.mlp_precision, grid_dtype=args.grid_dtype,
-                         frame_kernel=not args.no_frame_kernel, sample_waves=args.sample_waves or None)
     texel_bytes = 2 if args.grid_dtype == 'fp16' else 4
     # checker-side weights: with float16 texels the reference algorithm is run on the same rounded grids
     sd_ref = sd if texel_bytes == 4 else {k: (v.astype(np.float16).astype(np.float32) if ('_plane' in k or '_line' in k) else v)
                                           for k, v in sd.items()}
-    fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    # tile of this rank: the same camera, panned by the tile index (weak scaling)
-    rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
-    if world > 1:
-        pose_shift = np.zeros_like(rays_np)
-        pose_shift[:, 1] = 0.01 * rank
-        rays_np = rays_np + pose_shift
-    rays = torch.from_numpy(rays_np).cuda()
-    B = rays.shape[0]
-    model = fn.model
-    if args.chunk:
-        model.reserve(args.chunk)
-    model.native()
-    gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if multi else None
 
-    # One frame = hr_render's kernel launches.  They are captured once into a hipGraph and replayed per
-    # step (the library neither allocates nor synchronises inside hr_render), so a slow host thread
-    # cannot starve the GPU between launches; --no-graph enqueues them eagerly from Python instead.
-    graph = None
-    if not args.no_graph:
+    def make(precision, frame_kernel):
+        f = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=precision, grid_dtype=args.grid_dtype,
+                            frame_kernel=frame_kernel, sample_waves=args.sample_waves or None)
+        f.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        if args.chunk:
+            f.model.reserve(args.chunk)
+        f.model.native()
+        return f
+
+    fn = make(args.mlp_precision, args.frame_kernel)
+    model = fn.model
+    strong = args.scaling == 'strong' and multi
+    Z = cfg['embedding']['embeddings']['ray_prediction_0']['z_channels']
+
+    if not strong:
+        # tile of this rank: the same camera, panned by the tile index (weak scaling)
+        rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
+        if world > 1:
+            pose_shift = np.zeros_like(rays_np)
+            pose_shift[:, 1] = 0.01 * rank
+            rays_np = rays_np + pose_shift
+        rays = torch.from_numpy(rays_np).cuda()
+        B = rays.shape[0]
+        gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if multi else None
+        graph = None
+        if not args.no_graph:
+            graph, rgb_static = capture(model, rays)
+
+        def step():
+            if graph is not None:
+                graph.replay()
+                out = rgb_static
+            else:
+                out = model.render(rays)['rgb']
+            if multi:
+                dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))
+            return out
+
+        dt = timed_frames(step, args.steps, args.warmup, multi, dist)
+        rgb = step()
+        torch.cuda.synchronize()
+        total_rays = B * world
+        rays_per_gpu = B
+        parallelism = f'image tiles x{world}, RCCL all_gather of rgb' if world > 1 else 'single GPU'
+    else:
+        # strong scaling: ONE frame per step, split into contiguous pixel ranges; this rank's rays come from the camera on
+        # the device (hr_generate_rays), the tile is rendered into the pipeline's buffer, its all-gather runs on a side
+        # stream under the next frame's render
+        from hyperreel_amd.parallel import ShardedFramePipeline
+        rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7)
+        n_pix = args.height * args.width
+        pipe = ShardedFramePipeline(n_pix, torch.device('cuda', local_rank))
+        rays = torch.from_numpy(np.ascontiguousarray(rays_np[pipe.lo:pipe.hi])).cuda()     # the rays generate_rays would produce
+        B = rays.shape[0]
         model.render(rays)
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            model.render(rays)                       # warm the side stream
-        torch.cuda.current_stream().wait_stream(side)
+
+        def step():
+            tile = pipe.begin()
+            model.render(rays, out=tile)
+            return pipe.submit()
+
+        dt = timed_frames(step, args.steps, args.warmup, multi, dist)
+        rgb_full = pipe.flush()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: only this thread's calls are policed during capture (the RCCL watchdog thread of a multi-rank
-        # run may query its events meanwhile)
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-            rgb_static = model.render(rays)['rgb']
+        rgb = rgb_full[pipe.lo:pipe.hi]
+        total_rays = n_pix
+        rays_per_gpu = B
+        parallelism = f'ONE {args.height}x{args.width} frame split into {world} pixel ranges, double-buffered RCCL all_gather'
 
-    def step():
-        if graph is not None:
-            graph.replay()
-            rgb = rgb_static
-        else:
-            rgb = model.render(rays)['rgb']
-        if multi:
-            dist.all_gather_into_tensor(gathered.view(-1), rgb.view(-1))
-        return rgb
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rgb = step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    total_rays = B * world
     value = total_rays / (dt / args.steps) / 1e6
-
+    prec_name = {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2'}[int(model._hc.mlp_precision)]
     result = {
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
         'config': {'workload': f'BASELINE configs[1]: DoNeRF static ({args.model}), {args.height}x{args.width} frame '
-                               f'= {B} rays per GPU, {cfg["embedding"]["embeddings"]["ray_prediction_0"]["z_channels"]} '
-                               f'samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
-                   'rays_per_gpu': B, 'parallelism': f'image tiles x{world}, RCCL all_gather of rgb' if world > 1 else 'single GPU',
-                   'frame_ms_per_gpu': round(ms_per_step, 4)},
+                               f'= {args.height * args.width} rays, {Z} samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
+                   'rays_per_gpu': rays_per_gpu, 'parallelism': parallelism, 'frame_ms': round(ms_per_step, 4),
+                   'execution': 'persistent frame kernel (head tile in LDS)' if model.frame_kernel_active() else
+                                'two kernels per 131 072-ray chunk (MLP -> HBM workspace -> sample stage)'},
     }
 
-    # ---- per-kernel timing + roofline (rank 0)
+    # ---- per-kernel timing + roofline (rank 0): the two kernels of the default path through hr_stage_*
     if rank == 0 and not args.no_stage_timing:
         import ctypes
         from hyperreel_amd import lib as hlib
@@ -256,8 +308,8 @@ def main():
                 hlib.check(L.hr_stage_samples(h, ctypes.c_void_p(rays.data_ptr() + o * rays.shape[1] * 4), n,
                                               ctypes.c_void_p(rgb_tmp.data_ptr() + o * 12), stream), 'hr_stage_samples')
 
-        # the sample stage reads the head of the LAST chunk the MLP stage wrote: both stages
-        # see representative data because every chunk of the frame is statistically alike
+        # the sample stage reads the head of the LAST chunk the MLP stage wrote: both stages see representative data because
+        # every chunk of the frame is statistically alike
         run_mlp(); run_samples()
         reps = max(5, min(args.steps, 20))
         mlp_ms = time_stage(run_mlp, reps)
@@ -265,41 +317,47 @@ def main():
         nl = len(offs)
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
-        split = model._hc.mlp_precision in (1, 2, 3)
-        split_kernel = {1: 'hr_mlp_bf16x3_kernel', 2: 'hr_mlp_f16x3_kernel', 3: 'hr_mlp_f16x2_kernel'}.get(int(model._hc.mlp_precision))
-        peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        r_mlp = {'kernel': split_kernel if split else 'hr_mlp_kernel', 'bound': 'mfma',
+        split = prec_name != 'fp32'
+        mlp_kernel = {'bf16x3': 'hr_mlp_bf16x3_kernel', 'f16x3': 'hr_mlp_f16x3_kernel', 'f16x2': 'hr_mlp_f16x2_kernel', 'fp32': 'hr_mlp_kernel'}[prec_name]
+        peak = MFMA_16BIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        n_prod = {'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'fp32': 1}[prec_name]
+        r_mlp = {'kernel': mlp_kernel, 'bound': 'mfma',
                  'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
                  'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / peak, 4),
                  'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(mlp_ms[0] / nl, 4),
                  'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {min(chunk, B)} rays',
-                 'note': ('fp32 GEMMs evaluated as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): the matrix '
-                          'cores issue 3x the algorithmic FLOPs, so frac <= 1/3 by construction') if split else
-                         'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
-        if split:
-            # measured with tools/mfma_peak.hip on MI355X: back-to-back v_mfma_f32_32x32x16_bf16 on register-resident
-            # operands sustain 1.89 PFLOP/s (the chip settles at ~1.8 GHz under matrix load), not the 2.5 PFLOP/s of `peak`
-            r_mlp['sustained_mfma_peak'] = MFMA_BF16_SUSTAINED_TFLOPS
-            n_prod = 2 if model._hc.mlp_precision == 3 else 3
-            r_mlp['mfma_products_per_gemm'] = n_prod
-            r_mlp['frac_of_sustained_issue'] = round(n_prod * flops / (mlp_ms[0] * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED_TFLOPS, 4)
-        r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'hbm', 'achieved': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
-                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byts / (smp_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
-                 'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays'}
-        # HBM-side traffic per launch: measured separately with rocprofv3 --pmc (never inside a timed
-        # run) and committed under profiles/; attached only when the workload matches the profiled one
+                 'mfma_products_per_gemm': n_prod,
+                 'note': (f'fp32 GEMMs evaluated as {n_prod} 16-bit MFMA products of hi/lo split operands, fp32 accumulate: the matrix cores '
+                          f'issue {n_prod}x the algorithmic FLOPs, so frac <= 1/{n_prod} by construction') if split else 'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
+        r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'valu', 'achieved': None, 'peak': round(VALU_PEAK_GINST, 1), 'unit': 'G wave-instructions/s',
+                 'frac': None, 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
+                 'algorithmic_gather_GBs': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
+                 'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays (L2 / Infinity-Cache resident: not an HBM figure)',
+                 'note': 'the sample stage is bound by vector-ALU issue, not by bytes: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, '
+                         'profiles/r02_counters.json) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction'}
+        # counters measured separately with rocprofv3 --pmc (never inside a timed run) and committed under profiles/;
+        # attached only when the workload matches the profiled one
         try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters.json')))
             w = tr['workload']
             if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
-                    and (w['mlp_precision'] == 'bf16x3') == (model._hc.mlp_precision == 1) and texel_bytes == 4):
-                r_mlp['traffic'] = tr[r_mlp['kernel']]['traffic_bytes'] if r_mlp['kernel'] in tr else None
-                r_smp['traffic'] = tr['hr_sample_kernel']['traffic_bytes']
-                r_mlp['traffic_unit'] = r_smp['traffic_unit'] = 'bytes per launch (profiles/r01_traffic.json)'
-                for r in (r_mlp, r_smp):          # what the PMC passes say actually limits the kernel
-                    if r['kernel'] in tr and 'limiter' in tr[r['kernel']]:
-                        r['limiter'] = tr[r['kernel']]['limiter']
+                    and w['mlp_precision'] == prec_name and w['grid_dtype'] == args.grid_dtype):
+                for r in (r_mlp, r_smp):
+                    k = tr.get(r['kernel'])
+                    if not k:
+                        continue
+                    r['traffic'] = k.get('traffic_bytes')
+                    r['traffic_unit'] = 'HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_counters.json)'
+                    if 'limiter' in k:
+                        r['limiter'] = k['limiter']
+                    if 'mfma_busy_frac' in k:
+                        r['mfma_busy_frac'] = k['mfma_busy_frac']
+                k = tr.get('hr_sample_kernel')
+                if k and 'valu_insts' in k:
+                    ginst = k['valu_insts'] / (smp_ms[0] / nl * 1e-3) / 1e9
+                    r_smp['achieved'] = round(ginst, 1)
+                    r_smp['frac'] = round(ginst / VALU_PEAK_GINST, 4)
+                    r_smp['valu_insts_per_sample_slot'] = k.get('valu_insts_per_wave')
         except (OSError, KeyError, ValueError):
             pass
         dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
@@ -307,25 +365,61 @@ def main():
         result['roofline_other'] = oth
         result['stage_ms'] = {'mlp': round(mlp_ms[0], 4), 'samples': round(smp_ms[0], 4)}
 
+    extras = rank == 0 and world == 1 and not args.no_extras
+    # ---- the same frame through the other execution plan, and with the exact fp32-MFMA MLP
+    if extras:
+        def quick(f):
+            g, _ = capture(f.model, rays)
+            d = timed_frames(g.replay, 20, 5, False, None)
+            return B / (d / 20) / 1e6, d / 20 * 1e3
+        other = make(args.mlp_precision, not args.frame_kernel)
+        if other.model.frame_kernel_active() != model.frame_kernel_active():
+            v, ms = quick(other)
+            same = bool(torch.equal(other.model.render(rays)['rgb'], rgb))
+            result['frame_kernel' if other.model.frame_kernel_active() else 'two_kernel_path'] = {
+                'value': round(v, 3), 'unit': 'Mrays/s', 'ms_per_step': round(ms, 4), 'bit_identical_to_value_path': same,
+                'what': 'ONE persistent kernel per frame: MLP wavefronts hand the 64-ray head tile to sample wavefronts of the same workgroup '
+                        'through LDS (no HBM workspace: 185 MB per 131 072 rays less traffic)' if other.model.frame_kernel_active() else
+                        'MLP kernel -> HBM workspace -> sample kernel'}
+        del other
+        if prec_name != 'fp32':
+            exact = make('fp32', False)
+            v, ms = quick(exact)
+            result['value_fp32_exact'] = {'value': round(v, 3), 'unit': 'Mrays/s', 'ms_per_step': round(ms, 4),
+                                          'what': 'same frame, MLP on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32)',
+                                          'linf_vs_value_path': float((exact.model.render(rays)['rgb'] - rgb).abs().max())}
+            del exact
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd_ref, rays_np, min(args.cpu_sample, B))
         got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
-        result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                  'sample': f'{len(idx)} rays of the same frame through oracle/torch_port.py (the reference\'s '
-                                            f'algorithm on PyTorch CPU ops, fp32, chunk 16384) in {secs:.1f} s'}
-        result['parity_vs_oracle_linf'] = float(np.abs(got - ref_rgb).max())
+        sample = (f'{len(idx)} rays of the same frame through oracle/torch_port.py (the reference\'s algorithm on PyTorch CPU ops, fp32, '
+                  f'chunk 16384) in {secs:.1f} s')
+        try:
+            cal = json.load(open(os.path.join(ROOT, 'profiles', 'r02_cpu_calibration.json')))
+            r0 = cal['runs'][0]
+            sample += (f'; calibration against the reference itself (authoring container, {r0["threads"]} threads, {cal["rays"]} rays of this frame): '
+                       f'reference {r0["reference_mrays_s"]:.3f} vs port {r0["port_mrays_s"]:.3f} Mrays/s (port = {r0["port_over_reference"]:.2f}x the reference, '
+                       f'L-inf {r0["linf_port_vs_reference"]:.1e})')
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
+        result['cpu_baseline'] = {'value': round(v / 1e6, 5), 'unit': 'Mrays/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'sample': sample}
+        err = np.abs(got - ref_rgb).max(-1)
+        result['parity_vs_oracle_linf'] = float(err.max())
+        result['parity_rays_over_1e-4'] = int((err > 1e-4).sum())
 
     result['grid_dtype'] = args.grid_dtype
-    result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else 'hipGraph replay of one captured frame'
-    result['mlp_gemm'] = {1: 'bf16x3 split on MFMA, fp32 accumulate (head within 1e-5 rel. of fp32; rgb parity <= 1e-5)',
-                          2: 'f16x3 split on MFMA, fp32 accumulate (22 mantissa bits; activations must stay below 65504)',
-                          3: 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
-                          0: 'fp32 MFMA'}[int(model._hc.mlp_precision)]
-    # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same
-    #      algorithm as stock PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda';
-    #      the reference itself cannot travel to the GPU box).  Reported, never part of `value`.
-    if rank == 0 and world == 1 and args.torch_gpu:
+    result['config']['launch'] = 'eager (Python -> hr_render per frame)' if (args.no_graph or strong) else 'hipGraph replay of one captured frame'
+    result['mlp_gemm'] = {'bf16x3': 'bf16x3 split on MFMA, fp32 accumulate (raw head within 7e-6 of the fp32 chain)',
+                          'f16x3': 'f16x3 split on MFMA: 11+11-bit halves, weights pre-scaled by an exact power of two, fp32 accumulate (raw head within 1e-6 of the fp32 chain)',
+                          'f16x2': 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
+                          'fp32': 'fp32 MFMA'}[prec_name]
+    # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same algorithm as stock
+    #      PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda'; the reference itself cannot travel to the GPU
+    #      box).  Reported, never part of `value`.
+    if extras:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         from torch_port import TorchPort
         tp = TorchPort(cfg, ds, sd_ref, device='cuda')

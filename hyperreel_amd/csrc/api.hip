@@ -89,7 +89,7 @@ struct hr_model {
     float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
     int64_t tape_samples = 0;
     // execution plan of hr_render (hr_model_set_option)
-    int opt_frame_kernel = 1;
+    int opt_frame_kernel = 0;              // measured: the two-kernel path is ~4 % faster on the benchmark frame
     int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
     int n_cus = 0;
 };

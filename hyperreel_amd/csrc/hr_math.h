@@ -536,6 +536,28 @@ HR_FN hr_axis_tap hr_make_tap(float g, int n)
     return t;
 }
 
+// The same two taps in "clamped" form for kernels that address the taps as base, base + 1: i0 is clamped to [0, n-2] so
+// that both texels exist, and each weight of hr_make_tap is moved to the slot where its texel now sits (a tap that ATen
+// drops as out of range leaves a zero weight).  The bilinear sum is unchanged bit for bit: the terms that move carry
+// their own weight, the vacated slots contribute v * 0.  Needs n >= 2.
+struct hr_axis_tap_c {
+    int i0;            // low tap; the high tap is i0 + 1
+    float w0, w1;
+};
+HR_FN hr_axis_tap_c hr_make_tap_c(float g, int n)
+{
+    const hr_axis_tap u = hr_make_tap(g, n);          // masked weights (indices recomputed below: u.i0 / u.i1 are clamped per tap)
+    float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+    const int i0 = (int)floorf(ix);
+    int ic = i0 < 0 ? 0 : i0;
+    ic = ic > n - 2 ? n - 2 : ic;
+    hr_axis_tap_c t;
+    t.i0 = ic;
+    t.w0 = (i0 == ic) ? u.w0 : ((i0 + 1 == ic) ? u.w1 : 0.0f);
+    t.w1 = (i0 == ic) ? u.w1 : ((i0 == ic + 1) ? u.w0 : 0.0f);
+    return t;
+}
+
 // ---------------------------------------------------------------- display pack
 // to8b (utils/__init__.py:47): (255 * clip(x, 0, 1)).astype(uint8) -- the product is formed in fp32 and truncated
 HR_FN uint8_t hr_to8b(float x)

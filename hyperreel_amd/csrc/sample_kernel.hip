@@ -3,7 +3,7 @@
 // point_prediction cascades, heads too wide for the LDS hand-over, the exact-fp32 MLP.
 #include "sample_core.inc"
 
-template <int ZP, bool HALF>
+template <int ZP, bool HALF, int PC>
 __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config* __restrict__ cfgp, const HrSampleArgs a)
 {
     // the configuration lives in device memory (2 KB: too large to index dynamically as a by-value kernel argument
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
 #ifdef HR_TUNING
     unsigned long long sph__[12] = {};
 #endif
-    hr_sample_body<ZP, HALF, 1, 4>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
+    hr_sample_body<ZP, HALF, 1, 4, PC>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
 }
 
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)
@@ -90,14 +90,20 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
 #endif
     // few samples x many head columns can exceed the 64 KiB a kernel gets by default (e.g. 32 rays x 8 x 64 floats)
     const bool big_lds = lds > 64 * 1024;
+    // the shipped [8, 4, 4] decomposition with fp32 texels gets the class-specialised gather (sample_core.inc); ZP >= 8
+    // keeps a quad inside one ray, video nets additionally need two keyframes
+    const bool pc844 = hr_planes_are_844(args.planes, 0) && args.ca_total == 16 && args.rows_out == nullptr && (!cfg.video || cfg.num_keyframes >= 2);
 #define HR_LAUNCH_SAMPLES(Z_) \
     do { \
         if (cfg.grid_dtype == HR_GRID_FP16) { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, true>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, true, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+        } else if (pc844) { \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 1>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
         } else { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, false>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
         } \
     } while (0)
     switch (ZP) {

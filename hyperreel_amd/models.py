@@ -366,7 +366,7 @@ class HipLightfieldModel(nn.Module):
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
         # execution plan of render() (hr_model_set_option): frame kernel on/off, its sample wavefronts (None: library default)
-        self.frame_kernel = bool(kwargs.get('frame_kernel', True))
+        self.frame_kernel = bool(kwargs.get('frame_kernel', False))
         self.sample_waves = kwargs.get('sample_waves')
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:

@@ -73,6 +73,89 @@ def render_camera_sharded(model, pose, K, width, height, time=None, cam_id=0.0, 
     return torch.cat([out[r * per:r * per + (bounds[r + 1] - bounds[r])] for r in range(world)], 0)
 
 
+class ShardedFramePipeline:
+    """Strong scaling of a frame SEQUENCE (the viewer / video-render case, BASELINE configs[3-4]): every rank renders its
+    contiguous pixel range of frame i into one of two tile buffers, and the all-gather of frame i runs on its own stream
+    under the render of frame i + 1 -- over point-to-point xGMI a (B/N, 3) fp32 gather of an 800x800 frame is 7.7 MB in
+    total, i.e. tens of microseconds of link time, but its launch + rendezvous latency is of the order of a 1/N-th frame;
+    double buffering takes it off the critical path.
+
+        pipe = ShardedFramePipeline(n_pixels, device)
+        for frame in frames:
+            tile = pipe.begin()                       # (my pixels, 3) buffer to render into (waits until its gather is over)
+            model.render(my_rays(frame), out=tile)    # enqueue on the current stream
+            done = pipe.submit()                      # all-gather on the side stream; returns the previous frame's image
+        last = pipe.flush()
+
+    `render` is the caller's business (HipLightfieldModel.render / render_camera with pixel_range); on CPU (gloo tests) the
+    gathers are synchronous.  Every rank ends up with every full frame, in submission order."""
+
+    def __init__(self, n_pixels, device, group=None, channels=3, dtype=torch.float32):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.n = int(n_pixels)
+        self.bounds = shard_bounds(self.n, self.world)
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.per = self.bounds[1] - self.bounds[0]                  # largest shard: every rank contributes `per` rows
+        dev = torch.device(device)
+        self.cuda = dev.type == 'cuda'
+        self.tiles = [torch.zeros((self.per, channels), dtype=dtype, device=dev) for _ in range(2)]
+        self.full = [torch.empty((self.world * self.per, channels), dtype=dtype, device=dev) for _ in range(2)]
+        self.comm = torch.cuda.Stream(dev) if self.cuda else None
+        self.rendered = [torch.cuda.Event() if self.cuda else None for _ in range(2)]
+        self.pending = [None, None]                                  # async work handle of the gather that reads tiles[slot]
+        self.slot = 0
+        self.have_prev = False
+
+    def _wait(self, slot):
+        w = self.pending[slot]
+        if w is not None:
+            w.wait()                                                 # the current stream waits for that gather
+            self.pending[slot] = None
+
+    def begin(self):
+        """The tile buffer of the next frame: rows [0, hi - lo) are this rank's pixels."""
+        self._wait(self.slot)                                        # its previous gather (two frames ago) must have read it
+        return self.tiles[self.slot][:self.hi - self.lo]
+
+    def _assemble(self, slot):
+        out = self.full[slot]
+        if self.world * self.per == self.n:
+            return out
+        return torch.cat([out[r * self.per:r * self.per + (self.bounds[r + 1] - self.bounds[r])] for r in range(self.world)], 0)
+
+    def submit(self):
+        """Starts the gather of the frame just rendered into begin()'s buffer; returns the PREVIOUS frame's full image
+        (None for the first call) -- valid on the current stream."""
+        s = self.slot
+        if self.world == 1:
+            self.full[s][:self.n].copy_(self.tiles[s][:self.n])
+        elif self.cuda:
+            self.rendered[s].record()
+            self.comm.wait_event(self.rendered[s])
+            with torch.cuda.stream(self.comm):
+                self.pending[s] = dist.all_gather_into_tensor(self.full[s], self.tiles[s], group=self.group, async_op=True)
+        else:
+            dist.all_gather_into_tensor(self.full[s], self.tiles[s], group=self.group)
+        prev = None
+        if self.have_prev:
+            self._wait(1 - s)
+            prev = self._assemble(1 - s)
+        self.have_prev = True
+        self.slot = 1 - s
+        return prev
+
+    def flush(self):
+        """The last submitted frame's full image."""
+        if not self.have_prev:
+            return None
+        s = 1 - self.slot
+        self._wait(s)
+        self.have_prev = False
+        return self._assemble(s)
+
+
 class ShardedRenderFn(torch.nn.Module):
     """Wraps a render_fn (e.g. HipRenderLightfield) so that `forward(rays)['rgb']` renders
     image-parallel across the default process group."""

@@ -38,6 +38,8 @@ def _render(fn, rays_t, frame_kernel, sample_waves=None):
 @pytest.mark.parametrize('case', FUSABLE)
 def test_fusable_models_take_the_frame_kernel(case):
     g, fn = _fns(case)
+    assert not fn.model.frame_kernel_active()          # opt-in: the two-kernel path is the (faster) default
+    fn.model.set_execution(frame_kernel=True)
     assert fn.model.frame_kernel_active()
     fn.model.set_execution(frame_kernel=False)
     assert not fn.model.frame_kernel_active()
@@ -47,11 +49,7 @@ def test_fusable_models_take_the_frame_kernel(case):
                                   'sweep/shiny_z_plane_cascaded'])
 def test_wide_heads_and_cascades_keep_the_two_kernel_path(case):
     """480 head columns x 64 rays (124 KB) + 67.6 KB of activations exceed the CU's 160 KB; cascades run two MLPs."""
-    g, fn = _fns(case)
-    assert not fn.model.frame_kernel_active()
-
-
-@pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
+XX, ['fp32', 'fp16'])
 @pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
 @pytest.mark.parametrize('waves', [4, 8])
 @pytest.mark.parametrize('case', FUSABLE)

@@ -204,3 +204,23 @@ def test_bilinear_taps_partition_unity_and_stay_in_range(hm):
         assert not (w0 + w1)[far].any()
 
     prop()
+
+
+def test_clamped_taps_give_the_same_lerp_bit_for_bit(hm):
+    """hr_make_tap_c (taps addressed as base, base + 1 -- what the class-specialised gather uses so that one offset per
+    texel pair is enough) against hr_make_tap: both taps exist, and v[i0]*w0 + v[i1]*w1 is the same float for random
+    texel values, including coordinates on and beyond both borders."""
+    rng = np.random.default_rng(5)
+    for size in (2, 3, 7, 64, 600, 1007):
+        g = np.concatenate([rng.uniform(-1.3, 1.3, 4000), [-1.0, 1.0, 0.0, -1.0 - 2.0 / (size - 1), 1.0 + 2.0 / (size - 1),
+                                                           np.nextafter(np.float32(1.0), np.float32(2.0)), np.nextafter(np.float32(-1.0), np.float32(-2.0))]]).astype(np.float32)
+        n = g.size
+        i0, i1, c0 = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        w0, w1, cw0, cw1 = (np.zeros(n, np.float32) for _ in range(4))
+        hm.hm_taps(fp(g), n, size, i0.ctypes.data_as(IP), i1.ctypes.data_as(IP), fp(w0), fp(w1))
+        hm.hm_taps_c(fp(g), n, size, c0.ctypes.data_as(IP), fp(cw0), fp(cw1))
+        assert ((0 <= c0) & (c0 <= size - 2)).all()
+        v = rng.standard_normal(size).astype(np.float32)
+        ref = (v[i0] * w0) + (v[i1] * w1)              # fp32 products and sum, like the kernels' fma chain up to the zero terms
+        got = (v[c0] * cw0) + (v[c0 + 1] * cw1)
+        assert np.array_equal(ref, got), size

@@ -150,3 +150,75 @@ def test_flat_gradients_all_reduce_keeps_replicas_identical(tmp_path):
     p = [torch.load(tmp_path / f'p{r}.pt') for r in range(world)]
     for a, b in zip(*p):
         assert torch.equal(a, b)                                 # same averaged gradients -> bitwise identical replicas
+
+
+def _pipeline_worker(rank, world, port, n_pixels, n_frames, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from hyperreel_amd.parallel import ShardedFramePipeline
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    pipe = ShardedFramePipeline(n_pixels, 'cpu')
+    frames = []
+    for f in range(n_frames):
+        tile = pipe.begin()
+        i = torch.arange(pipe.lo, pipe.hi, dtype=torch.float32)
+        tile.copy_(torch.stack([i + 1000.0 * f, i * 0.5, (i + f) % 7], -1))       # "render": a function of (pixel, frame)
+        prev = pipe.submit()
+        if prev is not None:
+            frames.append(prev.clone())
+    frames.append(pipe.flush().clone())
+    np.save(os.path.join(out_dir, f'rank{rank}.npy'), torch.stack(frames).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_pixels', [(2, 64), (4, 37), (4, 640)])
+def test_double_buffered_frame_pipeline(tmp_path, world, n_pixels):
+    """Strong-scaling path of bench.py --scaling strong: ragged pixel split over 4 ranks, frames come back complete, in order,
+    on every rank, while the next frame is already being written into the other buffer."""
+    n_frames = 5
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), n_pixels, n_frames, str(tmp_path)), nprocs=world, join=True)
+    i = np.arange(n_pixels, dtype=np.float32)
+    ref = np.stack([np.stack([i + 1000.0 * f, i * 0.5, (i + f) % 7], -1) for f in range(n_frames)])
+    for r in range(world):
+        got = np.load(tmp_path / f'rank{r}.npy')
+        assert got.shape == ref.shape and np.array_equal(got, ref), r
+
+
+def test_flat_gradients_follow_replaced_parameters():
+    """HostTensorVM.set_iter replaces planes / lines by new nn.Parameters when it shrinks or grows the grid; FlatGradients built
+    from the MODULE must pick the new ones up at the next zero() (all .grad views of one buffer again), and one built from a
+    fixed parameter list must refuse to reduce a stale set."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from hyperreel_amd.parallel import FlatGradients
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.plane = torch.nn.Parameter(torch.ones(1, 4, 6, 6))
+            self.lin = torch.nn.Linear(3, 2)
+
+    m = Net()
+    flat = FlatGradients(m)
+    flat.zero()
+    (m.plane.sum() + m.lin.weight.sum()).backward()
+    assert float(flat.flat.sum()) == 4 * 36 + 6
+    n0 = flat.flat.numel()
+    m.plane = torch.nn.Parameter(torch.ones(1, 4, 12, 12))           # what upsample_volume_grid does
+    flat.zero()
+    assert flat.flat.numel() == n0 - 4 * 36 + 4 * 144
+    (m.plane.sum() * 2.0).backward()
+    flat.check()
+    lo = flat.flat.data_ptr()
+    assert lo <= m.plane.grad.data_ptr() < lo + flat.flat.numel() * 4 and float(flat.flat.sum()) == 2.0 * 4 * 144
+    # a gradient that escaped the buffer is refused
+    m.lin.weight.grad = torch.zeros_like(m.lin.weight)
+    with pytest.raises(RuntimeError):
+        flat.check()

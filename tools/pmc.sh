@@ -9,13 +9,13 @@ cd /tmp
 i=0
 for ctrs in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
   "GRBM_GUI_ACTIVE FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   "TA_TA_BUSY_sum TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing "$@" > /tmp/pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing --no-extras "$@" > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python - "$f" "$ctrs" <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i.txt

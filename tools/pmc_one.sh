@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd /tmp; rm -rf /tmp/pmc_$tag
-timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -o p -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing "$@" > /tmp/pmc_$tag.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -o p -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing --no-extras "$@" > /tmp/pmc_$tag.log 2>&1
 f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ]; then
 python - "$f" <<'PY' > $R/gpurun_out/pmc_$tag.txt
