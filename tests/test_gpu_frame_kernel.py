@@ -49,7 +49,12 @@ def test_fusable_models_take_the_frame_kernel(case):
                                   'sweep/shiny_z_plane_cascaded'])
 def test_wide_heads_and_cascades_keep_the_two_kernel_path(case):
     """480 head columns x 64 rays (124 KB) + 67.6 KB of activations exceed the CU's 160 KB; cascades run two MLPs."""
-XX, ['fp32', 'fp16'])
+    g, fn = _fns(case)
+    fn.model.set_execution(frame_kernel=True)
+    assert not fn.model.frame_kernel_active()
+
+
+@pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
 @pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
 @pytest.mark.parametrize('waves', [4, 8])
 @pytest.mark.parametrize('case', FUSABLE)
