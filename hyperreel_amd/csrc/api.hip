@@ -928,6 +928,43 @@ int hr_pack_display(const float* rgb_dev, int32_t h, int32_t w, int32_t transpos
     return HR_OK;
 }
 
+size_t hr_linear_workspace(int64_t rows, int32_t in, int32_t out)
+{
+    if (rows < 1 || in < 1 || out < 1) return 0;
+    return hr_linear_workspace_bytes(rows, in, out);
+}
+
+int hr_linear_forward(const float* x_dev, int64_t ldx, int64_t rows, int32_t in, const float* w_dev, const float* b_dev, int32_t out,
+                      float leaky_slope, float* y_dev, int64_t ldy, void* stream)
+{
+    if (rows < 0 || in < 1 || out < 1 || ldx < in || ldy < out) return fail(HR_E_INVALID, "bad Linear shape");
+    if (rows > 0 && (!x_dev || !w_dev || !y_dev)) return fail(HR_E_INVALID, "null argument");
+    if (rows > 0x7fffffff) return fail(HR_E_INVALID, "more than 2^31 rows");
+    hr_launch_linear_forward(x_dev, ldx, rows, in, w_dev, b_dev, out, leaky_slope, y_dev, ldy, (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+int hr_linear_backward(const float* x_dev, int64_t ldx, const float* w_dev, const float* y_dev, int64_t ldy, const float* dy_dev, int64_t ld_dy,
+                       int64_t rows, int32_t in, int32_t out, float leaky_slope, float* dx_dev, int64_t ld_dx, float* dw_dev, float* db_dev,
+                       float* workspace_dev, void* stream)
+{
+    if (rows < 0 || in < 1 || out < 1 || ldx < in || ld_dy < out || (dx_dev && ld_dx < in) || (y_dev && ldy < out))
+        return fail(HR_E_INVALID, "bad Linear shape");
+    if (rows > 0 && (!x_dev || !w_dev || !dy_dev || !dw_dev || !db_dev || !workspace_dev)) return fail(HR_E_INVALID, "null argument");
+    if (leaky_slope >= 0.0f && !y_dev) return fail(HR_E_INVALID, "an activated layer needs its output for the LeakyReLU mask");
+    if (rows > 0x7fffffff) return fail(HR_E_INVALID, "more than 2^31 rows");
+    if (rows == 0) {
+        HR_HIP(hipMemsetAsync(dw_dev, 0, sizeof(float) * (size_t)out * in, (hipStream_t)stream));
+        HR_HIP(hipMemsetAsync(db_dev, 0, sizeof(float) * (size_t)out, (hipStream_t)stream));
+        return HR_OK;
+    }
+    hr_launch_linear_backward(x_dev, ldx, w_dev, y_dev, ldy, dy_dev, ld_dy, rows, in, out, leaky_slope, dx_dev, ld_dx, dw_dev, db_dev, workspace_dev,
+                              (hipStream_t)stream);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 int hr_plane_reg_forward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, float* sums_dev, void* stream)
 {
     if (channels < 0 || h < 1 || w < 1) return fail(HR_E_INVALID, "bad plane shape");

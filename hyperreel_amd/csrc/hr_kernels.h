@@ -114,5 +114,12 @@ void hr_launch_rows(const hr_config& cfg, const HrRowsArgs& args, hipStream_t st
 void hr_launch_dense_alpha(const HrMaskArgs& args, hipStream_t stream);
 void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream);
 void hr_launch_features(const hr_config* cfg_dev, const float* rays, int64_t n, float* out, hipStream_t stream);
+// training GEMMs of the MLP (train_gemm_kernel.hip)
+size_t hr_linear_workspace_bytes(int64_t rows, int in, int out);
+void hr_launch_linear_forward(const float* x, int64_t ldx, int64_t rows, int in, const float* w, const float* b, int out, float slope,
+                              float* y, int64_t ldy, hipStream_t stream);
+void hr_launch_linear_backward(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* dy, int64_t ld_dy,
+                               int64_t rows, int in, int out, float slope, float* dx, int64_t ld_dx, float* dw, float* db, float* workspace,
+                               hipStream_t stream);
 
 #endif

@@ -3,8 +3,10 @@
 What INRSystem.training_step (nlf/__init__.py:634-709) gets from torch.autograd for the reference, split the way the
 hardware wants it:
   * ray parameterisation + positional encoding: hr_train_features (no parameters, no gradient);
-  * the sample-prediction MLP: plain GEMMs -- torch.nn.functional.linear on the reference-named nn.Linear parameters
-    (rocBLAS forward and backward), exactly BaseMLP.forward (nlf/nets/mlp.py:159-172);
+  * the sample-prediction MLP: `HipLinear`, a torch.autograd.Function over hr_linear_forward / hr_linear_backward -- every
+    Linear (+ LeakyReLU) and its dgrad / wgrad / bias gradient as split-precision MFMA GEMMs (csrc/train_gemm_kernel.hip)
+    on the reference-named nn.Linear parameters, exactly BaseMLP.forward (nlf/nets/mlp.py:159-172); torch only concatenates
+    the skip layer's input;
   * everything after the MLP (head activations, intersection, sort, contraction, offsets / flow, VM gather, density,
     compositing, colour): one hand-written HIP forward and one backward kernel behind `SampleStage`, a
     torch.autograd.Function over the C ABI (hr_train_forward / hr_train_backward).
@@ -14,7 +16,6 @@ schedulers and regularizers apply unchanged.  There is no CPU path: the tensors 
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import lib as _lib
 
@@ -152,6 +153,47 @@ def ray_features(handle, rays, mlp_in):
     return out
 
 
+class HipLinear(torch.autograd.Function):
+    """y = LeakyReLU_slope(x W^T + b) (slope < 0: no activation) and its backward on the matrix cores
+    (hr_linear_forward / hr_linear_backward: three bf16 MFMA products per fp32 GEMM, fp32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope):
+        L = _lib.load()
+        dev = x.device
+        if dev.type != 'cuda' or weight.device != dev:
+            raise RuntimeError('HipLinear runs on the HIP device; there is no CPU path')
+        x = x.float()
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        w, b = weight.detach().contiguous().float(), bias.detach().contiguous().float()
+        rows, fin, fout = x.shape[0], x.shape[1], w.shape[0]
+        y = torch.empty((rows, fout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_linear_forward(_ptr(x), x.stride(0), rows, fin, _ptr(w), _ptr(b), fout, float(slope), _ptr(y), fout, _stream(dev)),
+                       'hr_linear_forward')
+        ctx.slope = float(slope)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.load()
+        x, w, y = ctx.saved_tensors
+        dev = x.device
+        dy = dy.contiguous().float()
+        rows, fin, fout = x.shape[0], x.shape[1], w.shape[0]
+        dx = torch.empty((rows, fin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((fout,), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(int(L.hr_linear_workspace(rows, fin, fout)) // 4, 1),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_linear_backward(_ptr(x), x.stride(0), _ptr(w), _ptr(y) if ctx.slope >= 0 else C.c_void_p(0), fout, _ptr(dy), fout,
+                                            rows, fin, fout, ctx.slope, _ptr(dx) if dx is not None else C.c_void_p(0), fin, _ptr(dw), _ptr(db),
+                                            _ptr(ws), _stream(dev)), 'hr_linear_backward')
+        return dx, dw, db, None
+
+
 def mlp_forward(net, x, skip_mask):
     """BaseMLP.forward (nlf/nets/mlp.py:159-172) on the reference-named parameters: Linear + LeakyReLU(0.01), the
     input concatenated in front of the activations at the skip layers, no activation after the last Linear."""
@@ -161,9 +203,7 @@ def mlp_forward(net, x, skip_mask):
         lin = layer[0] if i < n - 1 else layer
         if (skip_mask >> i) & 1:
             x = torch.cat([inp, x], -1)
-        x = F.linear(x, lin.weight, lin.bias)
-        if i < n - 1:
-            x = F.leaky_relu(x, 0.01)
+        x = HipLinear.apply(x, lin.weight, lin.bias, 0.01 if i < n - 1 else -1.0)
     return x
 
 

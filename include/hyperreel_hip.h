@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 17
+#define HR_ABI_VERSION 18
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -339,6 +339,26 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
  * not accumulated), for the parameter values of the last hr_train_forward / hr_model_finalize. */
 int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev, const float* d_rgb_dev, int64_t n_rays,
                       int32_t white_bg, float* d_head_dev, const hr_train_tensors* grads, void* stream);
+
+/* The Linear layers of the sample-prediction MLP in training (BaseMLP.forward under autograd, nlf/nets/mlp.py:159-172;
+ * INRSystem.training_step, nlf/__init__.py:634-709), no model involved; all tensors device memory, float32, row-major with
+ * the given leading dimensions (so that the `cat([input, x])` of a skip layer can be a view into a wider buffer).  Every
+ * fp32 GEMM runs on the matrix cores as bf16 MFMA products of split operands with fp32 accumulation (bf16 parts because
+ * gradients span the fp32 exponent range): the backward GEMMs as three products of hi/lo halves (the bf16x3 arithmetic of
+ * the render path), the forward as six products of a three-way split (24 mantissa bits: its output feeds the sample stage's
+ * threshold decisions, which must fall as in the fp32 reference).
+ *   forward:   y (rows, out) = act(x (rows, in) W^T + b),  W (out, in) as torch stores nn.Linear.weight;
+ *              act = LeakyReLU(leaky_slope) when leaky_slope >= 0, none when < 0 (the last Linear)
+ *   backward:  with dy (rows, out) the gradient of y and, for an activated layer, y itself (its sign is LeakyReLU's mask):
+ *              dy' = dy * (y > 0 ? 1 : slope);  dx (rows, in) = dy' W (skipped when dx_dev is NULL);  dw (out, in) = dy'^T x;
+ *              db (out) = column sums of dy'.  The batch dimension of dw / db is reduced in a fixed order (no atomics).
+ *              workspace_dev: hr_linear_workspace(rows, in, out) bytes. */
+size_t hr_linear_workspace(int64_t rows, int32_t in, int32_t out);
+int hr_linear_forward(const float* x_dev, int64_t ldx, int64_t rows, int32_t in, const float* w_dev, const float* b_dev, int32_t out,
+                      float leaky_slope, float* y_dev, int64_t ldy, void* stream);
+int hr_linear_backward(const float* x_dev, int64_t ldx, const float* w_dev, const float* y_dev, int64_t ldy, const float* dy_dev, int64_t ld_dy,
+                       int64_t rows, int32_t in, int32_t out, float leaky_slope, float* dx_dev, int64_t ld_dx, float* dw_dev, float* db_dev,
+                       float* workspace_dev, void* stream);
 
 /* Occupancy of the feature grids: TensorBase.getDenseAlpha (nlf/nets/tensorf_base.py:381-401) and its keyframe
  * override (nlf/nets/tensorf_dynamic.py:499-536) -- alpha = 1 - exp(-sigma * length) at the n[0] x n[1] x n[2] lattice points

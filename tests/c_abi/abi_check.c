@@ -41,6 +41,9 @@ int main(void)
         if (hr_generate_rays(NULL, 6, 0, 0, NULL, NULL) != HR_E_INVALID) return 16;
         if (hr_model_create_cascade(NULL, &cfg, &m) != HR_E_INVALID || m != NULL) return 17;
         if (hr_model_set_option(NULL, HR_OPT_FRAME_KERNEL, 1) != HR_E_INVALID) return 18;
+        if (hr_linear_forward(&x, 4, 8, 4, &x, NULL, 0, 0.01f, &x, 4, NULL) != HR_E_INVALID) return 20;          /* out < 1 */
+        if (hr_linear_backward(&x, 4, &x, NULL, 4, &x, 4, 8, 4, 4, 0.01f, NULL, 4, &x, &x, &x, NULL) != HR_E_INVALID) return 21;   /* mask missing */
+        if (hr_linear_workspace(0, 4, 4) != 0) return 22;
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
     }
     return 0;

@@ -75,3 +75,59 @@ def trainable_sweep_cases(cascades=False):
             hc = plan.compile_model(g.cfg, g.dataset, g.grid, iteration=g.iteration)[1]
         out.append(c)
     return out
+
+
+class GradGolden:
+    """Gradients of sum(rgb * G) from the REFERENCE'S OWN autograd in train mode (oracle/refgen/make_grad_golden.py): full arrays for
+    small tensors, 16 seeded projections + the L2 norm for the MLP's large matrices."""
+
+    def __init__(self, case, white):
+        z = np.load(os.path.join(GOLDEN_DIR, 'grad', f'{case}_bg{int(white)}.npz'))
+        self.recipe = json.loads(bytes(z['recipe']).decode())
+        self.rgb = z['rgb']
+        self.full = {k[5:]: z[k] for k in z.files if k.startswith('full/')}
+        self.proj = {k[5:]: z[k] for k in z.files if k.startswith('proj/')}
+        self.norm = {k[5:]: z[k] for k in z.files if k.startswith('norm/')}
+        self.n_rays = int(self.recipe['n_rays'])
+        self.G = np.random.default_rng(self.recipe['g_seed']).standard_normal((self.n_rays, 3)).astype(np.float32)
+
+    def names(self):
+        return sorted(set(self.full) | set(self.proj))
+
+    def check(self, name, got, rel):
+        """got: the gradient of tensor `name` (any shape with the same element order).  rel: tolerance relative to the reference
+        gradient's largest element (full) / to its norm (projections: each is a N(0, |g|^2) combination of the elements)."""
+        got = np.asarray(got, np.float64).ravel()
+        if name in self.full:
+            want = self.full[name].astype(np.float64).ravel()
+            assert got.size == want.size, (name, got.size, want.size)
+            scale = np.abs(want).max()
+            err = np.abs(got - want).max()
+            assert err <= rel * scale + 1e-9, f'{name}: |err| {err:.3e} vs max |g| {scale:.3e}'
+        else:
+            norm, size = self.norm[name]
+            assert got.size == int(size), (name, got.size, size)
+            seed = (sum(ord(c) * (i + 1) for i, c in enumerate(name)) * 2654435761 + got.size) % (2 ** 32)
+            v = np.random.default_rng(seed).standard_normal((16, got.size)).astype(np.float32).astype(np.float64)
+            err = np.abs(v @ got - self.proj[name]).max()
+            assert err <= rel * norm * 4.0 + 1e-9, f'{name}: projection error {err:.3e} vs |g| {norm:.3e}'
+            assert abs(np.linalg.norm(got) - norm) <= rel * norm + 1e-9, name
+
+
+def port_leaves(port):
+    """TorchPort tensors under the reference's parameter names (the keys of a gradient golden)."""
+    out = {}
+    net = 'model.color_model.net.'
+    video = bool(port.o.video) if hasattr(port, 'o') else bool(getattr(port, 'video', False))
+    a_name, b_name = ('plane_space', 'plane_time') if video else ('plane', 'line')
+    for kind, ga, gb in (('density', port.d_a, port.d_b), ('app', port.a_a, port.a_b)):
+        for j in range(3):
+            out[f'{net}{kind}_{a_name}.{j}'] = ga[j]
+            out[f'{net}{kind}_{b_name}.{j}'] = gb[j]
+    out[net + 'basis_mat.weight'] = port.basis
+    n = len(port.layers)
+    for i, (w, b) in enumerate(port.layers):
+        mid = f'{i}.0' if i < n - 1 else f'{i}'
+        out[f'model.embedding_model.embeddings.0.net.layers.{mid}.weight'] = w
+        out[f'model.embedding_model.embeddings.0.net.layers.{mid}.bias'] = b
+    return out

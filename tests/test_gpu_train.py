@@ -183,3 +183,68 @@ def test_flat_gradient_views_receive_the_hip_gradients():
         else:
             # scatter-adds are not ordered: equal up to fp32 summation order
             assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize('rows,fin,fout,slope,ld_extra', [(16384, 18, 256, 0.01, 0), (1000, 274, 256, 0.01, 0), (777, 256, 480, -1.0, 0),
+                                                          (64, 256, 352, -1.0, 0), (5, 23, 64, 0.01, 0), (2048, 256, 256, 0.01, 18)])
+def test_hip_linear_matches_torch_forward_and_backward(rows, fin, fout, slope, ld_extra):
+    """HipLinear (hr_linear_forward / hr_linear_backward: bf16x3 MFMA GEMMs) against torch's addmm + leaky_relu under autograd:
+    y, dx, dW, db.  ld_extra: x is a column slice of a wider buffer (the skip layer's view)."""
+    import torch.nn.functional as F
+    from hyperreel_amd.train import HipLinear
+    g = torch.Generator('cuda').manual_seed(rows + fin)
+    xw = torch.randn((rows, fin + ld_extra), device='cuda', generator=g)
+    w = (torch.rand((fout, fin), device='cuda', generator=g) - 0.5) * (2.0 / fin ** 0.5)
+    b = (torch.rand((fout,), device='cuda', generator=g) - 0.5) * 0.2
+    dy = torch.randn((rows, fout), device='cuda', generator=g) * 1e-3          # gradient-sized values: no fp16-style flush
+    outs = []
+    for impl in ('hip', 'torch'):
+        xx = xw.clone().requires_grad_(True)
+        ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xs = xx[:, ld_extra:]
+        if impl == 'hip':
+            y = HipLinear.apply(xs, ww, bb, slope)
+        else:
+            y = F.linear(xs.double(), ww.double(), bb.double())
+            y = F.leaky_relu(y, slope) if slope >= 0 else y
+        y.backward(dy.to(y.dtype))
+        outs.append((y.detach().double(), xx.grad.double(), ww.grad.double(), bb.grad.double()))
+    for name, a, r in zip(('y', 'dx', 'dw', 'db'), outs[0], outs[1]):
+        tol = 2e-5 * float(r.abs().max()) + 1e-12
+        assert float((a - r).abs().max()) <= tol, f'{name}: {float((a - r).abs().max()):.3e} vs max {float(r.abs().max()):.3e}'
+    # deterministic reductions: a second backward gives the same bits
+    xx = xw.clone().requires_grad_(True)
+    ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    HipLinear.apply(xx[:, ld_extra:], ww, bb, slope).backward(dy)
+    assert torch.equal(ww.grad.double(), outs[0][2]) and torch.equal(bb.grad.double(), outs[0][3])
+
+
+@pytest.mark.parametrize('white', [0, 1])
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small',
+                                  'immersive_sphere_small'])
+def test_training_gradients_match_the_reference_autograd(case, white):
+    """The HIP training step (HipLinear GEMMs + SampleStage kernels) against gradients the REFERENCE ITSELF produced under
+    torch.autograd in train mode (tests/golden/grad, oracle/refgen/make_grad_golden.py): the un-clamped forward and
+    d sum(rgb * G) / d every trainable tensor of the path, by the reference's own parameter names."""
+    from gpu_common import make_render_fn
+    from helpers import GradGolden
+    g = Golden(case)
+    gg = GradGolden(case, white)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    fn.train()
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:gg.n_rays], np.float32)).cuda()
+    rgb = fn.model.forward_train(rays, white_bg=bool(white))
+    (rgb * torch.from_numpy(gg.G).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert np.abs(rgb.detach().cpu().numpy() - gg.rgb).max() <= 5e-5
+    params = dict(fn.named_parameters())
+    checked = 0
+    for name in gg.names():
+        assert name in params, name
+        p = params[name]
+        if p.grad is None:
+            assert not np.abs(gg.full.get(name, np.zeros(1))).max() > 0, name
+            continue
+        gg.check(name, p.grad.detach().cpu().numpy(), 1e-3)
+        checked += 1
+    assert checked >= 15

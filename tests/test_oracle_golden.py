@@ -88,3 +88,36 @@ def test_torch_port_matches_reference_on_the_trainable_shipped_yamls(case):
     g = Golden(case)
     out = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(g.rays)
     assert linf(out['rgb'], g.rgb) <= 2e-5
+
+
+GRAD_CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small']
+
+
+@pytest.mark.parametrize('white', [0, 1])
+@pytest.mark.parametrize('case', GRAD_CASES)
+def test_torch_port_autograd_matches_the_reference_autograd(case, white):
+    """The gradient comparator of the training path (torch.autograd on oracle/torch_port.py: tests/test_train_host.py,
+    tests/test_gpu_train.py) is itself pinned to the REFERENCE'S OWN autograd: d sum(rgb * G) / d {planes, lines, basis_mat,
+    every MLP weight and bias} from the reference modules in train mode (tests/golden/grad, oracle/refgen/make_grad_golden.py)."""
+    import torch
+    from helpers import GradGolden, port_leaves
+    from torch_port import TorchPort
+    g = Golden(case)
+    gg = GradGolden(case, white)
+    port = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    leaves = port_leaves(port)
+    for t in leaves.values():
+        t.requires_grad_(True)
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:gg.n_rays], np.float32))
+    rgb = port.color(port.embed(rays), train=True, white_bg=bool(white))
+    assert np.abs(rgb.detach().numpy() - gg.rgb).max() <= 2e-5
+    (rgb * torch.from_numpy(gg.G)).sum().backward()
+    checked = 0
+    for name in gg.names():
+        assert name in leaves, name
+        t = leaves[name]
+        if t.grad is None:
+            continue
+        gg.check(name, t.grad.numpy(), 2e-4)
+        checked += 1
+    assert checked >= 15
