@@ -4,7 +4,7 @@ full-size synthetic scene of bench.py.
 
     python tools/train_bench.py [--model donerf_sphere] [--batch 16384] [--steps 30] [--torch-gpu]
 
-Prints one JSON line: ms per step of the HIP training path (hr_train_features + rocBLAS MLP + hr_train_forward /
+Prints one JSON line: ms per step of the HIP training path (hr_train_features + HipLinear MFMA GEMMs + hr_train_forward /
 hr_train_backward) with the sample stage's forward and backward kernels timed on their own, and with --torch-gpu the
 same step of the PyTorch-ROCm restatement of the reference (oracle/torch_port.py, autograd over grid_sample / sort /
 cumprod) on the same GPU, weights and rays.  The oracle is only the comparator here, never the thing shipped.
@@ -92,10 +92,36 @@ def main():
         SampleStage.apply(h, rays, head_g, False, vm.basis_mat.weight, *grids).backward(d_rgb)
 
     ms_stage_both = timed(stage_both, args.steps)
+    # the MLP alone, forward + backward: the split-precision MFMA GEMMs (HipLinear) next to the same layers through
+    # torch's F.linear (rocBLAS / hipBLASLt fp32), the comparator they replaced
+    import torch.nn.functional as F
+    feats = ray_features(h, rays, hc.mlp_in)
+    d_head = torch.rand_like(head) * 1e-3
+
+    def mlp_hip():
+        for p in params:
+            p.grad = None
+        mlp_forward(pred.net, feats, hc.mlp_skip_mask).backward(d_head)
+
+    def mlp_blas():
+        for p in params:
+            p.grad = None
+        x, inp, n = feats, feats, len(pred.net.layers)
+        for i, layer in enumerate(pred.net.layers):
+            lin = layer[0] if i < n - 1 else layer
+            if (hc.mlp_skip_mask >> i) & 1:
+                x = torch.cat([inp, x], -1)
+            x = F.linear(x, lin.weight, lin.bias)
+            if i < n - 1:
+                x = F.leaky_relu(x, 0.01)
+        x.backward(d_head)
+
+    ms_mlp_hip, ms_mlp_blas = timed(mlp_hip, args.steps), timed(mlp_blas, args.steps)
     out = {'workload': f'{args.model}: training step, batch {args.batch} rays x {hc.z_channels} samples, grid {grid[0]}x{grid[1]}x{grid[2]}',
            'hip_ms_per_step': round(ms_step, 3), 'hip_ms_forward_backward': round(ms_fwd_bwd, 3),
            'hip_ms_sample_stage_forward': round(ms_stage_fwd, 3),
            'hip_ms_sample_stage_backward': round(ms_stage_both - ms_stage_fwd, 3),
+           'hip_ms_mlp_forward_backward': round(ms_mlp_hip, 3), 'rocblas_ms_mlp_forward_backward': round(ms_mlp_blas, 3),
            'hip_krays_per_s': round(args.batch / ms_step, 1)}
 
     if args.torch_gpu:
