@@ -88,6 +88,10 @@ struct hr_model {
     float* grad_b[3] = {};
     float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
     int64_t tape_samples = 0;
+    // occupancy early-reject (hr_model_set_occupancy)
+    float* occ = nullptr;
+    int occ_n[3] = {};
+    float occ_lo[3] = {}, occ_inv[3] = {};
     // execution plan of hr_render (hr_model_set_option)
     int opt_frame_kernel = 0;              // measured: the two-kernel path is ~4 % faster on the benchmark frame
     int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
@@ -735,6 +739,9 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
         if (it != m->raw.end()) a.color_table = it->second.p;
     }
     a.dbg_mode = 0;
+    a.occ = m->occ;
+    a.occ_w = m->occ_n[0]; a.occ_h = m->occ_n[1]; a.occ_d = m->occ_n[2];
+    for (int i = 0; i < 3; ++i) { a.occ_lo[i] = m->occ_lo[i]; a.occ_inv[i] = m->occ_inv[i]; }
     a.rows_per_ray = rows_per_ray(m->cfg);
     a.rows_out = nullptr;
     a.row_dim = a.n_row_inputs = 0;
@@ -841,6 +848,27 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream)
 {
     return hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
+}
+
+int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n[3], const float aabb[6], void* stream)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    if (m->is_coarse) return fail(HR_E_INVALID, "the coarse level of a cascade has no colour net");
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));          // launches in flight may still read the old volume
+    free_dev(m->occ);
+    if (!volume_dev) return HR_OK;
+    if (!n || !aabb || n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(HR_E_INVALID, "occupancy volume without a size / box");
+    for (int i = 0; i < 3; ++i)
+        if (!(aabb[3 + i] > aabb[i])) return fail(HR_E_INVALID, "empty occupancy box");
+    const size_t bytes = sizeof(float) * (size_t)n[0] * n[1] * n[2];
+    HR_HIP(hipMalloc((void**)&m->occ, bytes));
+    HR_HIP(hipMemcpy(m->occ, volume_dev, bytes, hipMemcpyDefault));
+    for (int i = 0; i < 3; ++i) {
+        m->occ_n[i] = n[i];
+        m->occ_lo[i] = aabb[i];
+        m->occ_inv[i] = (1.0f / (aabb[3 + i] - aabb[i])) * 2.0f;        // AlphaGridMask: invgridSize = 1.0 / aabbSize * 2
+    }
+    return HR_OK;
 }
 
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
@@ -1263,6 +1291,7 @@ void hr_model_destroy(hr_model* m)
     free_dev(m->basis);
     free_dev(m->head);
     free_dev(m->rows);
+    free_dev(m->occ);
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); }

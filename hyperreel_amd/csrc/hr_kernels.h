@@ -66,6 +66,11 @@ struct HrSampleArgs {
     float* rows_out;        // coarse pass only: input rows of the point MLP, (n_rays * Z, row_dim); no colour is produced
     int row_dim, n_row_inputs;
     int row_kind[4], row_len[4];   // HR_PIN_* and columns of each input
+    // optional occupancy early-reject (hr_model_set_occupancy): AlphaGridMask.sample_alpha of the raw point (utils/tensorf_utils.py:
+    // 459-484) must be > 0 for a sample to be gathered -- the test the reference carries at tensorf_no_sample.py:171-177
+    const float* occ;       // (D, H, W) float volume or NULL
+    int occ_w, occ_h, occ_d;
+    float occ_lo[3], occ_inv[3];   // g = (p - lo) * inv - 1
     int dbg_mode;           // measurement builds only (-DHR_TUNING, HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 

@@ -37,6 +37,7 @@ SYMBOLS = [
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
     ('hr_model_set_option', C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ('hr_model_get_option', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ('hr_model_set_occupancy', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_void_p]),
     ('hr_render', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_render_fields', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(hr_fields), C.c_void_p]),
     ('hr_generate_rays', C.c_int, [C.POINTER(hr_camera), C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -366,6 +366,10 @@ class HipLightfieldModel(nn.Module):
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
         # execution plan of render() (hr_model_set_option): frame kernel on/off, its sample wavefronts (None: library default)
+        # opt-in occupancy early-reject (hr_model_set_occupancy): samples the colour net's AlphaGridMask rejects are neither
+        # gathered nor composited -- the reference's own test at tensorf_no_sample.py:171-177, which it ships disabled
+        self.use_occupancy = bool(kwargs.get('use_occupancy', False))
+        self._occ_key = None
         self.frame_kernel = bool(kwargs.get('frame_kernel', False))
         self.sample_waves = kwargs.get('sample_waves')
         net = cfg['color']['net']
@@ -506,6 +510,7 @@ class HipLightfieldModel(nn.Module):
             else:
                 _lib.check(L.hr_model_create_cascade(C.byref(coarse), C.byref(hc), C.byref(h)), 'hr_model_create_cascade')
             self._native = h
+            self._occ_key = None                   # a fresh handle holds no occupancy volume
             self._apply_options()
             self._native_grid = self.grid_size
             self._native_box = (self.color_model.net.aabb.data_ptr(), self.color_model.net.aabb._version)
@@ -529,6 +534,33 @@ class HipLightfieldModel(nn.Module):
         self._coarse_hc = coarse
         self._sync_schedule(hc, coarse)          # an existing handle may still hold another iteration's constants
         return self._native
+
+    def _sync_occupancy(self):
+        """Hands the colour net's current mask volume to the native model (or clears it)."""
+        import ctypes as C
+        net = self.color_model.net
+        vol = getattr(net, 'alpha_volume', None) if self.use_occupancy else None
+        key = None if vol is None else (vol.data_ptr(), vol._version, tuple(vol.shape), net.alpha_aabb.data_ptr(), net.alpha_aabb._version)
+        if key == self._occ_key or self._native is None:
+            return
+        L = _lib.load()
+        dev = next(self.parameters()).device
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if vol is None:
+                _lib.check(L.hr_model_set_occupancy(self._native, C.c_void_p(0), None, None, stream), 'hr_model_set_occupancy')
+            else:
+                v = vol.detach().contiguous().float().to(dev)
+                n = (C.c_int32 * 3)(v.shape[2], v.shape[1], v.shape[0])
+                box = (C.c_float * 6)(*net.alpha_aabb.detach().cpu().reshape(-1).tolist())
+                _lib.check(L.hr_model_set_occupancy(self._native, C.c_void_p(v.data_ptr()), n, box, stream), 'hr_model_set_occupancy')
+        self._occ_key = key
+
+    def set_occupancy(self, enable=True):
+        """Turns the occupancy early-reject of render() on or off (needs a mask: updateAlphaMask or a checkpoint's)."""
+        self.use_occupancy = bool(enable)
+        if self._native is not None:
+            self._sync_occupancy()
 
     def _apply_options(self):
         L = _lib.load()
@@ -584,6 +616,7 @@ class HipLightfieldModel(nn.Module):
         'head' (B,Z*P) listed in `want`.  out: an existing (B,3) float32 device tensor to render into."""
         import ctypes as C
         h = self.native()
+        self._sync_occupancy()
         L = _lib.load()
         rays = self._check_rays(rays)
         B = rays.shape[0]

@@ -275,6 +275,15 @@ enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACT
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 
+/* Opt-in occupancy early-reject of the render path.  The reference builds an AlphaGridMask while training
+ * (TensorBase.updateAlphaMask) and carries the test in its forward -- `alphas = self.alphaMask.sample_alpha(xyz_sampled[ray_valid]);
+ * ray_valid &= alphas > 0` (nlf/nets/tensorf_no_sample.py:171-177, utils/tensorf_utils.py:459-484) -- but ships it disabled
+ * (`... and False`).  With a volume set, hr_render / hr_render_fields apply exactly that test to every valid sample before the
+ * feature gather: rejected samples are not fetched and composite with sigma = 0, i.e. the image is the reference's with its
+ * `and False` removed (pinned by a fixture rendered that way).  volume_dev: (n[2], n[1], n[0]) floats as AlphaGridMask.alpha_volume
+ * holds them (x fastest), copied; aabb: its box [min xyz, max xyz].  NULL volume: back to the shipped behaviour.  Waits for `stream`. */
+int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n[3], const float aabb[6], void* stream);
+
 /* rgb_dev[n,3] = render_fn(rays_dev[n,ray_dim])['rgb']  (eval mode: clamped to [0,1]). */
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,

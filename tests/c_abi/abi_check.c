@@ -44,6 +44,7 @@ int main(void)
         if (hr_linear_forward(&x, 4, 8, 4, &x, NULL, 0, 0.01f, &x, 4, NULL) != HR_E_INVALID) return 20;          /* out < 1 */
         if (hr_linear_backward(&x, 4, &x, NULL, 4, &x, 4, 8, 4, 4, 0.01f, NULL, 4, &x, &x, &x, NULL) != HR_E_INVALID) return 21;   /* mask missing */
         if (hr_linear_workspace(0, 4, 4) != 0) return 22;
+        if (hr_model_set_occupancy(NULL, NULL, n3, box, NULL) != HR_E_INVALID) return 23;
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
     }
     return 0;

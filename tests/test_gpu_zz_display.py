@@ -106,3 +106,38 @@ def test_training_gradients_of_cascades_and_long_intersections(case):
     # the MLPs: the gradient reached them (their values are autograd's own once d_head is right, which the planes certify)
     got = [p.grad for m in fn.model.embedding_model.embeddings if hasattr(m, 'net') and hasattr(m.net, 'layers') for p in m.net.parameters()]
     assert got and all(gp is not None and bool(torch.isfinite(gp).all()) for gp in got)
+
+
+def test_occupancy_early_reject_equals_the_reference_with_its_mask_enabled():
+    """Opt-in occupancy test of the render path (hr_model_set_occupancy): the image must equal what the REFERENCE renders
+    when the test it ships disabled (`if self.alphaMask is not None and False`, tensorf_no_sample.py:171) is switched on --
+    tests/golden/mask/alpha_mask_render.npz, made by oracle/refgen/make_alpha_mask.py from the reference's own forward
+    source on an uncarved scene whose mask threshold cuts into real density (masked vs shipped image: L-inf 0.69).
+    Off, the image is the shipped one; both execution plans agree bit for bit."""
+    import json
+    import os
+    from gpu_common import make_render_fn, to_torch_state_dict
+    from helpers import GOLDEN_DIR
+    from hyperreel_amd import config as C, scenes
+    z = np.load(os.path.join(GOLDEN_DIR, 'mask', 'alpha_mask_render.npz'))
+    r = json.loads(bytes(z['recipe']).decode())
+    cfg = C.model_config(r['model'])
+    cfg['color']['net']['alpha_mask_thre'] = r['thre']
+    sd = scenes.make_state_dict(cfg, r['dataset'], r['grid'], r['seed'], 'dense', 1.0)
+    fn = make_render_fn(cfg, r['dataset'], sd)
+    net = fn.model.color_model.net
+    rays = torch.from_numpy(np.ascontiguousarray(z['rays'], np.float32)).cuda()
+    plain = fn.model.render(rays)['rgb'].cpu().numpy()
+    assert np.abs(plain - z['rgb_plain']).max() <= 1e-4
+    net.updateAlphaMask(tuple(r['n1']))                                  # the mask, built on the device (hr_dense_alpha)
+    assert np.array_equal(net.alpha_volume.cpu().numpy(), z['mask_volume'])
+    fn.model.set_occupancy(True)
+    masked = fn.model.render(rays)['rgb']
+    assert np.abs(masked.cpu().numpy() - z['rgb_masked']).max() <= 1e-4
+    assert np.abs(z['rgb_masked'] - z['rgb_plain']).max() > 0.1          # the fixture distinguishes the two behaviours
+    fn.model.set_execution(frame_kernel=True)
+    if fn.model.frame_kernel_active():
+        assert torch.equal(fn.model.render(rays)['rgb'], masked)
+    fn.model.set_execution(frame_kernel=False)
+    fn.model.set_occupancy(False)
+    assert np.abs(fn.model.render(rays)['rgb'].cpu().numpy() - z['rgb_plain']).max() <= 1e-4

@@ -1,0 +1,39 @@
+"""Speed of the opt-in occupancy early-reject on a sparse scene: the 600^3 DoNeRF benchmark scene with its density carved to
+a sub-box (scenes.carve_density: what a trained scene looks like -- most of the volume empty), 800x800 frame, with and
+without hr_model_set_occupancy.  python tools/occupancy_bench.py"""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hyperreel_amd import config as C, scenes
+from hyperreel_amd.render import build_render_fn
+
+cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf_sphere')
+sd = scenes.carve_density(scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0))
+grid = [int(v) for v in sd['model.color_model.net.gridSize']]
+fn = build_render_fn(cfg, dataset=ds, grid_size=grid)
+fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800, frame=7)).cuda()
+net = fn.model.color_model.net
+
+
+def ms(n=30):
+    for _ in range(5):
+        fn.model.render(rays)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        fn.model.render(rays)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+plain = fn.model.render(rays)['rgb'].clone()
+t_plain = ms()
+net.updateAlphaMask((200, 200, 200))
+kept = float(net.alpha_volume.mean())
+fn.model.set_occupancy(True)
+masked = fn.model.render(rays)['rgb'].clone()
+t_mask = ms()
+print(json.dumps({'workload': 'donerf_sphere 600^3, density carved to a sub-box, 800x800 frame', 'mask_kept_fraction': round(kept, 4),
+                  'ms_per_frame_shipped': round(t_plain, 3), 'ms_per_frame_occupancy': round(t_mask, 3), 'speedup': round(t_plain / t_mask, 3),
+                  'linf_masked_vs_shipped': float((masked - plain).abs().max())}))
