@@ -147,6 +147,46 @@ def capture(model, rays):
     return graph, out
 
 
+def viewer_figures(sizes=((512, 512), (800, 800)), model_name='immersive_sphere'):
+    """BASELINE configs[4] (Google Immersive, viewer path): one displayed frame = camera -> rays on the device
+    (hr_generate_rays; datasets/base.py:485-518) -> render -> the viewer's transpose / flip / 8-bit pack (hr_pack_display;
+    utils/gui_utils.py:174-205), captured as ONE hipGraph and replayed; float16 texels, and next to the default f16x3 MLP the
+    two-product f16x2 speed mode.  ms per displayed frame."""
+    from hyperreel_amd.render import build_render_fn
+    cfg, ds = C.model_config(model_name), C.dataset_scalars(model_name)
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    grid = [int(v) for v in sd['model.color_model.net.gridSize']]
+    out = {'model': model_name, 'grid': grid, 'grid_dtype': 'fp16',
+           'what': 'pose -> hr_generate_rays -> hr_render -> hr_pack_display (RGBA8, transposed + flipped like NeRFGUI.test_step), one hipGraph replay per frame'}
+    pose = scenes.look_at_pose((0.3, 0.0, 0.0), (1.0, 0.1, 0.05))
+    for prec in ('auto', 'f16x2'):
+        f = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=prec, grid_dtype='fp16')
+        f.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        m = f.model
+        for (h, w) in sizes:
+            foc = 0.5 * w / np.tan(0.5 * np.deg2rad(40.0))
+            K = np.array([[foc, 0, w / 2], [0, foc, h / 2], [0, 0, 1]], np.float32)
+
+            def frame():
+                return m.pack_display(m.render_camera(pose, K, w, h, time=7.0 / 49.0), h, w, transpose=True, flip=True, rgba8=True)
+            frame()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                frame()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                frame()
+            d = timed_frames(g.replay, 30, 5, False, None)
+            out[f'{"f16x3" if prec == "auto" else prec}_{h}x{w}_ms'] = round(d / 30 * 1e3, 4)
+        del f, m
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -439,6 +479,12 @@ def main():
             'what': 'the reference algorithm as stock PyTorch-ROCm ops (grid_sample, addmm, sort, cumprod) on the same MI355X',
             'speedup_of_value': round(value / best[0], 1),
             'linf_vs_hip': float((out_t - rgb).abs().max())}
+
+    if extras and args.model == 'donerf_sphere':
+        try:
+            result['viewer_path'] = viewer_figures()
+        except Exception as e:                                  # never lose the headline line to an extra
+            result['viewer_path'] = {'error': repr(e)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -70,6 +70,9 @@ struct hr_model {
     float* grid_b[3] = {};
     HrGridPlane planes[3] = {};
     float* basis = nullptr;
+    float* basis_t = nullptr;            // column-major copy for the decode-matrix fold (HrSampleArgs::basis_t)
+    int* slot_col = nullptr;
+    int basis_ld = 0;
     int n_basis_cols = 0;
     int ca_total = 0;
     // workspace
@@ -624,6 +627,23 @@ int hr_model_finalize(hr_model* m)
         HR_HIP(hipMalloc((void**)&m->basis, bytes > 0 ? bytes : 16));
         if (bytes > 0) HR_HIP(hipMemcpy(m->basis, m->raw["basis_mat.weight"].p, bytes, hipMemcpyDeviceToDevice));
         m->packed_bytes += (int64_t)bytes;
+        // column-major copy + the slot -> column map (what hr_fill_decode used to recompute per ray and slot)
+        const int AD = c.app_dim, ld = (AD + 3) & ~3;
+        std::vector<float> bm((size_t)AD * n_app_sum), bt((size_t)(n_app_sum > 0 ? n_app_sum : 1) * ld, 0.0f);
+        if (bytes > 0) HR_HIP(hipMemcpy(bm.data(), m->raw["basis_mat.weight"].p, bytes, hipMemcpyDeviceToHost));
+        for (int col = 0; col < n_app_sum; ++col)
+            for (int r = 0; r < AD; ++r) bt[(size_t)col * ld + r] = bm[(size_t)r * n_app_sum + col];
+        std::vector<int> sc(m->ca_total > 0 ? m->ca_total : 1, -1);
+        for (int j = 0; j < 3; ++j)
+            if (m->planes[j].ca4 > 0)
+                for (int rel = 0; rel < m->planes[j].app_real; ++rel) sc[m->planes[j].app_off + rel] = m->planes[j].app_real_off + rel;
+        free_dev(m->basis_t);
+        free_dev(reinterpret_cast<float*&>(m->slot_col));
+        HR_HIP(hipMalloc((void**)&m->basis_t, bt.size() * sizeof(float)));
+        HR_HIP(hipMemcpy(m->basis_t, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice));
+        HR_HIP(hipMalloc((void**)&m->slot_col, sc.size() * sizeof(int)));
+        HR_HIP(hipMemcpy(m->slot_col, sc.data(), sc.size() * sizeof(int), hipMemcpyHostToDevice));
+        m->basis_ld = ld;
     }
     HR_HIP(hipDeviceSynchronize());
     HR_HIP(hipGetLastError());
@@ -730,6 +750,9 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.fields = hr_fields();
     for (int j = 0; j < 3; ++j) a.planes[j] = m->planes[j];
     a.basis = m->basis;
+    a.basis_t = m->basis_t;
+    a.slot_col = m->slot_col;
+    a.basis_ld = m->basis_ld;
     a.n_basis_cols = m->n_basis_cols;
     a.ca_total = m->ca_total;
     // the table is read in place from the uploaded copy (12 floats per camera, no re-layout)
@@ -1289,6 +1312,8 @@ void hr_model_destroy(hr_model* m)
         free_dev(m->grid_b[j]);
     }
     free_dev(m->basis);
+    free_dev(m->basis_t);
+    free_dev(reinterpret_cast<float*&>(m->slot_col));
     free_dev(m->head);
     free_dev(m->rows);
     free_dev(m->occ);

@@ -57,6 +57,9 @@ struct HrSampleArgs {
     hr_fields fields;       // optional diagnostics (NULL pointers when unused)
     HrGridPlane planes[3];
     const float* basis;     // (app_dim, n_basis_cols) row-major, torch layout
+    const float* basis_t;   // the same matrix column-major: basis_t[col * basis_ld + row] -- the 27 (3) values a decode-matrix slot folds are contiguous
+    const int* slot_col;    // padded appearance slot -> column of basis_mat, or -1 (ca_total entries)
+    int basis_ld;           // app_dim rounded up to a multiple of 4
     int n_basis_cols;       // sum of the real appearance channels of the sampled planes
     int ca_total;           // padded appearance slots (multiple of 4) = sum 4*ca4
     const float* color_table;  // (color_table_views, 12) per-camera [3x3 | shift], or NULL
