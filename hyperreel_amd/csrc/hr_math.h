@@ -114,9 +114,13 @@ HR_FN float hr_axis_plane_t(float val, float o, float d)
 // nlf/param.py:244-253 (pluecker), :87-115 (two_plane), :20-24 (identity) followed by
 // nlf/pe.py:210-221 (windowed) / :53-66 (basic).  Writes mlp_in floats to `out`
 // (stride 1).  Returns the number written.
-HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
+// part / nparts: the work can be shared by `nparts` callers on the same ray (the MLP kernels' 4 wavefronts): every caller
+// evaluates the cheap parameterisation, caller `part` writes the identity columns if part == 0 and the sin/cos columns
+// whose running index is congruent to `part` -- the libm-grade sincos chains are what the prologue's time goes into.
+HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out, int part = 0, int nparts = 1)
 {
     int n_out = 0;
+    int pe_idx = 0;
     for (int g = 0; g < c.n_groups; ++g) {
         const hr_param_group& pg = c.groups[g];
         // up to 8 parameterised values, kept in registers (all loops over them are unrolled)
@@ -159,15 +163,19 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
         }
 #define HR_X(i) ((i) == 0 ? x0 : (i) == 1 ? x1 : (i) == 2 ? x2 : (i) == 3 ? x3 : (i) == 4 ? x4 : (i) == 5 ? x5 : (i) == 6 ? x6 : x7)
         const bool ident = (pg.pe_type == HR_PE_NONE) || (pg.pe_type == HR_PE_BASIC) || !pg.pe_exclude_identity;
-        if (ident)
-            for (int i = 0; i < nx; ++i) out[n_out++] = HR_X(i);
+        if (ident) {
+            if (part == 0)
+                for (int i = 0; i < nx; ++i) out[n_out + i] = HR_X(i);
+            n_out += nx;
+        }
         if (pg.pe_type == HR_PE_WINDOWED) {
             float f = 1.0f;
             for (int j = 0; j < pg.pe_n_freqs; ++j) {
                 f = f * pg.pe_freq_mult;                           // freq_multiplier ** (j+1)
                 float bf = pg.pe_base_mult * f;
                 const float w = pg.pe_weight[j];                   // WindowedPE.weight(j), pe.py:186-208 (1 after the window)
-                for (int i = 0; i < nx; ++i) {                     // [sin(all i), cos(all i)] per frequency
+                for (int i = 0; i < nx; ++i, ++pe_idx) {          // [sin(all i), cos(all i)] per frequency
+                    if (pe_idx % nparts != part) continue;
                     float sv, cv;
                     HR_SINCOS(bf * HR_X(i), &sv, &cv);
                     out[n_out + i] = w * sv;
@@ -178,11 +186,11 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out)
         } else if (pg.pe_type == HR_PE_BASIC) {  // [x, sin(f_j x_i) (i-major, j-minor), cos(...)]
             for (int i = 0; i < nx; ++i) {
                 float f = 1.0f;
-                for (int j = 0; j < pg.pe_n_freqs; ++j) { f = f * pg.pe_freq_mult; out[n_out++] = sinf(f * HR_X(i)); }
+                for (int j = 0; j < pg.pe_n_freqs; ++j, ++pe_idx) { f = f * pg.pe_freq_mult; if (pe_idx % nparts == part) out[n_out] = sinf(f * HR_X(i)); ++n_out; }
             }
             for (int i = 0; i < nx; ++i) {
                 float f = 1.0f;
-                for (int j = 0; j < pg.pe_n_freqs; ++j) { f = f * pg.pe_freq_mult; out[n_out++] = cosf(f * HR_X(i)); }
+                for (int j = 0; j < pg.pe_n_freqs; ++j, ++pe_idx) { f = f * pg.pe_freq_mult; if (pe_idx % nparts == part) out[n_out] = cosf(f * HR_X(i)); ++n_out; }
             }
         }
 #undef HR_X
