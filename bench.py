@@ -206,8 +206,8 @@ def main():
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
     ap.add_argument('--lib', default='', help='measurement builds only (tools/build_variant.py): load this library instead of the in-tree one')
-    ap.add_argument('--frame-kernel', action='store_true', help='render through the persistent frame kernel (head tile in LDS) instead of the two-kernel path')
-    ap.add_argument('--no-frame-kernel', action='store_true', help='(default) two-kernel path through the HBM workspace')
+    ap.add_argument('--frame-kernel', action='store_true', help='(default where the model fits) the persistent frame kernel, head tile in LDS')
+    ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead')
     ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
 
@@ -250,7 +250,8 @@ def main():
         f.model.native()
         return f
 
-    fn = make(args.mlp_precision, args.frame_kernel)
+    use_frame = not args.no_frame_kernel
+    fn = make(args.mlp_precision, use_frame)
     model = fn.model
     strong = args.scaling == 'strong' and multi
     Z = cfg['embedding']['embeddings']['ray_prediction_0']['z_channels']
@@ -400,10 +401,39 @@ def main():
                     r_smp['valu_insts_per_sample_slot'] = k.get('valu_insts_per_wave')
         except (OSError, KeyError, ValueError):
             pass
-        dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
-        result['roofline'] = dom
-        result['roofline_other'] = oth
         result['stage_ms'] = {'mlp': round(mlp_ms[0], 4), 'samples': round(smp_ms[0], 4)}
+        if model.frame_kernel_active() and not strong:
+            # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
+            # the frame's arithmetic) and quote the VALU issue fraction -- what actually limits it -- next to it
+            fr_ms = time_stage(lambda: model.render(rays, out=rgb_tmp), reps)
+            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel'}[prec_name]
+            r_fr = {'kernel': fk, 'bound': 'mfma', 'achieved': round(flops / (fr_ms[0] * 1e-3) / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(flops / (fr_ms[0] * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': 1,
+                    'avg_launch_ms': round(fr_ms[0], 4), 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {B} rays',
+                    'mfma_products_per_gemm': n_prod,
+                    'note': 'ONE persistent kernel per frame: MLP wavefronts (matrix cores) and sample wavefronts (vector ALU) of the same '
+                            'workgroup, head tile in LDS.  frac prices the whole frame against the 16-bit MFMA peak with the algorithmic MLP FLOPs '
+                            f'(<= 1/{n_prod} by construction); the kernel is bound by the sample wavefronts\' dependent-instruction latency at '
+                            '8 of them per CU (DESIGN.md 3c), see valu_busy_frac / mfma_busy_frac'}
+            try:
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters_frame_kernel.json')))
+                w = tr['workload']
+                if (w['model'] == args.model and w['rays_per_launch'] == B and w['grid'] == grid and w['mlp_precision'] == prec_name
+                        and w['grid_dtype'] == args.grid_dtype and fk in tr):
+                    k = tr[fk]
+                    r_fr['traffic'] = k.get('traffic_bytes')
+                    r_fr['traffic_unit'] = 'HBM-side bytes per launch = per frame (FETCH_SIZE + WRITE_SIZE, profiles/r02_counters_frame_kernel.json)'
+                    for key in ('valu_busy_frac', 'mfma_busy_frac', 'ta_busy_frac', 'limiter'):
+                        if key in k:
+                            r_fr[key] = k[key]
+            except (OSError, KeyError, ValueError):
+                pass
+            result['roofline'] = r_fr
+            result['roofline_other'] = {'what': 'the two kernels of the other execution plan (two_kernel_path), timed through hr_stage_*', 'mlp': r_mlp, 'samples': r_smp}
+        else:
+            dom, oth = (r_mlp, r_smp) if mlp_ms[0] >= smp_ms[0] else (r_smp, r_mlp)
+            result['roofline'] = dom
+            result['roofline_other'] = oth
 
     extras = rank == 0 and world == 1 and not args.no_extras
     # ---- the same frame through the other execution plan, and with the exact fp32-MFMA MLP
@@ -412,7 +442,7 @@ def main():
             g, _ = capture(f.model, rays)
             d = timed_frames(g.replay, 20, 5, False, None)
             return B / (d / 20) / 1e6, d / 20 * 1e3
-        other = make(args.mlp_precision, not args.frame_kernel)
+        other = make(args.mlp_precision, not use_frame)
         if other.model.frame_kernel_active() != model.frame_kernel_active():
             v, ms = quick(other)
             same = bool(torch.equal(other.model.render(rays)['rgb'], rgb))

@@ -554,15 +554,19 @@ struct hr_axis_tap_c {
 };
 HR_FN hr_axis_tap_c hr_make_tap_c(float g, int n)
 {
-    const hr_axis_tap u = hr_make_tap(g, n);          // masked weights (indices recomputed below: u.i0 / u.i1 are clamped per tap)
+    // same arithmetic as hr_make_tap for ix and the two weights (ATen's (x1 - ix), (ix - x0)), evaluated once
     float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
-    const int i0 = (int)floorf(ix);
+    float f0 = floorf(ix);
+    float f1 = f0 + 1.0f;
+    const int i0 = (int)f0;
+    const float w0 = ((i0 >= 0) && (i0 < n)) ? (f1 - ix) : 0.0f;          // zeroed for a tap ATen drops as out of range
+    const float w1 = ((i0 + 1 >= 0) && (i0 + 1 < n)) ? (ix - f0) : 0.0f;
     int ic = i0 < 0 ? 0 : i0;
     ic = ic > n - 2 ? n - 2 : ic;
     hr_axis_tap_c t;
     t.i0 = ic;
-    t.w0 = (i0 == ic) ? u.w0 : ((i0 + 1 == ic) ? u.w1 : 0.0f);
-    t.w1 = (i0 == ic) ? u.w1 : ((i0 == ic + 1) ? u.w0 : 0.0f);
+    t.w0 = (i0 == ic) ? w0 : ((i0 + 1 == ic) ? w1 : 0.0f);
+    t.w1 = (i0 == ic) ? w1 : ((i0 == ic + 1) ? w0 : 0.0f);
     return t;
 }
 

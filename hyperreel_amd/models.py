@@ -370,7 +370,7 @@ class HipLightfieldModel(nn.Module):
         # gathered nor composited -- the reference's own test at tensorf_no_sample.py:171-177, which it ships disabled
         self.use_occupancy = bool(kwargs.get('use_occupancy', False))
         self._occ_key = None
-        self.frame_kernel = bool(kwargs.get('frame_kernel', False))
+        self.frame_kernel = bool(kwargs.get('frame_kernel', True))
         self.sample_waves = kwargs.get('sample_waves')
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:

@@ -262,13 +262,13 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
 
 /* Execution plan of hr_render.  The arithmetic is the same under every setting (bit-identical images); the options choose
  * how it is laid out on the device.
- *   HR_OPT_FRAME_KERNEL   0 (default): two kernels per chunk of rays -- the MLP writes the (B, Z*P) head that the reference
- *                         materialises between RayPredictionEmbedding and Intersect (nlf/embedding/ray.py:332-337 ->
- *                         nlf/intersect/base.py:142-259) to an HBM workspace, the sample kernel reads it back.
- *                         1: models whose 64-ray head tile fits the CU's LDS are rendered by ONE persistent kernel in
- *                         which MLP wavefronts hand that tile to sample wavefronts of the same workgroup through LDS (no
- *                         workspace traffic); models that do not fit, and every hr_render_fields call with a non-NULL
- *                         `fields`, keep the two-kernel path.
+ *   HR_OPT_FRAME_KERNEL   1 (default): models whose 64-ray head tile fits the CU's LDS are rendered by ONE persistent kernel in
+ *                         which MLP wavefronts hand the (B, Z*P) head that the reference materialises between
+ *                         RayPredictionEmbedding and Intersect (nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259)
+ *                         to sample wavefronts of the same workgroup through LDS -- no workspace traffic; models that do
+ *                         not fit (wider heads, cascades, the exact-fp32 MLP), and every hr_render_fields call with a
+ *                         non-NULL `fields`, take the two-kernel path.  0: always two kernels per chunk of rays -- the MLP
+ *                         writes the head to an HBM workspace, the sample kernel reads it back.
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8.
  * hr_model_get_option(HR_OPT_FRAME_KERNEL_ACTIVE) answers whether hr_render currently takes the frame kernel (read-only). */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2 };

@@ -38,11 +38,11 @@ def _render(fn, rays_t, frame_kernel, sample_waves=None):
 @pytest.mark.parametrize('case', FUSABLE)
 def test_fusable_models_take_the_frame_kernel(case):
     g, fn = _fns(case)
-    assert not fn.model.frame_kernel_active()          # opt-in: the two-kernel path is the (faster) default
-    fn.model.set_execution(frame_kernel=True)
-    assert fn.model.frame_kernel_active()
+    assert fn.model.frame_kernel_active()              # the default plan where the head tile fits
     fn.model.set_execution(frame_kernel=False)
     assert not fn.model.frame_kernel_active()
+    fn.model.set_execution(frame_kernel=True)
+    assert fn.model.frame_kernel_active()
 
 
 @pytest.mark.parametrize('case', ['technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',

@@ -7,22 +7,23 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; T=${1:-a}
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 mkdir -p gpurun_out
-bash tools/pmc.sh ${T}_two > /dev/null 2>&1
+bash tools/pmc.sh ${T}_two --no-frame-kernel > /dev/null 2>&1
 python tools/make_counters.py ${T}_two gpurun_out/r02_counters.json donerf_sphere f16x3 fp32 131072 600 600 600 > gpurun_out/r02_${T}_counters_summary.txt
-bash tools/pmc.sh ${T}_frame --frame-kernel > /dev/null 2>&1
+bash tools/pmc.sh ${T}_frame > /dev/null 2>&1
 python tools/make_counters.py ${T}_frame gpurun_out/r02_counters_frame_kernel.json donerf_sphere f16x3 fp32 640000 600 600 600 >> gpurun_out/r02_${T}_counters_summary.txt
 cp gpurun_out/r02_counters.json profiles/r02_counters.json      # so that this run's bench line quotes them
+cp gpurun_out/r02_counters_frame_kernel.json profiles/r02_counters_frame_kernel.json
 timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/r02_${T}_bench.json
-cd /tmp && rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o rp -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-stage-timing --no-extras > /tmp/prof.log 2>&1
+cd /tmp && rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o rp -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-stage-timing --no-extras --no-frame-kernel > /tmp/prof.log 2>&1
 cd $R
 for f in $(find /tmp/prof -name "*kernel_stats*.csv"); do cp $f gpurun_out/r02_${T}_kernel_stats.csv; done
 for f in $(find /tmp/prof -name "*kernel_trace*.csv"); do head -60 $f > gpurun_out/r02_${T}_kernel_trace_head.csv; done
-cd /tmp && rm -rf /tmp/prof2 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -o rp -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-stage-timing --no-extras --frame-kernel > /tmp/prof2.log 2>&1
+cd /tmp && rm -rf /tmp/prof2 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -o rp -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-stage-timing --no-extras > /tmp/prof2.log 2>&1
 cd $R
 for f in $(find /tmp/prof2 -name "*kernel_stats*.csv"); do cp $f gpurun_out/r02_${T}_kernel_stats_frame_kernel.csv; done
 cat gpurun_out/r02_${T}_counters_summary.txt; python -c "
 import json; d=json.load(open('gpurun_out/r02_${T}_bench.json'))
-for k in ('value','ms_per_step','stage_ms','frame_kernel','value_fp32_exact','pytorch_gpu_baseline','cpu_baseline','parity_vs_oracle_linf','parity_rays_over_1e-4'): print(k, d.get(k))
+for k in ('value','ms_per_step','stage_ms','frame_kernel','two_kernel_path','value_fp32_exact','pytorch_gpu_baseline','cpu_baseline','parity_vs_oracle_linf','parity_rays_over_1e-4','viewer_path'): print(k, d.get(k))
 print('roofline', {k: d['roofline'].get(k) for k in ('kernel','bound','achieved','peak','frac','traffic','avg_launch_ms','mfma_busy_frac')})
-print('other', {k: d['roofline_other'].get(k) for k in ('kernel','bound','achieved','peak','frac','traffic','avg_launch_ms','valu_insts_per_sample_slot')})
+print('roofline all', d['roofline']); print('other', d['roofline_other'])
 "; head -8 gpurun_out/r02_${T}_kernel_stats.csv; head -5 gpurun_out/r02_${T}_kernel_stats_frame_kernel.csv
