@@ -93,6 +93,7 @@ struct hr_model {
     int64_t tape_samples = 0;
     // occupancy early-reject (hr_model_set_occupancy)
     float* occ = nullptr;
+    unsigned* occ_cells = nullptr;        // one bit per lattice cell, built from a 0/1 volume (HrSampleArgs::occ_cells)
     int occ_n[3] = {};
     float occ_lo[3] = {}, occ_inv[3] = {};
     // execution plan of hr_render (hr_model_set_option)
@@ -763,6 +764,7 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     }
     a.dbg_mode = 0;
     a.occ = m->occ;
+    a.occ_cells = m->occ_cells;
     a.occ_w = m->occ_n[0]; a.occ_h = m->occ_n[1]; a.occ_d = m->occ_n[2];
     for (int i = 0; i < 3; ++i) { a.occ_lo[i] = m->occ_lo[i]; a.occ_inv[i] = m->occ_inv[i]; }
     a.rows_per_ray = rows_per_ray(m->cfg);
@@ -879,6 +881,7 @@ int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n
     if (m->is_coarse) return fail(HR_E_INVALID, "the coarse level of a cascade has no colour net");
     HR_HIP(hipStreamSynchronize((hipStream_t)stream));          // launches in flight may still read the old volume
     free_dev(m->occ);
+    free_dev(reinterpret_cast<float*&>(m->occ_cells));
     if (!volume_dev) return HR_OK;
     if (!n || !aabb || n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(HR_E_INVALID, "occupancy volume without a size / box");
     for (int i = 0; i < 3; ++i)
@@ -890,6 +893,31 @@ int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n
         m->occ_n[i] = n[i];
         m->occ_lo[i] = aabb[i];
         m->occ_inv[i] = (1.0f / (aabb[3 + i] - aabb[i])) * 2.0f;        // AlphaGridMask: invgridSize = 1.0 / aabbSize * 2
+    }
+    // cell table: a 0/1 volume (what updateAlphaMask stores) sampled strictly inside a lattice cell is > 0 exactly when one of
+    // the cell's 8 corners is set
+    if (n[0] > 1 && n[1] > 1 && n[2] > 1) {
+        const size_t W = n[0], H = n[1], D = n[2];
+        std::vector<float> v(W * H * D);
+        HR_HIP(hipMemcpy(v.data(), m->occ, bytes, hipMemcpyDeviceToHost));
+        bool binary = true;
+        for (float x : v) if (x != 0.0f && x != 1.0f) { binary = false; break; }
+        if (binary) {
+            const size_t cells = (W - 1) * (H - 1) * (D - 1);
+            std::vector<unsigned> bits((cells + 31) / 32, 0u);
+            for (size_t z = 0; z + 1 < D; ++z)
+                for (size_t y = 0; y + 1 < H; ++y)
+                    for (size_t x = 0; x + 1 < W; ++x) {
+                        bool any = false;
+                        for (int c = 0; c < 8 && !any; ++c) any = v[((z + (c >> 2)) * H + y + ((c >> 1) & 1)) * W + x + (c & 1)] != 0.0f;
+                        if (any) {
+                            const size_t cell = (z * (H - 1) + y) * (W - 1) + x;
+                            bits[cell >> 5] |= 1u << (cell & 31);
+                        }
+                    }
+            HR_HIP(hipMalloc((void**)&m->occ_cells, bits.size() * sizeof(unsigned)));
+            HR_HIP(hipMemcpy(m->occ_cells, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
     }
     return HR_OK;
 }
@@ -1317,6 +1345,7 @@ void hr_model_destroy(hr_model* m)
     free_dev(m->head);
     free_dev(m->rows);
     free_dev(m->occ);
+    free_dev(reinterpret_cast<float*&>(m->occ_cells));
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); }

@@ -72,6 +72,8 @@ struct HrSampleArgs {
     // optional occupancy early-reject (hr_model_set_occupancy): AlphaGridMask.sample_alpha of the raw point (utils/tensorf_utils.py:
     // 459-484) must be > 0 for a sample to be gathered -- the test the reference carries at tensorf_no_sample.py:171-177
     const float* occ;       // (D, H, W) float volume or NULL
+    const unsigned* occ_cells;   // one bit per lattice CELL (W-1, H-1, D-1; x fastest): any of its 8 corners set -- for a point strictly
+                                 //   inside a cell of a 0/1 volume the trilinear sample is > 0 exactly when that bit is set; NULL: volume not binary
     int occ_w, occ_h, occ_d;
     float occ_lo[3], occ_inv[3];   // g = (p - lo) * inv - 1
     int dbg_mode;           // measurement builds only (-DHR_TUNING, HR_SAMPLE_DBG): 1 = skip the feature gather

@@ -27,13 +27,17 @@ def ms(n=30):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+out = {'workload': 'donerf_sphere 600^3, density carved to a sub-box, 800x800 frame'}
 plain = fn.model.render(rays)['rgb'].clone()
-t_plain = ms()
 net.updateAlphaMask((200, 200, 200))
-kept = float(net.alpha_volume.mean())
-fn.model.set_occupancy(True)
-masked = fn.model.render(rays)['rgb'].clone()
-t_mask = ms()
-print(json.dumps({'workload': 'donerf_sphere 600^3, density carved to a sub-box, 800x800 frame', 'mask_kept_fraction': round(kept, 4),
-                  'ms_per_frame_shipped': round(t_plain, 3), 'ms_per_frame_occupancy': round(t_mask, 3), 'speedup': round(t_plain / t_mask, 3),
-                  'linf_masked_vs_shipped': float((masked - plain).abs().max())}))
+out['mask_kept_fraction'] = round(float(net.alpha_volume.mean()), 4)
+for plan, fk in (('frame_kernel', True), ('two_kernels', False)):
+    fn.model.set_execution(frame_kernel=fk)
+    fn.model.set_occupancy(False)
+    t_plain = ms()
+    fn.model.set_occupancy(True)
+    masked = fn.model.render(rays)['rgb'].clone()
+    t_mask = ms()
+    out[plan] = {'ms_per_frame_shipped': round(t_plain, 3), 'ms_per_frame_occupancy': round(t_mask, 3), 'speedup': round(t_plain / t_mask, 3),
+                 'linf_masked_vs_shipped': float((masked - plain).abs().max())}
+print(json.dumps(out))
