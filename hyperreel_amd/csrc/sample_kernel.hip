@@ -90,17 +90,20 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
 #endif
     // few samples x many head columns can exceed the 64 KiB a kernel gets by default (e.g. 32 rays x 8 x 64 floats)
     const bool big_lds = lds > 64 * 1024;
-    // the shipped [8, 4, 4] decomposition with fp32 texels gets the class-specialised gather (sample_core.inc); ZP >= 8
+    // the shipped [8, 4, 4] / [8, 0, 0] decompositions with fp32 texels get the class-specialised gather (sample_core.inc); ZP >= 8
     // keeps a quad inside one ray, video nets additionally need two keyframes
-    const bool pc844 = hr_planes_are_844(args.planes, 0) && args.ca_total == 16 && args.rows_out == nullptr && (!cfg.video || cfg.num_keyframes >= 2);
+    const int pclass = (args.rows_out == nullptr && (!cfg.video || cfg.num_keyframes >= 2)) ? hr_plane_class(args.planes, 0, args.ca_total) : 0;
 #define HR_LAUNCH_SAMPLES(Z_) \
     do { \
         if (cfg.grid_dtype == HR_GRID_FP16) { \
             if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((hr_sample_kernel<Z_, true, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
-        } else if (pc844) { \
+        } else if (pclass == 1) { \
             if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 1>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+        } else if (pclass == 2) { \
+            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 2>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
         } else { \
             if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
