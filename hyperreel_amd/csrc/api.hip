@@ -65,6 +65,10 @@ struct hr_model {
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
     int n_out = 0;
+    void* wstream = nullptr;              // register-resident MLP kernel: the split weights in consumption order (mlp_reg_impl.inc)
+    uint2* chunks = nullptr;              //   {first KB, KBs} per chunk, device
+    int n_chunks = 0;                     //   0: configuration not covered, the LDS-activation kernel runs
+    int opt_mlp_kernel = 0;               // HR_OPT_MLP_KERNEL: 1 = the register-resident kernel (measurement builds with -DHR_WITH_REG_KERNEL; slower)
     // packed grids
     float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
     float* grid_b[3] = {};
@@ -461,6 +465,7 @@ int hr_model_finalize(hr_model* m)
     int live_cols[64];
     for (int i = 0, j = 0; i < P_user; ++i)
         if (m->col_map.col[i] >= 0) live_cols[j++] = i;
+    std::vector<uint16_t> stream;          // weights for the register-resident kernel, all layers
     for (int l = 0; l < c.mlp_layers; ++l) {
         const bool last = (l == c.mlp_layers - 1);
         const int N_user = layer_out(c, l), Kt = layer_in(c, l);
@@ -541,6 +546,42 @@ int hr_model_finalize(hr_model* m)
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
             HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             m->packed_bytes += (int64_t)pk.size() * sizeof(uint16_t);
+#ifdef HR_WITH_REG_KERNEL
+            // the same weights in the order the register-resident kernel consumes them (mlp_reg_impl.inc): per chunk
+            // [k-step][tile of the pair][hi 1 KB, lo 1 KB]; hidden k-steps with the contraction index permuted inside the
+            // 16-block so that an accumulator quad IS the next layer's operand: slot (h, j) <-> 16 s + 8 (j >> 2) + 4 h + (j & 3)
+            if (W == 256) {
+                const int KIN = m->k0p / 16;
+                const bool two_products = (c.mlp_precision == HR_MLP_F16X2);
+                auto put_tile = [&](int tile, bool hidden, int ks) {
+                    const size_t base = stream.size();
+                    stream.resize(base + (two_products ? 512 : 1024), 0);
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int hh = lane >> 5;
+                            const int kk = hidden ? (skip ? m->k0p : 0) + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * ks + 8 * hh + j;
+                            const float v = wk(32 * tile + (lane & 31), kk) * wmul;
+                            const uint16_t hi = half ? f16_rne(v) : bf16_rne(v);
+                            stream[base + lane * 8 + j] = hi;
+                            if (!two_products) stream[base + 512 + lane * 8 + j] = half ? f16_rne(v - f16_to_float(hi)) : bf16_rne(v - bf16_to_float(hi));
+                        }
+                };
+                if (first) {
+                    for (int q = 0; q < 2; ++q)
+                        for (int kt = 0; kt < KIN; ++kt)
+                            for (int j = 0; j < 4; ++j) put_tile(4 * q + j, false, kt);
+                } else {
+                    for (int t0 = 0; t0 < nt; t0 += 2) {
+                        const int ntp = (t0 + 1 < nt) ? 2 : 1;
+                        if (skip)
+                            for (int kt = 0; kt < KIN; ++kt)
+                                for (int j = 0; j < ntp; ++j) put_tile(t0 + j, false, kt);
+                        for (int ks = 0; ks < 16; ++ks)
+                            for (int j = 0; j < ntp; ++j) put_tile(t0 + j, true, ks);
+                    }
+                }
+            }
+#endif
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
@@ -550,6 +591,31 @@ int hr_model_finalize(hr_model* m)
         m->n_tiles[l] = nt;
         m->packed_bytes += (int64_t)nb * sizeof(float);
     }
+
+#ifdef HR_WITH_REG_KERNEL
+    free_dev(reinterpret_cast<float*&>(m->wstream));
+    free_dev(reinterpret_cast<float*&>(m->chunks));
+    m->n_chunks = 0;
+    if (!stream.empty()) {
+        unsigned table[2 * 256];
+        int nc = 0;
+        if (c.mlp_precision == HR_MLP_BF16X3) nc = hr_reg_chunks_bf16x3(c, m->k0p, m->n_tiles, table, 256);
+        else if (c.mlp_precision == HR_MLP_F16X3) nc = hr_reg_chunks_f16x3(c, m->k0p, m->n_tiles, table, 256);
+        else if (c.mlp_precision == HR_MLP_F16X2) nc = hr_reg_chunks_f16x2(c, m->k0p, m->n_tiles, table, 256);
+        size_t kb = 0;
+        for (int i = 0; i < nc; ++i) kb += table[2 * i + 1];
+        if (nc > 0 && kb * 1024 == stream.size() * sizeof(uint16_t)) {
+            HR_HIP(hipMalloc((void**)&m->wstream, stream.size() * sizeof(uint16_t)));
+            HR_HIP(hipMemcpy(m->wstream, stream.data(), stream.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HR_HIP(hipMalloc((void**)&m->chunks, nc * sizeof(uint2)));
+            HR_HIP(hipMemcpy(m->chunks, table, nc * sizeof(uint2), hipMemcpyHostToDevice));
+            m->n_chunks = nc;
+            m->packed_bytes += (int64_t)stream.size() * sizeof(uint16_t) + nc * sizeof(uint2);
+        } else if (nc > 0) {
+            return fail(HR_E_INVALID, "weight stream of %zu bytes does not match its chunk list (%zu KB)", stream.size() * sizeof(uint16_t), kb);
+        }
+    }
+#endif
 
     if (m->is_coarse) {      // coarse level of a cascade: no grids
         HR_HIP(hipDeviceSynchronize());
@@ -713,9 +779,18 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     return HR_OK;
 }
 
-static void launch_mlp(const hr_config& c, const HrMlpArgs& a, hipStream_t st)
+static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
+#ifdef HR_WITH_REG_KERNEL
+    if (m->opt_mlp_kernel && a.n_chunks > 0) {   // register-resident kernel (mlp_reg_impl.inc), measurement builds only
+        if (c.mlp_precision == HR_MLP_BF16X3) return hr_launch_mlp_reg_bf16x3(c, a, m->n_cus, st);
+        if (c.mlp_precision == HR_MLP_F16X3) return hr_launch_mlp_reg_f16x3(c, a, m->n_cus, st);
+        if (c.mlp_precision == HR_MLP_F16X2) return hr_launch_mlp_reg_f16x2(c, a, m->n_cus, st);
+    }
+#else
+    (void)m;
+#endif
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
@@ -738,6 +813,9 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.nq = (m->n_out + 3) / 4;
     a.k0p = m->k0p;
     a.trace = nullptr;
+    a.wstream = m->wstream;
+    a.chunks = m->chunks;
+    a.n_chunks = m->n_chunks;
 }
 
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
@@ -780,7 +858,7 @@ static void launch_cascade_front(hr_model* m, const float* rays, int64_t n, hipS
     hr_model* c0 = m->coarse;
     HrMlpArgs ma;
     fill_mlp_args(c0, ma, rays, n);
-    launch_mlp(c0->kcfg, ma, st);
+    launch_mlp(c0, c0->kcfg, ma, st);
     HrSampleArgs sa;
     fill_sample_args(c0, sa, rays, n, nullptr);
     sa.rows_out = m->rows;
@@ -792,7 +870,7 @@ static void launch_cascade_front(hr_model* m, const float* rays, int64_t n, hipS
     kc.ray_dim = m->cfg.casc_row_dim;            // the point MLP's "rays" are the rows
     HrMlpArgs mb;
     fill_mlp_args(m, mb, m->rows, n * m->cfg.casc_in_z);
-    launch_mlp(kc, mb, st);
+    launch_mlp(m, kc, mb, st);
 }
 
 static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st)
@@ -803,7 +881,7 @@ static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t 
     }
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays, n);
-    launch_mlp(m->kcfg, ma, st);
+    launch_mlp(m, m->kcfg, ma, st);
 }
 
 // The frame kernel (fused_impl.inc) for the whole ray list; false: the model does not fit it (nothing launched)
@@ -931,6 +1009,13 @@ int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
     } else if (option == HR_OPT_SAMPLE_WAVES) {
         if (value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 4 or 8");
         m->opt_sample_waves = value;
+    } else if (option == HR_OPT_MLP_KERNEL) {
+        if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_MLP_KERNEL takes 0 or 1");
+#ifndef HR_WITH_REG_KERNEL
+        if (value == 1) return fail(HR_E_INVALID, "the register-resident MLP kernel is an experiment that is not part of this build (tools/build_variant.py reg -DHR_WITH_REG_KERNEL)");
+#endif
+        m->opt_mlp_kernel = value;
+        if (m->coarse) m->coarse->opt_mlp_kernel = value;
     } else {
         return fail(HR_E_INVALID, "unknown or read-only option %d", option);
     }
@@ -942,7 +1027,11 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (!m || !value) return fail(HR_E_INVALID, "null argument");
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
-    else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
+    else if (option == HR_OPT_MLP_KERNEL) *value = m->opt_mlp_kernel;
+    else if (option == HR_OPT_MLP_KERNEL_ACTIVE) {
+        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
+        *value = (m->opt_mlp_kernel && m->n_chunks > 0) ? 1 : 0;
+    } else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
     } else return fail(HR_E_INVALID, "unknown option %d", option);
@@ -1312,7 +1401,7 @@ int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsig
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays_dev, n_rays);
     ma.trace = trace_dev;
-    launch_mlp(m->kcfg, ma, (hipStream_t)stream);
+    launch_mlp(m, m->kcfg, ma, (hipStream_t)stream);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }
@@ -1335,6 +1424,8 @@ void hr_model_destroy(hr_model* m)
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
         free_dev(m->bias[l]);
     }
+    free_dev(reinterpret_cast<float*&>(m->wstream));
+    free_dev(reinterpret_cast<float*&>(m->chunks));
     for (int j = 0; j < 3; ++j) {
         free_dev(m->grid_a[j]);
         free_dev(m->grid_b[j]);

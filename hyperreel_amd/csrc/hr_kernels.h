@@ -41,6 +41,9 @@ struct HrMlpArgs {
     int nq;                      // ceil(n_out / 4)
     int k0p;                     // mlp_in padded to a multiple of 16
     unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
+    const void* wstream;         // register-resident kernel (mlp_reg_impl.inc): all layers' split weights in consumption order
+    const uint2* chunks;         //   {first KB, KBs} of each chunk of one tile's pass over the stream
+    int n_chunks;                //   0: the configuration is not covered by that kernel
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -84,6 +87,14 @@ void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stre
 //   W[n = 32*nt + (lane & 31)][k = 16*kt + 8*(lane >> 5) + 0..7], part 0 = hi (bf16(w)), 1 = lo (bf16(w - hi))
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_mlp_f16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // same layouts, fp16 halves
+// register-resident form (mlp_reg_impl.inc): activations in registers, weights streamed through an LDS ring, persistent.
+// hr_reg_chunks_*: the chunk list of the weight stream ({first KB, KBs} pairs; 0 = configuration not covered).
+int hr_reg_chunks_bf16x3(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
+int hr_reg_chunks_f16x3(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
+int hr_reg_chunks_f16x2(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
+void hr_launch_mlp_reg_bf16x3(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
+void hr_launch_mlp_reg_f16x3(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
+void hr_launch_mlp_reg_f16x2(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
 void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 // fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.

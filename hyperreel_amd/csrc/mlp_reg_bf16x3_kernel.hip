@@ -1,0 +1,7 @@
+// bf16x3 instance of the register-resident MLP kernel (mlp_reg_impl.inc); element type and products as in mlp_bf16x3_kernel.hip.
+#define HR_SPLIT_E __bf16
+#define HR_SPLIT_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define HR_REG_KERNEL hr_mlp_reg_bf16x3_kernel
+#define HR_REG_CHUNKS hr_reg_chunks_bf16x3
+#define HR_REG_LAUNCH hr_launch_mlp_reg_bf16x3
+#include "mlp_reg_impl.inc"
