@@ -16,13 +16,274 @@
 #include "hr_kernels.h"
 #include "hr_mask.h"
 #include "hr_train.h"
+#include "sample_core.inc"      // the render kernels' lane-per-sample building blocks (sort, cooperative gather)
 
+// Phase A walks a ray serially and is bound by the latency of that walk (every sample's gather waits on its point), not by
+// issue slots: a batch of 16 384 rays in full wavefronts is ONE wavefront per CU with nothing to hide the latency behind.
+// HR_TRAIN_RPW rays per wavefront (the other lanes idle) gives every SIMD several wavefronts instead.
+#ifndef HR_TRAIN_RPW
+#define HR_TRAIN_RPW 16
+#endif
 template <int ZP>
 __global__ __launch_bounds__(64) void hr_train_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
-    const int64_t ray = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= HR_TRAIN_RPW) return;
+    const int64_t ray = (int64_t)blockIdx.x * HR_TRAIN_RPW + threadIdx.x;
     if (ray >= a.n_rays) return;
     hr_ray_train<ZP>(*cfgp, a, ray);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase A, one LANE per (ray, sample) -- the mapping of the render kernels (sample_core.inc): the ZP samples of a ray sit in
+// adjacent lanes, the sort is a bitonic network over lane exchanges, the transmittance an inclusive product scan, the colour a
+// butterfly sum, and the compositing backward one suffix-sum scan.  Same arithmetic as hr_ray_train (which stays: ZP > 64,
+// and the host build the CPU tests check against torch.autograd), with the forward's gather done by the render path's
+// cooperative gather (hr_gather_844 / hr_gather_plane_coop: same values).  32x the lanes of the one-thread-per-ray walk and
+// no per-lane scratch arrays.
+template <int ZP>
+__device__ __forceinline__ void hr_bitonic_sort_kv(float& v, int& id, int k)
+{
+    // ascending in (value, original index): a total order, so the result is the stable sort of hr_ray_train / sort_z
+#pragma unroll
+    for (int size = 2; size <= ZP; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j, 64);
+            const int oi = __shfl_xor(id, j, 64);
+            const bool up = ((k & size) == 0), lower = ((k & j) == 0);
+            const bool o_less = (o < v) || (o == v && oi < id);
+            if ((lower == up) ? o_less : !o_less) { v = o; id = oi; }
+        }
+    }
+}
+
+template <int ZP, int NB, int PC>
+__global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+{
+    static_assert(ZP <= 64, "a ray inside one wavefront");
+    const hr_config& c = *cfgp;
+    constexpr int RPB = 256 / ZP;
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrices
+    const int CA = a.ca_total, Z = c.z_channels, P = c.preds_per_z;
+    const int tid = threadIdx.x;
+    const int rib = tid / ZP, k = tid % ZP;
+    const int64_t ray0 = (int64_t)blockIdx.x * RPB;
+    const int64_t ray = ray0 + rib;
+    const bool ray_ok = ray < a.n_rays;
+    for (int e = tid; e < RPB * 3 * CA; e += 256) {
+        const int r = e / (3 * CA), i = e - r * 3 * CA;
+        float v = 0.0f;
+        if (ray0 + r < a.n_rays) {
+            float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+            if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+            v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
+        }
+        lds[e] = v;
+    }
+    __syncthreads();
+    const float* M = lds + rib * 3 * CA;
+    const bool lane_ok = ray_ok && k < Z;
+    const int64_t rr_ = ray_ok ? ray : 0;
+    const float* r = a.rays + rr_ * c.ray_dim;
+    const float* head = a.head + rr_ * (int64_t)Z * P;
+    const float* hk = head + (lane_ok ? k : 0) * P;
+    const float ro[3] = {r[0] - c.isect_origin[0], r[1] - c.isect_origin[1], r[2] - c.isect_origin[2]};
+    const float rd[3] = {r[3], r[4], r[5]};
+    const float t_ray = r[c.ray_dim - 1];
+
+    // ---- forward
+    float dist = __builtin_inff();
+    int src = k;
+    if (lane_ok) dist = hr_sample_distance(c, hk, k, ro, rd);
+    if (c.sort) hr_bitonic_sort_kv<ZP>(dist, src, k);
+    float oc[3] = {0.f, 0.f, 0.f};
+    if (c.contract_type != HR_CONTRACT_IDENTITY) hr_contract_point(c, ro[0], ro[1], ro[2], oc);
+    float base_t = 0.0f, time_off = 0.0f;
+    if (c.advect) { base_t = hr_base_time(c, t_ray); time_off = t_ray - base_t; }
+    float p[3] = {0.f, 0.f, 0.f};
+    float dist_c = 0.0f;
+    if (lane_ok) hr_sample_point(c, hk, dist, ro, rd, oc, time_off, p, &dist_c);
+    const float dist_next = __shfl_down(dist_c, 1, 64);
+    const float delta = (k == Z - 1) ? 1e10f : (dist_next - dist_c);
+    const bool valid = lane_ok && hr_sample_valid(c, p, dist_c);
+    float feat = 0.0f, pre0 = 0.0f, pre1 = 0.0f, pre2 = 0.0f;
+    {
+        float pn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) {
+            pn[0] = hr_normalize_coord(c, p[0], 0);
+            pn[1] = hr_normalize_coord(c, p[1], 1);
+            pn[2] = hr_normalize_coord(c, p[2], 2);
+            pn[3] = c.video ? hr_normalize_time(c, base_t) : 0.0f;
+        }
+        if constexpr (PC != 0) {
+            HrAxisTapsC at;
+            at.ax[0] = hr_make_tap_c(pn[0], c.grid[0]);
+            at.ax[1] = hr_make_tap_c(pn[1], c.grid[1]);
+            at.ax[2] = hr_make_tap_c(pn[2], c.grid[2]);
+            at.t = hr_make_tap_c(pn[3], (NB == 4 && c.video) ? c.num_keyframes : 2);
+            hr_gather_844<NB, PC>(a.planes, at, valid, M, feat, pre0, pre1, pre2);
+        } else {
+            HrAxisTaps at;
+            at.ax[0] = hr_make_tap(pn[0], c.grid[0]);
+            at.ax[1] = hr_make_tap(pn[1], c.grid[1]);
+            at.ax[2] = hr_make_tap(pn[2], c.grid[2]);
+            at.t = hr_make_tap(pn[3], c.video ? c.num_keyframes : 2);
+            hr_gather_plane_coop<0, 1, NB>(a.planes[0], at, valid, M, CA, feat, pre0, pre1, pre2);
+            hr_gather_plane_coop<1, 1, NB>(a.planes[1], at, valid, M, CA, feat, pre0, pre1, pre2);
+            hr_gather_plane_coop<2, 1, NB>(a.planes[2], at, valid, M, CA, feat, pre0, pre1, pre2);
+        }
+    }
+    const float sigma = valid ? hr_density(c, feat) : 0.0f;
+    const float alpha = lane_ok ? (1.0f - expf(-sigma * (delta * c.distance_scale))) : 0.0f;
+    const float inc = lane_ok ? ((1.0f - alpha) + 1e-10f) : 1.0f;
+    float prod = inc;                              // inclusive product over the ray's earlier lanes
+#pragma unroll
+    for (int d = 1; d < ZP; d <<= 1) {
+        const float o = __shfl_up(prod, d, 64);
+        if (k >= d) prod = prod * o;
+    }
+    float T = __shfl_up(prod, 1, 64);
+    if (k == 0) T = 1.0f;
+    const float wgt = lane_ok ? alpha * T : 0.0f;
+    const bool app = lane_ok && (wgt > c.weight_thresh);
+    const float pre[3] = {pre0, pre1, pre2};
+    float raw[3] = {0.f, 0.f, 0.f}, sc[3] = {1.f, 1.f, 1.f}, rr[3] = {0.f, 0.f, 0.f};
+    if (lane_ok) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (app) raw[i] = (c.shading == HR_SHADING_SH) ? fmaxf(pre[i] + 0.5f, 0.0f) : 1.0f / (1.0f + expf(-pre[i]));
+            rr[i] = raw[i];
+            if (c.f_color_scale.offset >= 0) {
+                sc[i] = hr_apply_act(c.f_color_scale.act, hk[c.f_color_scale.offset + i]) + 1.0f;
+                rr[i] = raw[i] * sc[i] + hr_apply_act(c.f_color_shift.act, hk[c.f_color_shift.offset + i]);
+            }
+        }
+    }
+    float c0 = wgt * rr[0], c1 = wgt * rr[1], c2 = wgt * rr[2], acc_w = wgt;
+#pragma unroll
+    for (int d = ZP >> 1; d > 0; d >>= 1) {        // every lane of the ray ends up with the ray's sums
+        c0 += __shfl_xor(c0, d, 64);
+        c1 += __shfl_xor(c1, d, 64);
+        c2 += __shfl_xor(c2, d, 64);
+        acc_w += __shfl_xor(acc_w, d, 64);
+    }
+    if (a.white_bg) { const float bg = 1.0f - acc_w; c0 += bg; c1 += bg; c2 += bg; }
+    const float cpre[3] = {c0, c1, c2};            // the composited colour before the per-ray scale / shift
+    float gscale[3] = {1.0f, 1.0f, 1.0f};
+    float tcol[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cam = 0;
+    if (c.f_color_scale_global.offset >= 0) {      // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gscale[i] = hr_apply_act(fs.act, head[fs.offset + i]) + 1.0f;
+        c0 = c0 * gscale[0] + hr_apply_act(fh.act, head[fh.offset + 0]);
+        c1 = c1 * gscale[1] + hr_apply_act(fh.act, head[fh.offset + 1]);
+        c2 = c2 * gscale[2] + hr_apply_act(fh.act, head[fh.offset + 2]);
+    } else if (a.color_table) {                    // transform_color_one (tensorf_utils.py:308-320, point.py:588-594)
+        cam = (int)rintf(r[c.ray_dim - 2]);
+        cam = cam < 0 ? 0 : (cam > c.color_table_views - 1 ? c.color_table_views - 1 : cam);
+        const float* e = a.color_table + 12 * cam;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tcol[i] = hr_apply_act(c.color_table_t_act, e[i]);
+        const float n0 = c0 + ((c0 * tcol[0] + c1 * tcol[1]) + c2 * tcol[2]);
+        const float n1 = c1 + ((c0 * tcol[3] + c1 * tcol[4]) + c2 * tcol[5]);
+        const float n2 = c2 + ((c0 * tcol[6] + c1 * tcol[7]) + c2 * tcol[8]);
+        c0 = n0 + hr_apply_act(c.color_table_s_act, e[9]);
+        c1 = n1 + hr_apply_act(c.color_table_s_act, e[10]);
+        c2 = n2 + hr_apply_act(c.color_table_s_act, e[11]);
+    }
+    if (a.rgb && ray_ok && k == 0) { a.rgb[ray * 3 + 0] = c0; a.rgb[ray * 3 + 1] = c1; a.rgb[ray * 3 + 2] = c2; }
+    if (!a.d_rgb) return;
+
+    // ---- backward of the compositing
+    float g[3] = {0.f, 0.f, 0.f};
+    if (ray_ok) { g[0] = a.d_rgb[ray * 3 + 0]; g[1] = a.d_rgb[ray * 3 + 1]; g[2] = a.d_rgb[ray * 3 + 2]; }
+    float* dhead = a.d_head + rr_ * (int64_t)Z * P;
+    float* dhk = dhead + (lane_ok ? k : 0) * P;
+    if (lane_ok)
+        for (int i = 0; i < P; ++i) dhk[i] = 0.0f;
+    if (c.f_color_scale_global.offset >= 0) {
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (lane_ok && k == 0) {               // sample 0's row is this lane's own
+                dhk[fs.offset + i] += g[i] * cpre[i] * hr_act_grad(fs.act, head[fs.offset + i]);
+                dhk[fh.offset + i] += g[i] * hr_act_grad(fh.act, head[fh.offset + i]);
+            }
+            g[i] = g[i] * gscale[i];               // everything below sees the gradient of the un-scaled colour
+        }
+    } else if (a.color_table) {
+        const float* e = a.color_table + 12 * cam;
+        float* de = a.d_color_table + 12 * cam;
+        float gn[3] = {g[0], g[1], g[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (ray_ok && k == 0) HR_ATOMIC_ADD(de + 9 + i, g[i] * hr_act_grad(c.color_table_s_act, e[9 + i]));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (ray_ok && k == 0) HR_ATOMIC_ADD(de + 3 * i + j, g[i] * cpre[j] * hr_act_grad(c.color_table_t_act, e[3 * i + j]));
+                gn[j] += g[i] * tcol[3 * i + j];
+            }
+        }
+        g[0] = gn[0]; g[1] = gn[1]; g[2] = gn[2];
+    }
+    const float gsum = a.white_bg ? (g[0] + g[1] + g[2]) : 0.0f;
+    float dpre[3] = {0.f, 0.f, 0.f};
+    if (lane_ok) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float dr = wgt * g[i];
+            if (c.f_color_scale.offset >= 0) {
+                const float hs = hk[c.f_color_scale.offset + i], hh = hk[c.f_color_shift.offset + i];
+                dhk[c.f_color_scale.offset + i] += dr * raw[i] * hr_act_grad(c.f_color_scale.act, hs);
+                dhk[c.f_color_shift.offset + i] += dr * hr_act_grad(c.f_color_shift.act, hh);
+            }
+            const float draw = dr * sc[i];
+            if (!app) dpre[i] = 0.0f;
+            else if (c.shading == HR_SHADING_SH) dpre[i] = (pre[i] + 0.5f > 0.0f) ? draw : 0.0f;
+            else dpre[i] = draw * raw[i] * (1.0f - raw[i]);
+        }
+    }
+    const float dw = lane_ok ? ((g[0] * rr[0] + g[1] * rr[1] + g[2] * rr[2]) - gsum) : 0.0f;
+    float suf = dw * wgt;                          // inclusive suffix sum of dw_j * w_j over the ray's later lanes
+#pragma unroll
+    for (int d = 1; d < ZP; d <<= 1) {
+        const float o = __shfl_down(suf, d, 64);
+        if (k + d < ZP) suf += o;
+    }
+    const float S = suf - dw * wgt;                // sum over j > k
+    const float dalpha = dw * T - S / inc;
+    const float e1 = 1.0f - alpha;
+    const float dsigma = dalpha * e1 * (delta * c.distance_scale);
+    const float dfeat = valid ? dsigma * hr_density_grad(c, feat) : 0.0f;
+    const float ddelta = (lane_ok && k < Z - 1) ? dalpha * e1 * sigma * c.distance_scale : 0.0f;
+    float ddelta_prev = __shfl_up(ddelta, 1, 64);
+    if (k == 0) ddelta_prev = 0.0f;
+    if (lane_ok) {                                 // hand the per-sample upstream gradients to phases B and C
+        const int64_t NS = a.n_rays * Z;
+        const int64_t s = ray * Z + k;
+        a.tape.ds[s] = dist;
+        a.tape.src[s] = src;
+        a.tape.dfeat[s] = dfeat;
+        a.tape.dpre[s] = dpre[0]; a.tape.dpre[NS + s] = dpre[1]; a.tape.dpre[2 * NS + s] = dpre[2];
+        a.tape.ddc[s] = ddelta_prev - ddelta;
+    }
+}
+
+template <int ZP>
+static void hr_launch_train_lanes(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
+{
+    constexpr int RPB = 256 / ZP;
+    const unsigned blocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
+    const size_t lds = sizeof(float) * RPB * 3 * args.ca_total;
+    const int pc = hr_plane_class(args.planes, 0, args.ca_total);
+    if (pc == 1 && !cfg.video) hipLaunchKernelGGL((hr_train_lanes_kernel<ZP, 2, 1>), dim3(blocks), dim3(256), lds, stream, args.cfg_dev, args);
+    else if (pc == 1) hipLaunchKernelGGL((hr_train_lanes_kernel<ZP, 4, 1>), dim3(blocks), dim3(256), lds, stream, args.cfg_dev, args);
+    else if (pc == 2) hipLaunchKernelGGL((hr_train_lanes_kernel<ZP, 4, 2>), dim3(blocks), dim3(256), lds, stream, args.cfg_dev, args);
+    else hipLaunchKernelGGL((hr_train_lanes_kernel<ZP, 4, 0>), dim3(blocks), dim3(256), lds, stream, args.cfg_dev, args);
 }
 
 // Phase B.  HR_TRAIN_LPS = 16 adjacent lanes per sample, one texel channel each (a plane pair has 8 or 16 channels per
@@ -30,7 +291,7 @@ __global__ __launch_bounds__(64) void hr_train_kernel(const hr_config* __restric
 // and walks the samples of RPB whole rays (1 ray when it has 16 samples or more).
 #define HR_TRAIN_LPS 16
 template <int ZP>
-__global__ __launch_bounds__(256) void hr_train_gather_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+__global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 256 / HR_TRAIN_LPS;
@@ -82,12 +343,12 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t 
     if (args.n_rays <= 0) return;
     int ZP = 8;
     while (ZP < cfg.z_channels) ZP <<= 1;
-    const unsigned blocks = (unsigned)((args.n_rays + 63) / 64);
-    switch (ZP) {
-        case 8: hipLaunchKernelGGL(hr_train_kernel<8>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
-        case 16: hipLaunchKernelGGL(hr_train_kernel<16>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
-        case 32: hipLaunchKernelGGL(hr_train_kernel<32>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
-        case 64: hipLaunchKernelGGL(hr_train_kernel<64>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
+    const unsigned blocks = (unsigned)((args.n_rays + HR_TRAIN_RPW - 1) / HR_TRAIN_RPW);
+    switch (ZP) {                                  // phase A: a lane per sample where a ray fits one wavefront
+        case 8: hr_launch_train_lanes<8>(cfg, args, stream); break;
+        case 16: hr_launch_train_lanes<16>(cfg, args, stream); break;
+        case 32: hr_launch_train_lanes<32>(cfg, args, stream); break;
+        case 64: hr_launch_train_lanes<64>(cfg, args, stream); break;
         case 128: hipLaunchKernelGGL(hr_train_kernel<128>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
         case 256: hipLaunchKernelGGL(hr_train_kernel<256>, dim3(blocks), dim3(64), 0, stream, args.cfg_dev, args); break;
         default: break;

@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 from hyperreel_amd import config as C          # noqa: E402
 from hyperreel_amd import scenes               # noqa: E402
+from hyperreel_amd import lib as _hrlib        # noqa: E402
+if os.environ.get('HR_LIB'):
+    _hrlib.LIB_PATH = os.path.abspath(os.environ['HR_LIB'])     # a measurement variant (tools/build_variant.py)
 
 
 def timed(fn, reps, warm=3):
