@@ -27,7 +27,9 @@
 
 #if defined(__HIPCC__)
 #define HR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
-#define HR_ATOMIC_ADD_RAY(p, v) atomicAdd((p), (v))      // per-ray accumulators in LDS, shared by the ray's sample threads
+// per-ray / per-workgroup accumulators in LDS, shared by the sample threads: the pointer IS an LDS address, say so (a pointer
+// picked from a runtime-indexed array otherwise becomes a flat atomic)
+#define HR_ATOMIC_ADD_RAY(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // sum of v over the `lanes` adjacent lanes that work on one sample (all of them active), returned to every one of them
 __device__ __forceinline__ float hr_lane_sum(float v, int lanes)
 {
@@ -544,7 +546,7 @@ HR_FN void hr_train_gather(const HrTrainArgs& a, const hr_axis_tap_g* ax, const 
 // (tools/atomic_ubench.hip: 331 vs 19.5 G atomics/s).
 HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrainTaps& t, const hr_axis_tap_g& gx, const hr_axis_tap_g& gy,
                                        const hr_axis_tap_g& gv, const hr_axis_tap_g& at, int ch, const float* M, float* dM, int CA,
-                                       float dfeat, const float* dpre, float* d3)
+                                       float dfeat, const float* dpre, float* d3, float* line_acc = nullptr)
 {
     const HrGridPlane& g = a.planes[j];
     const float* A = reinterpret_cast<const float*>(g.a);
@@ -571,8 +573,13 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
     float* GB = a.g_b[j];
     for (int i = 0; i < 4; ++i)
         if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
-    for (int i = 0; i < t.nb; ++i)
-        if (t.wb[i] != 0.0f) HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+    // the line of a static net has a few hundred texels that EVERY sample of the batch hits: on the device the caller can
+    // hand a workgroup-private accumulator (LDS) that it adds to the global one once at the end
+    for (int i = 0; i < t.nb; ++i) {
+        if (t.wb[i] == 0.0f) continue;
+        if (line_acc) HR_ATOMIC_ADD_RAY(line_acc + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+        else HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+    }
     // coordinates: d(weights)/d ix = (s0, s1) per axis
     d3[0] += dpa * ((a00 * gx.s0 + a01 * gx.s1) * gy.t.w0 + (a10 * gx.s0 + a11 * gx.s1) * gy.t.w1);
     d3[1] += dpa * ((a00 * gx.t.w0 + a01 * gx.t.w1) * gy.s0 + (a10 * gx.t.w0 + a11 * gx.t.w1) * gy.s1);
@@ -584,7 +591,7 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
 // dL/d normalised coordinates in dpn[3] (the host walks all channels with stride 1; on the device the 16 lanes of a
 // sample take stride 16 and add their shares up).
 HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, float* dM, int CA,
-                               float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1)
+                               float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1, float* const* line_acc = nullptr)
 {
     dpn[0] = 0.0f; dpn[1] = 0.0f; dpn[2] = 0.0f;
     for (int j = 0; j < 3; ++j) {
@@ -596,7 +603,8 @@ HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, co
         const hr_axis_tap_g& gv = ax[hr_plane_v(j)];
         const HrTrainTaps t = hr_train_taps(g, gx.t, gy.t, gv.t, at.t);
         float d3[3] = {0.0f, 0.0f, 0.0f};
-        for (int ch = ch0; ch < nch; ch += stride) hr_train_gather_bwd_channel(a, j, t, gx, gy, gv, at, ch, M, dM, CA, dfeat, dpre, d3);
+        for (int ch = ch0; ch < nch; ch += stride)
+            hr_train_gather_bwd_channel(a, j, t, gx, gy, gv, at, ch, M, dM, CA, dfeat, dpre, d3, line_acc ? line_acc[j] : nullptr);
         dpn[hr_plane_a0(j)] += d3[0] * gx.mult;
         dpn[hr_plane_a1(j)] += d3[1] * gy.mult;
         dpn[hr_plane_v(j)] += d3[2] * gv.mult;
@@ -662,7 +670,7 @@ HR_FN HrTrainRay hr_train_ray(const hr_config& c, const float* r)
 // threads of a sample call it together with their `lane`, split the channels between them and combine their shares of
 // the point gradient with HR_LANE_SUM.
 HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane = 0,
-                               int lanes = 1)
+                               int lanes = 1, float* const* line_acc = nullptr)
 {
     const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total;
     const int64_t s = ray * Z + k, NS = a.n_rays * Z;
@@ -677,7 +685,7 @@ HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t
         hr_axis_tap_g ax[3];
         for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
         float dpn[3];
-        hr_train_gather_bwd(a, ax, q.tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes);
+        hr_train_gather_bwd(a, ax, q.tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, line_acc);
         for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], lanes) * c.inv_size[i];
     }
     if (lane != 0) return;

@@ -329,6 +329,108 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
     }
 }
 
+// Phase B for static nets: the same walk by a PERSISTENT workgroup of 1024 threads (one per CU) that keeps the gradients of
+// the three lines in LDS.  A line has a few hundred texels and every sample of the batch adds to two of them: as global
+// atomics those adds were 0.77 of the phase's 1.46 ms on the 600^3 DoNeRF scene (the same number of plane atomics, spread
+// over 360 000 texels: 0.28 ms).  In LDS they are ds_add_f32; each workgroup adds its lines to the global ones once.
+template <int ZP>
+__global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+{
+    const hr_config& c = *cfgp;
+    constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
+    constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the three lines
+    const int CA = a.ca_total, Z = c.z_channels;
+    float* line_acc[3];
+    int line_n[3];
+    {
+        float* p = lds + 2 * RPB * 3 * CA;
+        for (int j = 0; j < 3; ++j) { line_acc[j] = p; line_n[j] = a.planes[j].bh * a.planes[j].tex; p += line_n[j]; }
+        for (float* q = lds + 2 * RPB * 3 * CA + threadIdx.x; q < p; q += 1024) *q = 0.0f;
+    }
+    const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
+    for (int64_t ray0 = (int64_t)blockIdx.x * RPB; ray0 < a.n_rays; ray0 += (int64_t)gridDim.x * RPB) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
+            const int r = e / (3 * CA), i = e - r * 3 * CA;
+            float v = 0.0f;
+            if (ray0 + r < a.n_rays) {
+                float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+                if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+                v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
+            }
+            lds[e] = v;
+            lds[RPB * 3 * CA + e] = 0.0f;
+        }
+        __syncthreads();
+        for (int si = grp; si < RPB * Z; si += GROUPS) {
+            const int r = si / Z, k = si - r * Z;
+            if (ray0 + r >= a.n_rays) continue;
+            hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
+            const int r = e / (3 * CA), i = e - r * 3 * CA;
+            if (ray0 + r >= a.n_rays) continue;
+            float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+            if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+            hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e]);
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < 3; ++j)
+        for (int i = threadIdx.x; i < line_n[j]; i += 1024) {
+            const float v = line_acc[j][i];
+            if (v != 0.0f) HR_ATOMIC_ADD(a.g_b[j] + i, v);
+        }
+}
+
+// bytes of LDS the lines of a static net need, 0 when the kernel above does not apply (a keyframe net's time planes)
+static size_t hr_train_line_bytes(const HrTrainArgs& args)
+{
+    size_t n = 0;
+    for (int j = 0; j < 3; ++j) {
+        const HrGridPlane& g = args.planes[j];
+        if (g.cd4 + g.ca4 == 0) continue;
+        if (g.bw != 1) return 0;
+        n += sizeof(float) * (size_t)g.bh * g.tex;
+    }
+    return n;
+}
+
+static int hr_train_n_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <int ZP>
+static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stream)
+{
+    constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
+    constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    const size_t line_bytes = hr_train_line_bytes(args);
+    const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total + line_bytes;
+    if (line_bytes == 0 || lds > 150 * 1024) return false;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        allowed = lds;
+    }
+    const int64_t iters = (args.n_rays + RPB - 1) / RPB;
+    const int cus = hr_train_n_cus();
+    hipLaunchKernelGGL(hr_train_gather_bwd_lines_kernel<ZP>, dim3((unsigned)(iters < cus ? iters : cus)), dim3(1024), lds, stream, args.cfg_dev, args);
+    return true;
+}
+
 // Phase C
 __global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
@@ -354,11 +456,21 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t 
         default: break;
     }
     if (!args.d_rgb) return;
+    bool done = false;
+    switch (ZP) {
+        case 8: done = hr_launch_gather_bwd_lines<8>(args, stream); break;
+        case 16: done = hr_launch_gather_bwd_lines<16>(args, stream); break;
+        case 32: done = hr_launch_gather_bwd_lines<32>(args, stream); break;
+        case 64: done = hr_launch_gather_bwd_lines<64>(args, stream); break;
+        case 128: done = hr_launch_gather_bwd_lines<128>(args, stream); break;
+        case 256: done = hr_launch_gather_bwd_lines<256>(args, stream); break;
+        default: break;
+    }
     const int GROUPS = 256 / HR_TRAIN_LPS;
     const int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
     const unsigned bblocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
     const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total;
-    switch (ZP) {
+    if (!done) switch (ZP) {
         case 8: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<8>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
         case 16: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<16>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
         case 32: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<32>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
