@@ -35,92 +35,139 @@ struct HrGemmArgs {
     int act;                                 // forward epilogue: LeakyReLU with `slope` when 1
     float* rowsum;                           // wgrad: partial row sums of A, (splits, M) or NULL
     int M, N, K;
-    int k_per_split;                         // multiple of 16; gridDim.z splits
+    int k_per_split;                         // multiple of HR_GK; gridDim.z splits
 };
 
 constexpr int HR_GT = 64;                    // tile edge
-constexpr int HR_GS = 24;                    // bf16 elements per LDS row (16 + 8: rows of a ds_read_b128 group on distinct banks)
+constexpr int HR_GK = 32;                    // contraction elements staged per step (two MFMA k-steps)
+constexpr int HR_GS = HR_GK + 8;             // bf16 elements per LDS row (+ 8: the rows of a ds_read_b128 group fall on distinct banks)
+
+// eight consecutive elements along the contiguous dimension of an operand: two 16-byte loads when the run is whole and
+// aligned, element loads (zero beyond the edge) otherwise
+__device__ __forceinline__ void hr_gemm_load8(const float* p, int valid, bool vec, float (&v)[8])
+{
+    if (vec && valid >= 8) {
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (e < valid) ? p[e] : 0.0f;
+    }
+}
 
 // A_MC: A is contiguous along m (else along k).  B_NC: B is contiguous along n (else along k).
 // SIX: the six-product form (operands split three ways).
+// Per step a workgroup stages a 64 x 32 slice of A and of B: a thread owns 8 consecutive elements of each along the
+// operand's contiguous dimension, loads the NEXT step's elements before the MFMAs of the current one (the global latency
+// runs under them), splits them into bf16 parts and stores them into the other of two LDS buffers: one barrier per step.
 template <bool A_MC, bool B_NC, bool SIX>
 __global__ __launch_bounds__(256) void hr_gemm_bf16x3_kernel(const HrGemmArgs a)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Ah[HR_GT * HR_GS], Al[HR_GT * HR_GS], Bh[HR_GT * HR_GS], Bl[HR_GT * HR_GS];
-    __shared__ __attribute__((aligned(16))) __bf16 Am[SIX ? HR_GT * HR_GS : 8], Bm[SIX ? HR_GT * HR_GS : 8];     // middle parts
-    __shared__ float rs[16 * HR_GT];                      // wgrad: per-k-thread partial row sums of A, added in a fixed order
+    constexpr int PARTS = SIX ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][PARTS][HR_GT * HR_GS], Bs[2][PARTS][HR_GT * HR_GS];
+    __shared__ float rs[A_MC ? HR_GK * HR_GT : 1];       // wgrad: per-thread partial row sums of A, added in a fixed order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * HR_GT, n0 = blockIdx.y * HR_GT;
     const int kb = blockIdx.z * a.k_per_split;
     const int ke = min(a.K, kb + a.k_per_split);
     const bool do_rowsum = (a.rowsum != nullptr) && (blockIdx.y == 0);
-    float racc[4] = {0.0f, 0.0f, 0.0f, 0.0f};            // this thread's share of the row sums (its 4 rows are fixed: A_MC)
+    float racc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // this thread's share of the row sums (its 8 rows are fixed: A_MC)
     hr_acc16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    // staging: 256 threads x 4 elements = a 64x16 slice.  The 4 elements of a thread run along the contiguous dimension.
-    //   A_MC: thread -> k = tid / 16, m = 4 * (tid % 16) + e       else: m = tid / 4, k = 4 * (tid % 4) + e
+    // staging roles.  contiguous along k: row = tid / 4, k = 8 * (tid % 4) ..;  contiguous along m (n): k = tid / 8, row = 8 * (tid % 8) ..
+    const int a_row = A_MC ? 8 * (tid & 7) : (tid >> 2), a_k = A_MC ? (tid >> 3) : 8 * (tid & 3);
+    const int b_row = B_NC ? 8 * (tid & 7) : (tid >> 2), b_k = B_NC ? (tid >> 3) : 8 * (tid & 3);
+    const bool vecA = (((A_MC ? a.sak : a.sam) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool vecM = a.mask && (((A_MC ? a.smk : a.smm) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0);
+    const bool vecB = (((B_NC ? a.sbk : a.sbn) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
-    for (int k0 = kb; k0 < ke; k0 += 16) {
-        float av[4], bv[4];
-        int am[4], ak[4], bn[4], bk[4];
+
+    float av[8], bv[8];
+    auto fetch = [&](int k0) {
+        // A (and its LeakyReLU mask)
+        {
+            const int gm = m0 + a_row, gk = k0 + a_k;
+            const int valid = A_MC ? ((gk < ke) ? min(8, a.M - gm) : 0) : ((gm < a.M) ? min(8, ke - gk) : 0);
+            const int64_t off = A_MC ? ((int64_t)gk * a.sak + gm) : ((int64_t)gm * a.sam + gk);
+            hr_gemm_load8(a.A + (valid > 0 ? off : 0), valid, vecA && ((off & 3) == 0), av);
+            if (a.mask) {
+                float mv[8];
+                const int64_t moff = A_MC ? ((int64_t)gk * a.smk + gm) : ((int64_t)gm * a.smm + gk);
+                hr_gemm_load8(a.mask + (valid > 0 ? moff : 0), valid, vecM && ((moff & 3) == 0), mv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (A_MC) { ak[e] = tid >> 4; am[e] = 4 * (tid & 15) + e; } else { am[e] = tid >> 2; ak[e] = 4 * (tid & 3) + e; }
-            if (B_NC) { bk[e] = tid >> 4; bn[e] = 4 * (tid & 15) + e; } else { bn[e] = tid >> 2; bk[e] = 4 * (tid & 3) + e; }
-            const int gm = m0 + am[e], gka = k0 + ak[e];
-            float v = 0.0f;
-            if (gm < a.M && gka < ke) {
-                v = a.A[(int64_t)gm * a.sam + (int64_t)gka * a.sak];
-                if (a.mask) v = (a.mask[(int64_t)gm * a.smm + (int64_t)gka * a.smk] > 0.0f) ? v : v * a.slope;
+                for (int e = 0; e < 8; ++e) av[e] = (mv[e] > 0.0f) ? av[e] : av[e] * a.slope;
             }
-            av[e] = v;
-            const int gn = n0 + bn[e], gkb = k0 + bk[e];
-            bv[e] = (gn < a.N && gkb < ke) ? a.B[(int64_t)gkb * a.sbk + (int64_t)gn * a.sbn] : 0.0f;
         }
-        __syncthreads();                                   // the previous step's MFMAs have read the LDS tiles
+        {
+            const int gn = n0 + b_row, gk = k0 + b_k;
+            const int valid = B_NC ? ((gk < ke) ? min(8, a.N - gn) : 0) : ((gn < a.N) ? min(8, ke - gk) : 0);
+            const int64_t off = B_NC ? ((int64_t)gk * a.sbk + gn) : ((int64_t)gn * a.sbn + gk);
+            hr_gemm_load8(a.B + (valid > 0 ? off : 0), valid, vecB && ((off & 3) == 0), bv);
+        }
+    };
+    auto split_store = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
+            const int ai = A_MC ? ((a_row + e) * HR_GS + a_k) : (a_row * HR_GS + a_k + e);
+            const int bi = B_NC ? ((b_row + e) * HR_GS + b_k) : (b_row * HR_GS + b_k + e);
             const __bf16 ah = (__bf16)av[e], bh = (__bf16)bv[e];
-            Ah[am[e] * HR_GS + ak[e]] = ah;
-            Bh[bn[e] * HR_GS + bk[e]] = bh;
+            As[buf][0][ai] = ah;
+            Bs[buf][0][bi] = bh;
             const float ar = av[e] - (float)ah, br = bv[e] - (float)bh;      // exact remainders
             if constexpr (SIX) {
                 const __bf16 amid = (__bf16)ar, bmid = (__bf16)br;
-                Am[am[e] * HR_GS + ak[e]] = amid;
-                Bm[bn[e] * HR_GS + bk[e]] = bmid;
-                Al[am[e] * HR_GS + ak[e]] = (__bf16)(ar - (float)amid);
-                Bl[bn[e] * HR_GS + bk[e]] = (__bf16)(br - (float)bmid);
+                As[buf][1][ai] = amid;
+                Bs[buf][1][bi] = bmid;
+                As[buf][2][ai] = (__bf16)(ar - (float)amid);
+                Bs[buf][2][bi] = (__bf16)(br - (float)bmid);
             } else {
-                Al[am[e] * HR_GS + ak[e]] = (__bf16)ar;
-                Bl[bn[e] * HR_GS + bk[e]] = (__bf16)br;
+                As[buf][1][ai] = (__bf16)ar;
+                Bs[buf][1][bi] = (__bf16)br;
             }
         }
         if (A_MC && do_rowsum) {                           // db: row sums of the (masked) A slice, in fp32
 #pragma unroll
-            for (int e = 0; e < 4; ++e) racc[e] += av[e];
+            for (int e = 0; e < 8; ++e) racc[e] += av[e];
         }
-        __syncthreads();
+    };
+
+    if (kb < ke) {
+        fetch(kb);
+        split_store(0);
+    }
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += HR_GK) {
+        const bool more = k0 + HR_GK < ke;
+        if (more) fetch(k0 + HR_GK);                       // in flight under this step's MFMAs
+        __syncthreads();                                   // buffer `buf` is complete; the other one is no longer read
         // operands: lane l holds 8 consecutive k (k = 8 * (l >> 5) ..) of row / column (l & 31)
-        const int ro = (lane & 31) * HR_GS + 8 * (lane >> 5);
-        const hr_bf8 a_h = *reinterpret_cast<const hr_bf8*>(Ah + wm * HR_GS + ro);
-        const hr_bf8 a_l = *reinterpret_cast<const hr_bf8*>(Al + wm * HR_GS + ro);
-        const hr_bf8 b_h = *reinterpret_cast<const hr_bf8*>(Bh + wn * HR_GS + ro);
-        const hr_bf8 b_l = *reinterpret_cast<const hr_bf8*>(Bl + wn * HR_GS + ro);
-        if constexpr (SIX) {                               // smallest terms first
-            const hr_bf8 a_m = *reinterpret_cast<const hr_bf8*>(Am + wm * HR_GS + ro);
-            const hr_bf8 b_m = *reinterpret_cast<const hr_bf8*>(Bm + wn * HR_GS + ro);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_m, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_h, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_m, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc, 0, 0, 0);
-        } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < HR_GK; kk += 16) {
+            const int ro = (lane & 31) * HR_GS + kk + 8 * (lane >> 5);
+            const hr_bf8 a_h = *reinterpret_cast<const hr_bf8*>(&As[buf][0][wm * HR_GS + ro]);
+            const hr_bf8 b_h = *reinterpret_cast<const hr_bf8*>(&Bs[buf][0][wn * HR_GS + ro]);
+            if constexpr (SIX) {                           // smallest terms first
+                const hr_bf8 a_m = *reinterpret_cast<const hr_bf8*>(&As[buf][1][wm * HR_GS + ro]);
+                const hr_bf8 b_m = *reinterpret_cast<const hr_bf8*>(&Bs[buf][1][wn * HR_GS + ro]);
+                const hr_bf8 a_l = *reinterpret_cast<const hr_bf8*>(&As[buf][2][wm * HR_GS + ro]);
+                const hr_bf8 b_l = *reinterpret_cast<const hr_bf8*>(&Bs[buf][2][wn * HR_GS + ro]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_m, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_m, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc, 0, 0, 0);
+            } else {
+                const hr_bf8 a_l = *reinterpret_cast<const hr_bf8*>(&As[buf][1][wm * HR_GS + ro]);
+                const hr_bf8 b_l = *reinterpret_cast<const hr_bf8*>(&Bs[buf][1][wn * HR_GS + ro]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc, 0, 0, 0);
+            }
         }
+        if (more) split_store(buf ^ 1);
+        buf ^= 1;
     }
     // accumulator layout of the 32x32 tile: register r of lane l is D[8 * (r >> 2) + 4 * (l >> 5) + (r & 3)][l & 31]
     float* Cz = a.C + (int64_t)blockIdx.z * a.M * a.ldc;
@@ -135,13 +182,14 @@ __global__ __launch_bounds__(256) void hr_gemm_bf16x3_kernel(const HrGemmArgs a)
             Cz[(int64_t)gm * a.ldc + gn] = v;
         }
     }
-    if (A_MC && do_rowsum) {
+    if (A_MC && do_rowsum) {                               // 32 k-threads per row, thread tid holds rows 8 * (tid & 7) .. + 7
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rs[(tid >> 4) * HR_GT + 4 * (tid & 15) + e] = racc[e];
+        for (int e = 0; e < 8; ++e) rs[(tid >> 3) * HR_GT + 8 * (tid & 7) + e] = racc[e];
         __syncthreads();
         if (tid < HR_GT && m0 + tid < a.M) {
             float t = 0.0f;
-            for (int i = 0; i < 16; ++i) t += rs[i * HR_GT + tid];
+            for (int i = 0; i < HR_GK; ++i) t += rs[i * HR_GT + tid];
             a.rowsum[(int64_t)blockIdx.z * a.M + m0 + tid] = t;
         }
     }
@@ -175,7 +223,7 @@ void hr_launch_linear_forward(const float* x, int64_t ldx, int64_t rows, int in,
     a.C = y; a.ldc = ldy;
     a.bias = b; a.act = slope >= 0.0f ? 1 : 0;
     a.M = (int)rows; a.N = out; a.K = in;
-    a.k_per_split = (in + 15) & ~15;
+    a.k_per_split = (in + HR_GK - 1) & ~(HR_GK - 1);
     dim3 grid((unsigned)((rows + HR_GT - 1) / HR_GT), (unsigned)((out + HR_GT - 1) / HR_GT), 1);
     hipLaunchKernelGGL((hr_gemm_bf16x3_kernel<false, false, true>), grid, dim3(256), 0, stream, a);
 }
@@ -194,7 +242,7 @@ void hr_launch_linear_backward(const float* x, int64_t ldx, const float* w, cons
         a.B = w; a.sbk = in; a.sbn = 1;
         a.C = dx; a.ldc = ld_dx;
         a.M = (int)rows; a.N = in; a.K = out;
-        a.k_per_split = (out + 15) & ~15;
+        a.k_per_split = (out + HR_GK - 1) & ~(HR_GK - 1);
         dim3 grid((unsigned)((rows + HR_GT - 1) / HR_GT), (unsigned)((in + HR_GT - 1) / HR_GT), 1);
         hipLaunchKernelGGL((hr_gemm_bf16x3_kernel<false, true, false>), grid, dim3(256), 0, stream, a);
     }
@@ -208,7 +256,7 @@ void hr_launch_linear_backward(const float* x, int64_t ldx, const float* w, cons
         a.C = workspace; a.ldc = in;
         a.rowsum = workspace + (size_t)splits * out * in;
         a.M = out; a.N = in; a.K = (int)rows;
-        a.k_per_split = (int)((((rows + splits - 1) / splits) + 15) & ~(int64_t)15);
+        a.k_per_split = (int)((((rows + splits - 1) / splits) + HR_GK - 1) & ~(int64_t)(HR_GK - 1));
         dim3 grid((unsigned)((out + HR_GT - 1) / HR_GT), (unsigned)((in + HR_GT - 1) / HR_GT), (unsigned)splits);
         hipLaunchKernelGGL((hr_gemm_bf16x3_kernel<true, true, false>), grid, dim3(256), 0, stream, a);
         const int64_t nw = (int64_t)out * in;
