@@ -33,6 +33,12 @@
 // sum of v over the `lanes` adjacent lanes that work on one sample (all of them active), returned to every one of them
 __device__ __forceinline__ float hr_lane_sum(float v, int lanes)
 {
+    if (lanes == 16) {        // one DPP row: rotate-and-add, every lane ends with the row's sum (no trip through the LDS crossbar)
+#define HR_ROR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, true))
+        HR_ROR_ADD(8); HR_ROR_ADD(4); HR_ROR_ADD(2); HR_ROR_ADD(1);
+#undef HR_ROR_ADD
+        return v;
+    }
     for (int d = lanes >> 1; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }

@@ -333,12 +333,13 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
 // the three lines in LDS.  A line has a few hundred texels and every sample of the batch adds to two of them: as global
 // atomics those adds were 0.77 of the phase's 1.46 ms on the 600^3 DoNeRF scene (the same number of plane atomics, spread
 // over 360 000 texels: 0.28 ms).  In LDS they are ds_add_f32; each workgroup adds its lines to the global ones once.
+#define HR_TRAIN_LINES_RPB(ZP) (((1024 / HR_TRAIN_LPS) + (ZP) - 1) / (ZP))
 template <int ZP>
 __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
-    constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);    // rays per trip: one sample per 16-lane group between the barriers (four were slower: 1.43 vs 1.32 ms)
     extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the three lines
     const int CA = a.ca_total, Z = c.z_channels;
     float* line_acc[3];
@@ -414,8 +415,7 @@ static int hr_train_n_cus()
 template <int ZP>
 static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stream)
 {
-    constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
-    constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
+    constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
     const size_t line_bytes = hr_train_line_bytes(args);
     const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total + line_bytes;
     if (line_bytes == 0 || lds > 150 * 1024) return false;
