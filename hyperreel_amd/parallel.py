@@ -90,8 +90,11 @@ class ShardedFramePipeline:
     `render` is the caller's business (HipLightfieldModel.render / render_camera with pixel_range); on CPU (gloo tests) the
     gathers are synchronous.  Every rank ends up with every full frame, in submission order."""
 
-    def __init__(self, n_pixels, device, group=None, channels=3, dtype=torch.float32):
+    def __init__(self, n_pixels, device, group=None, channels=3, dtype=torch.float32, always_gather=False):
         self.group = group
+        # always_gather: take the collective (and, on a GPU, the side-stream) path even in a one-rank group -- how the RCCL
+        # hand-over is exercised on a single-GPU box (tests/test_gpu_parallel.py)
+        self.always_gather = bool(always_gather) and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.n = int(n_pixels)
@@ -129,7 +132,7 @@ class ShardedFramePipeline:
         """Starts the gather of the frame just rendered into begin()'s buffer; returns the PREVIOUS frame's full image
         (None for the first call) -- valid on the current stream."""
         s = self.slot
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             self.full[s][:self.n].copy_(self.tiles[s][:self.n])
         elif self.cuda:
             self.rendered[s].record()

@@ -75,6 +75,8 @@ def main():
                   f'b.planes[{j}].app_off = {app_off}; b.planes[{j}].app_real = {na}; b.planes[{j}].app_real_off = {real_off}; '
                   f'b.planes[{j}].a = a.planes[{j}].a; b.planes[{j}].b = a.planes[{j}].b;')
         app_off += 4 * ca4; real_off += na
+    nd_, na_ = list(hc.n_den)[:3], list(hc.n_app)[:3]
+    pclass = 0 if half else (1 if (nd_ == [8, 4, 4] and na_ == [8, 4, 4]) else (2 if (nd_ == [8, 0, 0] and na_[0] == 8) else 0))
     src = f'''#define HR_PHASE_MARK
 #include "{B.CSRC}/sample_core.inc"
 __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
     hr_fill_decode<{ZP}>(c, b, L, k, M);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 102" ::: "memory");
-    hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, nullptr);
+    hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB, {pclass}>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, nullptr);
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 199" ::: "memory");
 }}
 '''
