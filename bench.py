@@ -369,7 +369,12 @@ def main():
                  'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {min(chunk, B)} rays',
                  'mfma_products_per_gemm': n_prod,
                  'note': (f'fp32 GEMMs evaluated as {n_prod} 16-bit MFMA products of hi/lo split operands, fp32 accumulate: the matrix cores '
-                          f'issue {n_prod}x the algorithmic FLOPs, so frac <= 1/{n_prod} by construction') if split else 'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
+                          f'issue {n_prod}x the algorithmic FLOPs, so frac <= 1/{n_prod} by construction.  The datasheet peak needs zero operands: '
+                          'with real data the power manager holds the shader clock at 1.84 GHz instead of 2.44 '
+                          '(profiles/r02_e_mfma_pipe_ubench.txt), 1.85 PFLOP/s sustained -- frac_of_sustained_issued prices the issued products against that') if split else 'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
+        if split:
+            r_mlp['sustained_mfma_tflops'] = 1850.0
+            r_mlp['frac_of_sustained_issued'] = round(n_prod * flops / (mlp_ms[0] * 1e-3) / 1e12 / 1850.0, 4)
         r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'valu', 'achieved': None, 'peak': round(VALU_PEAK_GINST, 1), 'unit': 'G wave-instructions/s',
                  'frac': None, 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
                  'algorithmic_gather_GBs': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
@@ -413,8 +418,13 @@ def main():
                     'mfma_products_per_gemm': n_prod,
                     'note': 'ONE persistent kernel per frame: MLP wavefronts (matrix cores) and sample wavefronts (vector ALU) of the same '
                             'workgroup, head tile in LDS.  frac prices the whole frame against the 16-bit MFMA peak with the algorithmic MLP FLOPs '
-                            f'(<= 1/{n_prod} by construction); the kernel is bound by the sample wavefronts\' dependent-instruction latency at '
-                            '8 of them per CU (DESIGN.md 3c), see valu_busy_frac / mfma_busy_frac'}
+                            f'(<= 1/{n_prod} by construction).  Limits (DESIGN.md 3c, 3d): the sample wavefronts\' dependent-instruction latency at '
+                            '8 of them per CU, and the power manager -- under real matrix operands the shader clock is 1.84 GHz against 2.44 GHz '
+                            'with zero operands (profiles/r02_e_mfma_pipe_ubench.txt), so the products of a frame alone are 0.82 ms at the '
+                            'sustained 1.85 PFLOP/s and overlapping the vector stage with them does not add the two rates; see valu_busy_frac / '
+                            'mfma_busy_frac',
+                    'sustained_mfma_tflops': 1850.0,
+                    'frac_of_sustained_issued': round(n_prod * flops / (fr_ms[0] * 1e-3) / 1e12 / 1850.0, 4)}
             try:
                 tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters_frame_kernel.json')))
                 w = tr['workload']
