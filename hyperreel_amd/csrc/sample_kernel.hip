@@ -54,12 +54,15 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     }
 
     // ---- per-ray quantities (computed redundantly by the ray's lanes) and the ray's decode matrix
+    // RGB shading: the decode matrix is basis_mat itself, the same for every ray -- the block keeps ONE copy, filled by its
+    // first ray's lanes (SH: one per ray, folded with that ray's view direction)
     const HrRayLane L = hr_load_ray(cfg, a, ray, ray_ok);
-    float* M = s_M + rib * 3 * CA;
+    const bool per_ray_M = (cfg.shading == HR_SHADING_SH);
+    float* M = s_M + (per_ray_M ? rib * 3 * CA : 0);
 #ifdef HR_TUNING
     if (!(a.dbg_mode & 4))
 #endif
-    hr_fill_decode<ZP>(cfg, a, L, k, M);
+    if (per_ray_M || rib == 0) hr_fill_decode<ZP>(cfg, a, L, k, M);
     __syncthreads();
 
 #ifdef HR_TUNING
