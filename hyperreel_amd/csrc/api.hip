@@ -1175,7 +1175,7 @@ static int ensure_tape(hr_model* m, int64_t ns, hipStream_t st)
     HR_HIP(hipStreamSynchronize(st));
     free_dev(m->tape);
     m->tape_samples = 0;
-    HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 8 * (size_t)ns));
+    HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 29 * (size_t)ns));       // HrTrainTape: 8 planes + 18 of taps + 3 of dL/d point
     m->tape_samples = ns;
     return HR_OK;
 }
@@ -1295,6 +1295,8 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     a.tape.dpre = m->tape + 3 * ns;      // 3 planes
     a.tape.ddc = m->tape + 6 * ns;
     a.tape.dts = m->tape + 7 * ns;
+    a.tape.taps = m->tape + 8 * ns;
+    a.tape.dp = m->tape + 26 * ns;
     a.d_rgb = d_rgb_dev;
     a.d_head = d_head_dev;
     a.d_basis = d_basis;

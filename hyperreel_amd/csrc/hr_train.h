@@ -59,6 +59,9 @@ struct HrTrainTape {
     float* dpre;      // dL / d decoded colour pre-activation, 3 planes of n_rays * Z
     float* ddc;       // dL / d final distance
     float* dts;       // dL / d pre-sort distance by ORIGINAL sample index (written by phase B)
+    // device, lane-per-sample phase A only (NULL otherwise): what phase B would recompute per 16-lane group
+    float* taps;      // 18 planes of n_rays * Z: per axis x, y, z the grid_sample tap {i0, i1 (int bits), w0, w1, s0, s1}
+    float* dp;        // dL / d point, 3 planes of n_rays * Z (phase B -> hr_sample_train_point_bwd)
 };
 
 struct HrTrainArgs {
@@ -696,6 +699,49 @@ HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t
     }
     if (lane != 0) return;
     const float dt = hr_sample_point_bwd(c, hk, ds, q.ro, q.rd, q.oc, q.time_off, dp, a.tape.ddc[s], a.d_head + s * P);
+    a.tape.dts[ray * Z + a.tape.src[s]] = dt;
+}
+
+// Phase B on the device when phase A left the taps on the tape: the 16 lanes of a sample only do what is per channel -- no
+// point, contraction or tap arithmetic repeated by every lane -- and the per-sample tail (hr_sample_point_bwd) is
+// hr_sample_train_point_bwd's, one lane per sample.
+HR_FN void hr_sample_train_bwd_taps(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane, int lanes,
+                                    float* const* line_acc)
+{
+    const int Z = c.z_channels, CA = a.ca_total;
+    const int64_t s = ray * Z + k, NS = a.n_rays * Z;
+    const float dfeat = a.tape.dfeat[s];
+    const float dpre[3] = {a.tape.dpre[s], a.tape.dpre[NS + s], a.tape.dpre[2 * NS + s]};
+    float dp[3] = {0.f, 0.f, 0.f};
+    if (dfeat != 0.0f || dpre[0] != 0.0f || dpre[1] != 0.0f || dpre[2] != 0.0f) {     // only samples that were valid
+        hr_axis_tap_g ax[3];
+        for (int i = 0; i < 3; ++i) {
+            const float* t = a.tape.taps + (size_t)(6 * i) * NS + s;
+            ax[i].t.i0 = __builtin_bit_cast(int, t[0]);
+            ax[i].t.i1 = __builtin_bit_cast(int, t[NS]);
+            ax[i].t.w0 = t[2 * NS]; ax[i].t.w1 = t[3 * NS];
+            ax[i].s0 = t[4 * NS]; ax[i].s1 = t[5 * NS];
+            ax[i].mult = 0.5f * (float)(c.grid[i] - 1);
+        }
+        float base_t = 0.0f;
+        if (c.advect) base_t = hr_base_time(c, a.rays[ray * c.ray_dim + c.ray_dim - 1]);
+        const hr_axis_tap_g tap_t = hr_make_tap_g(c.video ? hr_normalize_time(c, base_t) : 0.0f, c.video ? c.num_keyframes : 2);
+        float dpn[3];
+        hr_train_gather_bwd(a, ax, tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, line_acc);
+        for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], lanes) * c.inv_size[i];
+    }
+    if (lane != 0) return;
+    a.tape.dp[s] = dp[0]; a.tape.dp[NS + s] = dp[1]; a.tape.dp[2 * NS + s] = dp[2];
+}
+
+// ... and its tail: the sample of sorted rank k of `ray`, one thread
+HR_FN void hr_sample_train_point_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k)
+{
+    const int Z = c.z_channels, P = c.preds_per_z;
+    const int64_t s = ray * Z + k, NS = a.n_rays * Z;
+    const HrTrainRay q = hr_train_ray(c, a.rays + ray * c.ray_dim);
+    const float dp[3] = {a.tape.dp[s], a.tape.dp[NS + s], a.tape.dp[2 * NS + s]};
+    const float dt = hr_sample_point_bwd(c, a.head + s * P, a.tape.ds[s], q.ro, q.rd, q.oc, q.time_off, dp, a.tape.ddc[s], a.d_head + s * P);
     a.tape.dts[ray * Z + a.tape.src[s]] = dt;
 }
 

@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
             pn[1] = hr_normalize_coord(c, p[1], 1);
             pn[2] = hr_normalize_coord(c, p[2], 2);
             pn[3] = c.video ? hr_normalize_time(c, base_t) : 0.0f;
+            if (a.d_rgb && a.tape.taps) {          // what phase B needs of this sample's position: the three axis taps
+                const int64_t NS = a.n_rays * Z, s = ray * Z + k;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const hr_axis_tap_g g = hr_make_tap_g(pn[i], c.grid[i]);
+                    float* t = a.tape.taps + (size_t)(6 * i) * NS + s;
+                    t[0] = __builtin_bit_cast(float, g.t.i0); t[NS] = __builtin_bit_cast(float, g.t.i1);
+                    t[2 * NS] = g.t.w0; t[3 * NS] = g.t.w1; t[4 * NS] = g.s0; t[5 * NS] = g.s1;
+                }
+            }
         }
         if constexpr (PC != 0) {
             HrAxisTapsC at;
@@ -316,7 +326,8 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
     for (int si = grp; si < RPB * Z; si += GROUPS) {
         const int r = si / Z, k = si - r * Z;
         if (ray0 + r >= a.n_rays) continue;
-        hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
+        if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, nullptr);
+        else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
@@ -368,7 +379,8 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
         for (int si = grp; si < RPB * Z; si += GROUPS) {
             const int r = si / Z, k = si - r * Z;
             if (ray0 + r >= a.n_rays) continue;
-            hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
+            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
+            else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
         }
         __syncthreads();
         for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
@@ -431,6 +443,15 @@ static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stre
     return true;
 }
 
+// Tail of phase B (taps path): one thread per sorted sample
+__global__ __launch_bounds__(256) void hr_train_point_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+{
+    const hr_config& c = *cfgp;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_rays * c.z_channels) return;
+    hr_sample_train_point_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
+}
+
 // Phase C
 __global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
@@ -440,11 +461,13 @@ __global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config*
     hr_sample_train_dist_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
 }
 
-void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
+void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream_t stream)
 {
-    if (args.n_rays <= 0) return;
+    if (args_in.n_rays <= 0) return;
     int ZP = 8;
     while (ZP < cfg.z_channels) ZP <<= 1;
+    HrTrainArgs args = args_in;
+    if (ZP > 64) { args.tape.taps = nullptr; args.tape.dp = nullptr; }     // the one-thread-per-ray phase A leaves no taps
     const unsigned blocks = (unsigned)((args.n_rays + HR_TRAIN_RPW - 1) / HR_TRAIN_RPW);
     switch (ZP) {                                  // phase A: a lane per sample where a ray fits one wavefront
         case 8: hr_launch_train_lanes<8>(cfg, args, stream); break;
@@ -480,6 +503,7 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t 
         default: break;
     }
     const int64_t ns = args.n_rays * cfg.z_channels;
+    if (args.tape.taps) hipLaunchKernelGGL(hr_train_point_bwd_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
     hipLaunchKernelGGL(hr_train_dist_bwd_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }
 
