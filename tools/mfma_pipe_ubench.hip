@@ -23,17 +23,18 @@ __device__ __forceinline__ void wait4(W& w) { asm volatile("s_waitcnt lgkmcnt(4)
 
 // MODE 0: operands in registers.  1: A operands from LDS one k-step ahead.  2: + s_barrier every 8 k-steps.  3: + 32 KB global -> LDS DMA per 8 k-steps.  NB: distinct B operands (1 or 16).  ACC: 1, 2, 4 accumulators
 // ZERO: all operands 0 (same instruction stream, no toggling) -- the difference to random data is the power limit at work
-template <int MODE, int ACC, int NB, bool ZERO = false>
+// ZERO = 2: every operand element 1.0 (non-zero, but identical from one MFMA to the next)
+template <int MODE, int ACC, int NB, int ZERO = 0>
 __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, int iters, const unsigned char* wsrc, unsigned long long* clk)
 {
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 8 * 4096 / 4; i += 256) reinterpret_cast<float*>(lds)[i] = ZERO ? 0.0f : in[i & 1023] * 1e-3f;
+    for (int i = threadIdx.x; i < 8 * 4096 / 4; i += 256) reinterpret_cast<float*>(lds)[i] = ZERO == 1 ? 0.0f : ZERO == 2 ? __builtin_bit_cast(float, 0x3C003C00u) : in[i & 1023] * 1e-3f;     // (LDS operands: modes >= 1 only)
     __syncthreads();
     h8 bh[NB], bl[NB];
     for (int s = 0; s < NB; ++s)
-        for (int i = 0; i < 8; ++i) { bh[s][i] = ZERO ? (_Float16)0 : (_Float16)in[(threadIdx.x * 8 + i + s) & 1023]; bl[s][i] = ZERO ? (_Float16)0 : (_Float16)(in[(threadIdx.x * 8 + i + 512 + s) & 1023] * 1e-3f); }
+        for (int i = 0; i < 8; ++i) { bh[s][i] = ZERO == 1 ? (_Float16)0 : ZERO == 2 ? (_Float16)1 : (_Float16)in[(threadIdx.x * 8 + i + s) & 1023]; bl[s][i] = ZERO == 1 ? (_Float16)0 : ZERO == 2 ? (_Float16)1 : (_Float16)(in[(threadIdx.x * 8 + i + 512 + s) & 1023] * 1e-3f); }
     floatx16 acc[ACC];
     for (int j = 0; j < ACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + lane * 16;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void k(const float* in, float* out, int ite
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-template <int MODE, int ACC, int NB, bool ZERO = false>
+template <int MODE, int ACC, int NB, int ZERO = 0>
 void run(int iters, const float* din, float* dout, const unsigned char* wsrc = nullptr)
 {
     static unsigned long long* clk = nullptr;
@@ -89,7 +90,7 @@ void run(int iters, const float* din, float* dout, const unsigned char* wsrc = n
     const double n = (double)iters * 8 * 3 * ACC;
     unsigned long long hc[2];
     hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
-    printf("mode=%d acc=%d nb=%d%s: %.3f ms  %.1f TFLOP/s  %.1f ns per MFMA per wave   s_memtime/s_memrealtime = %.3f (x100 MHz)\n", MODE, ACC, NB, ZERO ? " zeros" : "", ms, (double)blocks * 4 * n * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12, ms * 1e6 / n, (double)hc[0] / (double)hc[1]);
+    printf("mode=%d acc=%d nb=%d%s: %.3f ms  %.1f TFLOP/s  %.1f ns per MFMA per wave   s_memtime/s_memrealtime = %.3f (x100 MHz)\n", MODE, ACC, NB, ZERO == 1 ? " zeros" : ZERO == 2 ? " ones" : "", ms, (double)blocks * 4 * n * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12, ms * 1e6 / n, (double)hc[0] / (double)hc[1]);
 }
 
 int main()
@@ -110,7 +111,8 @@ int main()
         run<1, 2, 1>(4000, din, dout);
         run<1, 2, 16>(4000, din, dout);
         run<1, 4, 16>(4000, din, dout);
-        run<0, 2, 16, true>(4000, din, dout);
+        run<0, 2, 16, 1>(4000, din, dout);
+        run<0, 2, 16, 2>(4000, din, dout);
         run<2, 2, 16>(4000, din, dout);
         run<3, 2, 16>(4000, din, dout, wsrc);
     }
