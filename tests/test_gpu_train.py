@@ -185,6 +185,44 @@ def test_flat_gradient_views_receive_the_hip_gradients():
             assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12
 
 
+def test_flat_gradients_survive_a_grid_upsample_of_the_real_model():
+    """The training loop grows the grids at the `upsamp_list` iterations (TensorBase.set_iter -> upsample_volume_grid,
+    tensorf_base.py:1151-1188), which REPLACES the plane / line nn.Parameters.  A FlatGradients built from the module must pick
+    the new parameters up at the next zero(): one buffer again, every .grad a view of it, and the HIP gradients of the grown
+    model land in it."""
+    from gpu_common import make_render_fn
+    from hyperreel_amd.parallel import FlatGradients
+    g = Golden('donerf_sphere_small')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    fn.train()
+    model = fn.model
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays[:128], np.float32)).cuda()
+    G = torch.from_numpy(np.random.default_rng(2).standard_normal((128, 3)).astype(np.float32)).cuda()
+    flat = FlatGradients(model)
+    flat.zero()
+    (model.forward_train(rays, white_bg=False) * G).sum().backward()
+    flat.check()
+    n0 = flat.flat.numel()
+    old_ids = {id(p) for p in model.parameters()}
+    target = [int(v * 1.5) for v in model.grid_size]
+    model.upsample_volume_grid(target)
+    assert {id(p) for p in model.parameters()} != old_ids            # parameters were replaced, not resized in place
+    flat.zero()                                                       # notices, rebuilds the buffer
+    assert flat.flat.numel() > n0
+    (model.forward_train(rays, white_bg=False) * G).sum().backward()
+    flat.check()
+    lo, hi = flat.flat.data_ptr(), flat.flat.data_ptr() + 4 * flat.flat.numel()
+    n_grid = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None and lo <= p.grad.data_ptr() < hi, name
+        if ('plane' in name or 'line' in name) and p.numel() > 0:
+            n_grid += 1
+            assert list(p.shape[2:]) != [] and bool(torch.isfinite(p.grad).all())
+    assert n_grid >= 6 and float(flat.flat.abs().max()) > 0
+
+
 @pytest.mark.parametrize('rows,fin,fout,slope,ld_extra', [(16384, 18, 256, 0.01, 0), (1000, 274, 256, 0.01, 0), (777, 256, 480, -1.0, 0),
                                                           (64, 256, 352, -1.0, 0), (5, 23, 64, 0.01, 0), (2048, 256, 256, 0.01, 18)])
 def test_hip_linear_matches_torch_forward_and_backward(rows, fin, fout, slope, ld_extra):
