@@ -47,7 +47,7 @@ def test_a_checkpoint_with_a_shrunk_box_renders_in_that_box():
     assert np.abs(render_np(fn, g.rays)['rgb'] - ref).max() <= 1e-4
 
 
-@pytest.mark.parametrize('case', ['alpha_mask_static', 'alpha_mask_video'])
+@pytest.mark.parametrize('case', ['alpha_mask_static', 'alpha_mask_video', 'alpha_mask_video_open'])
 def test_occupancy_mask_and_shrink_follow_the_reference(case):
     """TensorBase.set_iter at an update_AlphaMask_list iteration (tensorf_base.py:510-530): hr_dense_alpha -> max-pool ->
     threshold -> shrink, against what the reference's own code produced (tests/golden/mask, oracle/refgen/make_alpha_mask.py),
@@ -60,7 +60,11 @@ def test_occupancy_mask_and_shrink_follow_the_reference(case):
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mask', case + '.npz'))
     r = json.loads(bytes(z['recipe']).decode())
     cfg, ds = cfgmod.model_config(r['model']), r['dataset']
-    sd = scenes.carve_density(scenes.make_state_dict(cfg, ds, r['grid'], r['seed'], 'dense', 1.0))
+    if 'thre' in r:                         # 'alpha_mask_video_open': holes inside the mask's box, where the density is not zero --
+        cfg['color']['net']['alpha_mask_thre'] = r['thre']     # the case in which a keyframe net must NOT consult the previous mask
+    sd = scenes.make_state_dict(cfg, ds, r['grid'], r['seed'], 'dense', 1.0)
+    if r.get('carve', True):
+        sd = scenes.carve_density(sd)
     fn = make_render_fn(cfg, ds, sd)
     net = fn.model.color_model.net
     a1 = net.getDenseAlpha(r['n1'])
