@@ -21,6 +21,7 @@ The JSON line also carries
                   the instruction count per launch comes from the committed PMC pass (profiles/r02_counters.json);
   frame_kernel    the same frame through the single persistent frame kernel (head tile handed over in LDS);
   value_fp32_exact  the same frame with the exact fp32-MFMA MLP;
+  value_f16x2     the same frame with the opt-in two-product MLP arithmetic, and its own parity against the oracle;
   pytorch_gpu_baseline  the reference's algorithm as stock PyTorch-ROCm ops on this GPU (north star: ">= 10x");
   cpu_baseline    the CPU port of the reference's algorithm (oracle/torch_port.py) on a bounded sample of the same frame,
                   with its calibration against the reference itself (profiles/r02_cpu_calibration.json).
@@ -469,6 +470,16 @@ def main():
                                           'what': 'same frame, MLP on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32)',
                                           'linf_vs_value_path': float((exact.model.render(rays)['rgb'] - rgb).abs().max())}
             del exact
+        if prec_name in ('bf16x3', 'f16x3'):
+            # the two-product mode (weights rounded once to half): not the headline -- its error leaves little margin on the keyframe
+            # families -- but what the same frame costs with 2/3 of the matrix products, with its own parity below
+            fast = make('f16x2', use_frame)
+            v, ms = quick(fast)
+            fast_rgb = fast.model.render(rays)['rgb'].clone()
+            result['value_f16x2'] = {'value': round(v, 3), 'unit': 'Mrays/s', 'ms_per_step': round(ms, 4),
+                                     'what': 'same frame, MLP GEMMs as two fp16 MFMA products (activations split, weights rounded once to half): opt-in mlp_precision="f16x2"',
+                                     'linf_vs_value_path': float((fast_rgb - rgb).abs().max())}
+            del fast
         torch.cuda.empty_cache()
 
     # ---- CPU baseline (rank 0, N = 1)
@@ -489,6 +500,10 @@ def main():
         err = np.abs(got - ref_rgb).max(-1)
         result['parity_vs_oracle_linf'] = float(err.max())
         result['parity_rays_over_1e-4'] = int((err > 1e-4).sum())
+        if 'value_f16x2' in result:
+            e2 = np.abs(fast_rgb[torch.from_numpy(idx).cuda()].cpu().numpy() - ref_rgb).max(-1)
+            result['value_f16x2']['parity_vs_oracle_linf'] = float(e2.max())
+            result['value_f16x2']['parity_rays_over_1e-4'] = int((e2 > 1e-4).sum())
 
     result['grid_dtype'] = args.grid_dtype
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if (args.no_graph or strong) else 'hipGraph replay of one captured frame'
