@@ -300,50 +300,60 @@ static void hr_launch_train_lanes(const hr_config& cfg, const HrTrainArgs& args,
 // texel in every shipped model), so that the atomics of one tap are one contiguous run; a workgroup is 16 such groups
 // and walks the samples of RPB whole rays (1 ray when it has 16 samples or more).
 #define HR_TRAIN_LPS 16
+// rows of basis_mat: 3 (RGB) or 27 (SH: 3 colours x 9 basis functions)
+__device__ __forceinline__ int hr_train_basis_rows(const hr_config& c) { return c.shading == HR_SHADING_SH ? 27 : 3; }
+
 template <int ZP>
 __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 256 / HR_TRAIN_LPS;
     constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
-    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix, then [RPB][3 * CA] its gradient
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | basis_mat's gradient, this workgroup's share
     const int CA = a.ca_total, Z = c.z_channels;
-    const int64_t ray0 = (int64_t)blockIdx.x * RPB;
-    for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
-        const int r = e / (3 * CA), i = e - r * 3 * CA;
-        float v = 0.0f;
-        if (ray0 + r < a.n_rays) {
+    float* bacc = lds + 2 * RPB * 3 * CA;
+    const int nb = hr_train_basis_rows(c) * a.n_basis_cols;
+    for (int e = threadIdx.x; e < nb; e += 256) bacc[e] = 0.0f;
+    const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
+    // persistent: the workgroup walks ray blocks blockIdx.x, + gridDim.x, ... and adds its basis_mat gradient to the global one once
+    for (int64_t ray0 = (int64_t)blockIdx.x * RPB; ray0 < a.n_rays; ray0 += (int64_t)gridDim.x * RPB) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
+            const int r = e / (3 * CA), i = e - r * 3 * CA;
+            float v = 0.0f;
+            if (ray0 + r < a.n_rays) {
+                float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+                if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
+                v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
+            }
+            lds[e] = v;
+            lds[RPB * 3 * CA + e] = 0.0f;
+        }
+        __syncthreads();
+        for (int si = grp; si < RPB * Z; si += GROUPS) {
+            const int r = si / Z, k = si - r * Z;
+            if (ray0 + r >= a.n_rays) continue;
+            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, nullptr);
+            else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
+            const int r = e / (3 * CA), i = e - r * 3 * CA;
+            if (ray0 + r >= a.n_rays) continue;
             float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* rr = a.rays + (ray0 + r) * c.ray_dim;
             if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
-            v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
+            hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e], bacc);
         }
-        lds[e] = v;
-        lds[RPB * 3 * CA + e] = 0.0f;
     }
     __syncthreads();
-    const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
-    for (int si = grp; si < RPB * Z; si += GROUPS) {
-        const int r = si / Z, k = si - r * Z;
-        if (ray0 + r >= a.n_rays) continue;
-        if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, nullptr);
-        else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
-        const int r = e / (3 * CA), i = e - r * 3 * CA;
-        if (ray0 + r >= a.n_rays) continue;
-        float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* rr = a.rays + (ray0 + r) * c.ray_dim;
-        if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
-        hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e]);
+    for (int e = threadIdx.x; e < nb; e += 256) {
+        const float v = bacc[e];
+        if (v != 0.0f) HR_ATOMIC_ADD(a.d_basis + e, v);
     }
 }
 
-// Phase B for static nets: the same walk by a PERSISTENT workgroup of 1024 threads (one per CU) that keeps the gradients of
-// the three lines in LDS.  A line has a few hundred texels and every sample of the batch adds to two of them: as global
-// atomics those adds were 0.77 of the phase's 1.46 ms on the 600^3 DoNeRF scene (the same number of plane atomics, spread
-// over 360 000 texels: 0.28 ms).  In LDS they are ds_add_f32; each workgroup adds its lines to the global ones once.
 #define HR_TRAIN_LINES_RPB(ZP) (((1024 / HR_TRAIN_LPS) + (ZP) - 1) / (ZP))
 template <int ZP>
 __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
@@ -351,13 +361,17 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);    // rays per trip: one sample per 16-lane group between the barriers (four were slower: 1.43 vs 1.32 ms)
-    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the three lines
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the three lines | basis_mat's gradient
     const int CA = a.ca_total, Z = c.z_channels;
     float* line_acc[3];
     int line_n[3];
+    float* bacc;
+    const int nb = hr_train_basis_rows(c) * a.n_basis_cols;
     {
         float* p = lds + 2 * RPB * 3 * CA;
         for (int j = 0; j < 3; ++j) { line_acc[j] = p; line_n[j] = a.planes[j].bh * a.planes[j].tex; p += line_n[j]; }
+        bacc = p;
+        p += nb;
         for (float* q = lds + 2 * RPB * 3 * CA + threadIdx.x; q < p; q += 1024) *q = 0.0f;
     }
     const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
@@ -389,10 +403,14 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
             float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* rr = a.rays + (ray0 + r) * c.ray_dim;
             if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
-            hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e]);
+            hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e], bacc);
         }
     }
     __syncthreads();
+    for (int e = threadIdx.x; e < nb; e += 1024) {
+        const float v = bacc[e];
+        if (v != 0.0f) HR_ATOMIC_ADD(a.d_basis + e, v);
+    }
     for (int j = 0; j < 3; ++j)
         for (int i = threadIdx.x; i < line_n[j]; i += 1024) {
             const float v = line_acc[j][i];
@@ -429,7 +447,7 @@ static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stre
 {
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
     const size_t line_bytes = hr_train_line_bytes(args);
-    const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total + line_bytes;
+    const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols) + line_bytes;
     if (line_bytes == 0 || lds > 150 * 1024) return false;
     static size_t allowed = 0;
     if (lds > allowed) {
@@ -491,8 +509,10 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
     }
     const int GROUPS = 256 / HR_TRAIN_LPS;
     const int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
-    const unsigned bblocks = (unsigned)((args.n_rays + RPB - 1) / RPB);
-    const size_t lds = sizeof(float) * 2 * RPB * 3 * args.ca_total;
+    const int64_t nblocks = (args.n_rays + RPB - 1) / RPB;
+    const int64_t resident = 16 * (int64_t)hr_train_n_cus();          // four 256-thread workgroups per CU are resident (128 registers); four rounds of them: the blocks differ in cost
+    const unsigned bblocks = (unsigned)(nblocks < resident ? nblocks : resident);
+    const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
     if (!done) switch (ZP) {
         case 8: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<8>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
         case 16: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<16>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
