@@ -1231,6 +1231,7 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
     if (n_rays > 0 && (!head_dev || !rgb_dev)) return fail(HR_E_INVALID, "null head / rgb buffer");
     hipStream_t st = (hipStream_t)stream;
     if (params) {                     // this step's parameter values -> the kernels' texel layout (no allocation, no sync)
+        HrLayoutBatch batch = {};                  // all twelve tensors in one launch
         for (int j = 0; j < 3; ++j) {
             const HrGridPlane& g = m->planes[j];
             if (g.tex == 0) continue;
@@ -1239,10 +1240,11 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
                 if (io.ch[t] == 0) continue;
                 if (!io.p[t]) return fail(HR_E_INVALID, "hr_train_forward: params tensor of plane pair %d is NULL", j);
                 const bool is_a = t < 2;
-                hr_launch_interleave(io.p[t], is_a ? m->grid_a[j] : m->grid_b[j], 0, io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
-                                     (t & 1) ? 4 * g.cd4 : 0, st);
+                batch.job[batch.n++] = HrLayoutJob{io.p[t], is_a ? m->grid_a[j] : m->grid_b[j], io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
+                                                   (t & 1) ? 4 * g.cd4 : 0};
             }
         }
+        hr_launch_layout_batch(batch, true, st);
         const size_t bytes = m->raw["basis_mat.weight"].bytes;
         if (bytes > 0) {
             if (!params->basis) return fail(HR_E_INVALID, "hr_train_forward: params->basis is NULL");
@@ -1306,6 +1308,7 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         a.d_color_table = grads->color_table;
     }
     hr_launch_train(m->cfg, a, st);
+    HrLayoutBatch batch = {};                      // packed texel gradients -> the reference's (C, H, W) tensors, one launch
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = m->planes[j];
         if (g.tex == 0) continue;
@@ -1313,10 +1316,11 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         for (int t = 0; t < 4; ++t) {
             if (io.ch[t] == 0 || !io.p[t]) continue;
             const bool is_a = t < 2;
-            hr_launch_deinterleave(is_a ? m->grad_a[j] : m->grad_b[j], io.p[t], io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
-                                   (t & 1) ? 4 * g.cd4 : 0, st);
+            batch.job[batch.n++] = HrLayoutJob{is_a ? m->grad_a[j] : m->grad_b[j], io.p[t], io.ch[t], is_a ? g.ah : g.bh, is_a ? g.aw : g.bw, g.tex,
+                                               (t & 1) ? 4 * g.cd4 : 0};
         }
     }
+    hr_launch_layout_batch(batch, false, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }

@@ -134,6 +134,40 @@ void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, i
                            reinterpret_cast<float*>(dst), C, H, W, tex, c_off);
 }
 
+// All re-layouts of a training step in one launch: blockIdx.y = job, blockIdx.x strides over the job's elements.
+//   TO_PACKED:  dst[(y*W + x)*tex + c_off + c] = src[(c*H + y)*W + x]   (parameters -> texels, before the forward)
+//   else:       dst[(c*H + y)*W + x] = src[(y*W + x)*tex + c_off + c]   (texel gradients -> parameter gradients)
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void hr_layout_batch_kernel(const HrLayoutBatch b)
+{
+    const HrLayoutJob j = b.job[blockIdx.y];
+    const int64_t hw = (int64_t)j.H * j.W, n = hw * j.C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (TO_PACKED) {                           // i enumerates the destination order (y, x, c): contiguous writes per texel
+            const int c = (int)(i % j.C);
+            const int64_t yx = i / j.C;
+            j.dst[yx * j.tex + j.c_off + c] = j.src[(int64_t)c * hw + yx];
+        } else {                                   // i enumerates (c, y, x), x fastest: coalesced stores
+            const int c = (int)(i / hw);
+            const int64_t yx = i - (int64_t)c * hw;
+            j.dst[i] = j.src[yx * j.tex + j.c_off + c];
+        }
+    }
+}
+
+void hr_launch_layout_batch(const HrLayoutBatch& b, bool to_packed, hipStream_t stream)
+{
+    if (b.n <= 0) return;
+    int64_t most = 0;
+    for (int i = 0; i < b.n; ++i) most = most > (int64_t)b.job[i].C * b.job[i].H * b.job[i].W ? most : (int64_t)b.job[i].C * b.job[i].H * b.job[i].W;
+    if (most <= 0) return;
+    int64_t blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks, (unsigned)b.n);
+    if (to_packed) hipLaunchKernelGGL(hr_layout_batch_kernel<true>, grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL(hr_layout_batch_kernel<false>, grid, dim3(256), 0, stream, b);
+}
+
 // ---------------------------------------------------------------- TensoRF plane regularisers
 // TVLoss (nlf/regularizers/tensorf.py:14-34) and density_L1 (nlf/nets/tensorf_base.py:1024-1035) of one (1, C, H, W)
 // plane in one pass over it: sums += { sum (x[y] - x[y-1])^2, sum (x[x] - x[x-1])^2, sum |x| }.  The reference's torch

@@ -195,10 +195,14 @@ __global__ __launch_bounds__(256) void hr_gemm_bf16x3_kernel(const HrGemmArgs a)
     }
 }
 
-// out[i] = sum_z part[z * n + i], z ascending
-__global__ void hr_sum_partials_kernel(const float* part, int64_t n, int splits, float* out)
+// out[i] = sum_z part[z * n + i], z ascending -- for two arrays at once (dW's partial tiles and db's partial row sums)
+__global__ void hr_sum_partials_kernel(const float* part0, int64_t n0, float* out0, const float* part1, int64_t n1, float* out1, int splits)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* part = part0;
+    float* out = out0;
+    int64_t n = n0;
+    if (i >= n0) { i -= n0; part = part1; out = out1; n = n1; }
     if (i >= n) return;
     float s = 0.0f;
     for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
@@ -260,7 +264,7 @@ void hr_launch_linear_backward(const float* x, int64_t ldx, const float* w, cons
         dim3 grid((unsigned)((out + HR_GT - 1) / HR_GT), (unsigned)((in + HR_GT - 1) / HR_GT), (unsigned)splits);
         hipLaunchKernelGGL((hr_gemm_bf16x3_kernel<true, true, false>), grid, dim3(256), 0, stream, a);
         const int64_t nw = (int64_t)out * in;
-        hipLaunchKernelGGL(hr_sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, workspace, nw, splits, dw);
-        hipLaunchKernelGGL(hr_sum_partials_kernel, dim3((unsigned)((out + 255) / 256)), dim3(256), 0, stream, a.rowsum, (int64_t)out, splits, db);
+        hipLaunchKernelGGL(hr_sum_partials_kernel, dim3((unsigned)((nw + out + 255) / 256)), dim3(256), 0, stream, workspace, nw, dw, a.rowsum,
+                           (int64_t)out, db, splits);
     }
 }
