@@ -123,7 +123,6 @@ void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst,
 void hr_launch_pack_display(const float* rgb, int h, int w, int transpose, int flip, int rgba8, void* out, hipStream_t stream);
 void hr_launch_plane_reg_forward(const float* p, int C, int H, int W, float* sums, hipStream_t stream);
 void hr_launch_plane_reg_backward(const float* p, int C, int H, int W, const float* coef, float* grad, hipStream_t stream);
-void hr_launch_deinterleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 // the training step's re-layouts in ONE launch per direction (reference (C, H, W) tensors <-> packed channel-last texels): up to 12 jobs
 struct HrLayoutJob { const float* src; float* dst; int C, H, W, tex, c_off; };
 struct HrLayoutBatch { HrLayoutJob job[12]; int n; };

@@ -587,25 +587,6 @@ void hr_launch_features(const hr_config* cfg_dev, const float* rays, int64_t n, 
     hipLaunchKernelGGL(hr_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cfg_dev, rays, n, out);
 }
 
-// dst[c][y][x] = src[y][x][c_off + c]: packed texel gradients -> the reference's parameter layout
-__global__ __launch_bounds__(256) void hr_deinterleave_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int tex,
-                                                             int c_off)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over (c, y, x), x fastest: coalesced stores
-    const int64_t hw = (int64_t)H * W;
-    if (i >= hw * C) return;
-    const int c = (int)(i / hw);
-    const int64_t yx = i - (int64_t)c * hw;
-    dst[i] = src[yx * tex + c_off + c];
-}
-
-void hr_launch_deinterleave(const float* src, float* dst, int C, int H, int W, int tex, int c_off, hipStream_t stream)
-{
-    const int64_t n = (int64_t)C * H * W;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(hr_deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, C, H, W, tex, c_off);
-}
-
 // Occupancy of the grids (hr_mask.h): one thread per lattice point, z fastest -- neighbouring threads read neighbouring
 // line texels and the same plane texel rows.  8 M points (200^3) x 16 density channels x 6 taps: a few hundred microseconds,
 // twice per training run (update_AlphaMask_list).
