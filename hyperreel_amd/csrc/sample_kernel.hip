@@ -93,23 +93,20 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
 #endif
     // few samples x many head columns can exceed the 64 KiB a kernel gets by default (e.g. 32 rays x 8 x 64 floats)
     const bool big_lds = lds > 64 * 1024;
-    // the shipped [8, 4, 4] / [8, 0, 0] decompositions with fp32 texels get the class-specialised gather (sample_core.inc); ZP >= 8
+    // the shipped [8, 4, 4] / [8, 0, 0] decompositions get the class-specialised gather of their texel format (sample_core.inc); ZP >= 8
     // keeps a quad inside one ray, video nets additionally need two keyframes
     const int pclass = (args.rows_out == nullptr && (!cfg.video || cfg.num_keyframes >= 2)) ? hr_plane_class(args.planes, 0, args.ca_total) : 0;
+#define HR_LAUNCH_SAMPLES_T(Z_, H_, P_) \
+    do { \
+        if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, H_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((hr_sample_kernel<Z_, H_, P_>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+    } while (0)
 #define HR_LAUNCH_SAMPLES(Z_) \
     do { \
         if (cfg.grid_dtype == HR_GRID_FP16) { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, true, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
-        } else if (pclass == 1) { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 1>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
-        } else if (pclass == 2) { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 2>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+            if (pclass == 1) HR_LAUNCH_SAMPLES_T(Z_, true, 1); else if (pclass == 2) HR_LAUNCH_SAMPLES_T(Z_, true, 2); else HR_LAUNCH_SAMPLES_T(Z_, true, 0); \
         } else { \
-            if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((hr_sample_kernel<Z_, false, 0>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+            if (pclass == 1) HR_LAUNCH_SAMPLES_T(Z_, false, 1); else if (pclass == 2) HR_LAUNCH_SAMPLES_T(Z_, false, 2); else HR_LAUNCH_SAMPLES_T(Z_, false, 0); \
         } \
     } while (0)
     switch (ZP) {
@@ -122,4 +119,5 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
         default: break;  // Z > 256 is rejected by hr_model_create
     }
 #undef HR_LAUNCH_SAMPLES
+#undef HR_LAUNCH_SAMPLES_T
 }

@@ -76,7 +76,7 @@ def main():
                   f'b.planes[{j}].a = a.planes[{j}].a; b.planes[{j}].b = a.planes[{j}].b;')
         app_off += 4 * ca4; real_off += na
     nd_, na_ = list(hc.n_den)[:3], list(hc.n_app)[:3]
-    pclass = 0 if half else (1 if (nd_ == [8, 4, 4] and na_ == [8, 4, 4]) else (2 if (nd_ == [8, 0, 0] and na_[0] == 8) else 0))
+    pclass = 1 if (nd_ == [8, 4, 4] and na_ == [8, 4, 4]) else (2 if (nd_ == [8, 0, 0] and na_[0] == 8) else 0)
     src = f'''#define HR_PHASE_MARK
 #include "{B.CSRC}/sample_core.inc"
 __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
