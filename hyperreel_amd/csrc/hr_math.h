@@ -570,6 +570,24 @@ HR_FN hr_axis_tap_c hr_make_tap_c(float g, int n)
     return t;
 }
 
+// hr_make_tap_c for a coordinate that hr_sample_valid has let through (or the centre, 0, that masked samples are given): the
+// point is inside the aabb, so ix lies in [0, n - 1] up to rounding and floor(ix) is one of -1, 0, .., n - 1 -- the three
+// cases below.  Bit for bit the weights of hr_make_tap_c on that domain (tests/test_host_math.py), 7 instructions fewer per axis.
+HR_FN hr_axis_tap_c hr_make_tap_in(float g, int n)
+{
+    const float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+    const float f0 = floorf(ix);
+    const float f1 = f0 + 1.0f;
+    const int i0 = (int)f0;
+    const float a = f1 - ix, b = ix - f0;
+    const bool lo = i0 < 0, hi = i0 > n - 2;
+    hr_axis_tap_c t;
+    t.i0 = lo ? 0 : (hi ? n - 2 : i0);
+    t.w0 = lo ? b : (hi ? 0.0f : a);            // floor == -1: the only tap in range is texel 0, reached as the base
+    t.w1 = lo ? 0.0f : (hi ? a : b);            // floor == n - 1: the only tap in range is texel n - 1, reached as base + 1
+    return t;
+}
+
 // ---------------------------------------------------------------- display pack
 // to8b (utils/__init__.py:47): (255 * clip(x, 0, 1)).astype(uint8) -- the product is formed in fp32 and truncated
 HR_FN uint8_t hr_to8b(float x)

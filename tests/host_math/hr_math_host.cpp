@@ -64,6 +64,15 @@ void hm_taps_c(const float* g, int n, int size, int* i0, float* w0, float* w1)
     }
 }
 
+// the in-range form the render kernels use for coordinates of valid samples
+void hm_taps_in(const float* g, int n, int size, int* i0, float* w0, float* w1)
+{
+    for (int i = 0; i < n; ++i) {
+        hr_axis_tap_c t = hr_make_tap_in(g[i], size);
+        i0[i] = t.i0; w0[i] = t.w0; w1[i] = t.w1;
+    }
+}
+
 void hm_sh(const float* d, int n, float* out)
 {
     for (int i = 0; i < n; ++i) hr_sh_deg2(d[3 * i], d[3 * i + 1], d[3 * i + 2], out + 9 * i);

@@ -224,3 +224,22 @@ def test_clamped_taps_give_the_same_lerp_bit_for_bit(hm):
         ref = (v[i0] * w0) + (v[i1] * w1)              # fp32 products and sum, like the kernels' fma chain up to the zero terms
         got = (v[c0] * cw0) + (v[c0 + 1] * cw1)
         assert np.array_equal(ref, got), size
+
+
+def test_in_range_taps_equal_the_clamped_taps_where_a_valid_sample_can_be(hm):
+    """hr_make_tap_in (three cases instead of the general border logic) against hr_make_tap_c for every coordinate whose
+    floor(ix) is -1 .. n-1: inside the aabb, on both faces, and the few ulps beyond them that rounding can produce."""
+    rng = np.random.default_rng(6)
+    for size in (2, 3, 7, 64, 600, 640, 1007):
+        edge = [np.float32(-1.0), np.float32(1.0), np.float32(0.0)]
+        for _ in range(6):
+            edge += [np.nextafter(edge[-3], np.float32(-4.0)), np.nextafter(edge[-2], np.float32(4.0)), np.float32(0.0)]
+        lim = 1.0 + 1.9 / (size - 1)                       # floor(ix) stays within [-1, n-1]
+        g = np.concatenate([rng.uniform(-1.0, 1.0, 6000), rng.uniform(-lim, lim, 2000), rng.uniform(0.999, 1.0, 500), rng.uniform(-1.0, -0.999, 500),
+                            np.array(edge, np.float64)]).astype(np.float32)
+        n = g.size
+        a0, b0 = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        aw0, aw1, bw0, bw1 = (np.zeros(n, np.float32) for _ in range(4))
+        hm.hm_taps_c(fp(g), n, size, a0.ctypes.data_as(IP), fp(aw0), fp(aw1))
+        hm.hm_taps_in(fp(g), n, size, b0.ctypes.data_as(IP), fp(bw0), fp(bw1))
+        assert np.array_equal(a0, b0) and np.array_equal(aw0.view(np.int32), bw0.view(np.int32)) and np.array_equal(aw1.view(np.int32), bw1.view(np.int32)), size
