@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
 SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'fused_bf16x3_kernel.hip', 'fused_f16x3_kernel.hip', 'fused_f16x2_kernel.hip',
            'sample_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_gemm_kernel.hip']
 # compiled only into measurement variants (tools/build_variant.py <name> -D<flag>): the flag that enables them in api.hip -> sources
-EXPERIMENT_SOURCES = {'-DHR_WITH_REG_KERNEL': ['mlp_reg_bf16x3_kernel.hip', 'mlp_reg_f16x3_kernel.hip', 'mlp_reg_f16x2_kernel.hip']}
+EXPERIMENT_SOURCES = {'-DHR_WITH_REG_KERNEL': ['mlp_reg_bf16x3_kernel.hip', 'mlp_reg_f16x3_kernel.hip', 'mlp_reg_f16x2_kernel.hip'],
+                      '-DHR_WITH_F16F8': ['mlp_f16f8_kernel.hip']}
 HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'mlp_reg_impl.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by

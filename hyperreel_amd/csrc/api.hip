@@ -60,6 +60,7 @@ struct hr_model {
     // packed MLP
     float4* wpack[HR_MAX_LAYERS] = {};
     void* wsplit[HR_MAX_LAYERS] = {};
+    void* wf8[HR_MAX_LAYERS] = {};         // HR_MLP_F16F8: fp8 tiles of the hidden segments' cross terms (mlp_split_core.inc)
     float* bias[HR_MAX_LAYERS] = {};
     float winv[HR_MAX_LAYERS] = {};       // 2^-s of the packed split weights (HrMlpArgs::winv)
     int n_tiles[HR_MAX_LAYERS] = {};
@@ -188,7 +189,12 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
+#ifdef HR_WITH_F16F8
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16F8) return fail(HR_E_INVALID, "unknown mlp_precision");
+#else
+    if (c.mlp_precision == HR_MLP_F16F8) return fail(HR_E_INVALID, "mlp_precision f16f8 is experimental: not in this build of the library");
     if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X2) return fail(HR_E_INVALID, "unknown mlp_precision");
+#endif
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -278,6 +284,30 @@ uint16_t bf16_rne(float f)
 }
 
 // float -> IEEE half bits and back (round to nearest even; overflow -> inf like the hardware conversion)
+// OCP e4m3fn (1-4-3, bias 7, no infinity, max 448), round to nearest even, saturating
+uint8_t f8_e4m3_rne(float f)
+{
+    if (f != f) return 0x7f;
+    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+    float a = fabsf(f);
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < ldexpf(1.0f, -10)) return sign;                       // below half of the smallest subnormal (2^-9)
+    int e = 0;
+    (void)frexpf(a, &e);                                           // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                                 // a = 1.xxx * 2^E
+    if (E < -6) E = -6;                                            // subnormal range: fixed quantum 2^-9
+    const float q = ldexpf(1.0f, E - 3);                           // quantum: 3 mantissa bits
+    float n = nearbyintf(a / q);                                   // ties to even (default rounding mode)
+    float v = n * q;
+    if (v >= 448.0f) return sign | 0x7e;
+    if (v < ldexpf(1.0f, -6)) return sign | (uint8_t)n;            // subnormal: mantissa = n (n < 8)
+    int e2 = 0;
+    (void)frexpf(v, &e2);
+    const int E2 = e2 - 1;
+    const int mant = (int)(v / ldexpf(1.0f, E2 - 3)) - 8;
+    return sign | (uint8_t)(((E2 + 7) << 3) | mant);
+}
+
 uint16_t f16_rne(float f)
 {
     const _Float16 h = (_Float16)f;
@@ -474,7 +504,7 @@ int hr_model_finalize(hr_model* m)
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
         const bool split = (c.mlp_precision != HR_MLP_FP32);
-        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2);
+        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2 || c.mlp_precision == HR_MLP_F16F8);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -500,6 +530,7 @@ int hr_model_finalize(hr_model* m)
         };
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
+        free_dev(reinterpret_cast<float*&>(m->wf8[l]));
         free_dev(m->bias[l]);
         // fp16 modes: the weights of these MLPs are ~1/sqrt(fan_in), so the low half w - half(w) (~2^-12 w) would be a
         // subnormal half with an ABSOLUTE rounding error of 2^-25.  Packing w * 2^s (exact), with s putting the largest
@@ -546,6 +577,28 @@ int hr_model_finalize(hr_model* m)
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
             HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             m->packed_bytes += (int64_t)pk.size() * sizeof(uint16_t);
+#ifdef HR_WITH_F16F8
+            // f16f8: the hidden segment's cross-term operands as e4m3 bytes, per (64-wide block, tile) four 1 KB pieces
+            // [w_lo bytes 0-15][w_lo 16-31][w_hi 2^-12 0-15][w_hi 2^-12 16-31], lane-major; byte t of lane l <-> feature 32 tile + (l & 31),
+            // k = 64 kb + 32 (l >> 5) + t of the segment
+            if (c.mlp_precision == HR_MLP_F16F8 && !first && W == 256) {
+                const int k_seg = skip ? m->k0p : 0;
+                std::vector<uint8_t> p8((size_t)(W / 64) * nt * 4 * 64 * 16, 0);
+                for (int kb = 0; kb < W / 64; ++kb)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 32; ++j) {
+                                const float v = wk(32 * t + (lane & 31), k_seg + 64 * kb + 32 * (lane >> 5) + j) * wmul;
+                                const float hi = f16_to_float(f16_rne(v));
+                                const size_t piece = (((size_t)kb * nt + t) * 4 + (j >> 4)) * 64 + lane;
+                                p8[piece * 16 + (j & 15)] = f8_e4m3_rne(v - hi);
+                                p8[(piece + 2 * 64) * 16 + (j & 15)] = f8_e4m3_rne(hi * (1.0f / 4096.0f));
+                            }
+                HR_HIP(hipMalloc((void**)&m->wf8[l], p8.size()));
+                HR_HIP(hipMemcpy(m->wf8[l], p8.data(), p8.size(), hipMemcpyHostToDevice));
+                m->packed_bytes += (int64_t)p8.size();
+            }
+#endif
 #ifdef HR_WITH_REG_KERNEL
             // the same weights in the order the register-resident kernel consumes them (mlp_reg_impl.inc): per chunk
             // [k-step][tile of the pair][hi 1 KB, lo 1 KB]; hidden k-steps with the contraction index permuted inside the
@@ -794,6 +847,9 @@ static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
+#ifdef HR_WITH_F16F8
+    else if (c.mlp_precision == HR_MLP_F16F8) hr_launch_mlp_f16f8(c, a, st);       // two-kernel plan only (launch_frame: default branch)
+#endif
     else hr_launch_mlp(c, a, st);
 }
 
@@ -805,6 +861,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         a.wpack[l] = m->wpack[l];
         a.wsplit[l] = m->wsplit[l];
+        a.wf8[l] = m->wf8[l];
         a.bias[l] = m->bias[l];
         a.winv[l] = m->winv[l];
         a.n_tiles[l] = m->n_tiles[l];
@@ -1428,6 +1485,7 @@ void hr_model_destroy(hr_model* m)
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
+        free_dev(reinterpret_cast<float*&>(m->wf8[l]));
         free_dev(m->bias[l]);
     }
     free_dev(reinterpret_cast<float*&>(m->wstream));

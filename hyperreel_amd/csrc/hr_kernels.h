@@ -33,6 +33,7 @@ struct HrMlpArgs {
     float* head;                 // raw output of the last Linear, HQ layout (hr_head_index)
     const float4* wpack[HR_MAX_LAYERS];   // HR_MLP_FP32: fp32 tiles (16-column tiles)
     const void* wsplit[HR_MAX_LAYERS];    // HR_MLP_BF16X3: bf16 hi/lo tiles (32-feature tiles), see mlp_bf16x3_kernel.hip
+    const void* wf8[HR_MAX_LAYERS];       // HR_MLP_F16F8 (experimental): fp8 tiles of the hidden segments' cross terms, see mlp_split_core.inc
     const float* bias[HR_MAX_LAYERS];
     float winv[HR_MAX_LAYERS];   // split kernels: the packed weights of layer L are W * 2^s (fp16 modes: keeps the low halves out of
                                  //   the subnormal range); the epilogue multiplies the accumulator by winv = 2^-s (exact).  1 for bf16
@@ -96,6 +97,7 @@ void hr_launch_mlp_reg_bf16x3(const hr_config& cfg, const HrMlpArgs& args, int n
 void hr_launch_mlp_reg_f16x3(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
 void hr_launch_mlp_reg_f16x2(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
 void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
+void hr_launch_mlp_f16f8(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16 main product + fp8 cross terms (-DHR_WITH_F16F8 builds only)
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 // fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.
 // Returns false when the model does not fit it (nothing launched); probe: only answer.

@@ -97,7 +97,9 @@ enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
  * accumulation (needs mlp_hidden 256): bf16 halves (~2^-17 relative per product, fp32 range) or fp16 halves (~2^-22,
  * i.e. fp32-grade, but activations must stay below 65504); F16X2 additionally takes the weights as single halfs (two
  * products, 2^-12 relative weight rounding) */
-enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3 };
+enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
+       HR_MLP_F16F8 = 4 /* EXPERIMENTAL, measurement builds of the library only (hr_model_create returns HR_E_INVALID otherwise):
+                           fp16 main product, the two cross terms as fp8 (e4m3) MFMA products at twice the rate */ };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
