@@ -581,6 +581,26 @@ int hr_model_finalize(hr_model* m)
             // f16f8: the hidden segment's cross-term operands as e4m3 bytes, per (64-wide block, tile) four 1 KB pieces
             // [w_lo bytes 0-15][w_lo 16-31][w_hi 2^-12 0-15][w_hi 2^-12 16-31], lane-major; byte t of lane l <-> feature 32 tile + (l & 31),
             // k = 64 kb + 32 (l >> 5) + t of the segment
+#ifdef HR_F16F8_V2
+            // second cut (mlp_f16f8v2_kernel.hip): only w_lo is packed, per (block, tile) two 1 KB pieces; byte t of lane l <-> feature
+            // 32 tile + (l & 31), k = 64 kb + 16 (t >> 3) + 8 (l >> 5) + (t & 7): the k-order of the lane's four fp16 tiles of the block
+            if (c.mlp_precision == HR_MLP_F16F8 && !first && W == 256) {
+                const int k_seg = skip ? m->k0p : 0;
+                std::vector<uint8_t> p8((size_t)(W / 64) * nt * 2 * 64 * 16, 0);
+                for (int kb = 0; kb < W / 64; ++kb)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 32; ++j) {
+                                const float v = wk(32 * t + (lane & 31), k_seg + 64 * kb + 16 * (j >> 3) + 8 * (lane >> 5) + (j & 7)) * wmul;
+                                const float hi = f16_to_float(f16_rne(v));
+                                const size_t piece = (((size_t)kb * nt + t) * 2 + (j >> 4)) * 64 + lane;
+                                p8[piece * 16 + (j & 15)] = f8_e4m3_rne(v - hi);
+                            }
+                HR_HIP(hipMalloc((void**)&m->wf8[l], p8.size()));
+                HR_HIP(hipMemcpy(m->wf8[l], p8.data(), p8.size(), hipMemcpyHostToDevice));
+                m->packed_bytes += (int64_t)p8.size();
+            }
+#else
             if (c.mlp_precision == HR_MLP_F16F8 && !first && W == 256) {
                 const int k_seg = skip ? m->k0p : 0;
                 std::vector<uint8_t> p8((size_t)(W / 64) * nt * 4 * 64 * 16, 0);
@@ -598,6 +618,7 @@ int hr_model_finalize(hr_model* m)
                 HR_HIP(hipMemcpy(m->wf8[l], p8.data(), p8.size(), hipMemcpyHostToDevice));
                 m->packed_bytes += (int64_t)p8.size();
             }
+#endif
 #endif
 #ifdef HR_WITH_REG_KERNEL
             // the same weights in the order the register-resident kernel consumes them (mlp_reg_impl.inc): per chunk
