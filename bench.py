@@ -413,7 +413,7 @@ def main():
             # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
             # the frame's arithmetic) and quote the VALU issue fraction -- what actually limits it -- next to it
             fr_ms = time_stage(lambda: model.render(rays, out=rgb_tmp), reps)
-            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel'}[prec_name]
+            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel', 'f16f8': 'hr_frame_f16f8_kernel'}[prec_name]
             r_fr = {'kernel': fk, 'bound': 'mfma', 'achieved': round(flops / (fr_ms[0] * 1e-3) / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(flops / (fr_ms[0] * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': 1,
                     'avg_launch_ms': round(fr_ms[0], 4), 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {B} rays',

@@ -23,7 +23,7 @@ def experiment_sources(flags):
     """the extra translation units a measurement build with these -D flags needs"""
     out = [x for f in flags for x in EXPERIMENT_SOURCES.get(f, [])]
     if '-DHR_F16F8_V2' in flags:                      # second cut of the f16f8 kernel: same entry point, other file
-        out = ['mlp_f16f8v2_kernel.hip' if x == 'mlp_f16f8_kernel.hip' else x for x in out]
+        out = ['mlp_f16f8v2_kernel.hip' if x == 'mlp_f16f8_kernel.hip' else x for x in out] + ['fused_f16f8_kernel.hip']
     return out
 HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'mlp_reg_impl.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 

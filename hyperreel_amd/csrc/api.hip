@@ -977,6 +977,9 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
         case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+#if defined(HR_WITH_F16F8) && defined(HR_F16F8_V2)
+        case HR_MLP_F16F8: return hr_launch_frame_f16f8(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+#endif
         default: return false;          // the exact-fp32 MLP (v_mfma_f32_16x16x4_f32) keeps its own kernel
     }
 }

@@ -107,6 +107,8 @@ bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSa
                            hipStream_t stream);
 bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
                            hipStream_t stream);
+bool hr_launch_frame_f16f8(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
+                           hipStream_t stream);   // experimental builds only
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
 
