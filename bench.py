@@ -201,7 +201,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
-    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16x2', 'fp32', 'f16f8'],
+    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16x2', 'fp32'],
                     help="arithmetic of the MLP GEMMs: auto = 3-product fp16 split on MFMA (fp32-grade), or exact fp32 MFMA")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
@@ -315,7 +315,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rays / (dt / args.steps) / 1e6
-    prec_name = {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2', 4: 'f16f8'}[int(model._hc.mlp_precision)]
+    prec_name = {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2'}[int(model._hc.mlp_precision)]
     result = {
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -360,10 +360,9 @@ def main():
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
         split = prec_name != 'fp32'
-        mlp_kernel = {'bf16x3': 'hr_mlp_bf16x3_kernel', 'f16x3': 'hr_mlp_f16x3_kernel', 'f16x2': 'hr_mlp_f16x2_kernel', 'fp32': 'hr_mlp_kernel',
-                      'f16f8': 'hr_mlp_f16f8_kernel'}[prec_name]
+        mlp_kernel = {'bf16x3': 'hr_mlp_bf16x3_kernel', 'f16x3': 'hr_mlp_f16x3_kernel', 'f16x2': 'hr_mlp_f16x2_kernel', 'fp32': 'hr_mlp_kernel'}[prec_name]
         peak = MFMA_16BIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        n_prod = {'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'fp32': 1, 'f16f8': 2}[prec_name]      # f16f8: 1 + two fp8 products at twice the rate
+        n_prod = {'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'fp32': 1}[prec_name]
         r_mlp = {'kernel': mlp_kernel, 'bound': 'mfma',
                  'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
                  'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / peak, 4),
@@ -413,7 +412,7 @@ def main():
             # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
             # the frame's arithmetic) and quote the VALU issue fraction -- what actually limits it -- next to it
             fr_ms = time_stage(lambda: model.render(rays, out=rgb_tmp), reps)
-            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel', 'f16f8': 'hr_frame_f16f8_kernel'}[prec_name]
+            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel'}[prec_name]
             r_fr = {'kernel': fk, 'bound': 'mfma', 'achieved': round(flops / (fr_ms[0] * 1e-3) / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(flops / (fr_ms[0] * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': 1,
                     'avg_launch_ms': round(fr_ms[0], 4), 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {B} rays',
@@ -523,7 +522,6 @@ def main():
     result['mlp_gemm'] = {'bf16x3': 'bf16x3 split on MFMA, fp32 accumulate (raw head within 7e-6 of the fp32 chain)',
                           'f16x3': 'f16x3 split on MFMA: 11+11-bit halves, weights pre-scaled by an exact power of two, fp32 accumulate (raw head within 1e-6 of the fp32 chain)',
                           'f16x2': 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
-                          'f16f8': 'EXPERIMENTAL f16f8 on MFMA: fp16 main product + the two cross terms as e4m3 products, fp32 accumulate',
                           'fp32': 'fp32 MFMA'}[prec_name]
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same algorithm as stock
     #      PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda'; the reference itself cannot travel to the GPU

@@ -14,18 +14,7 @@ LIB_DIR = os.path.join(HERE, '_build')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
 SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'fused_bf16x3_kernel.hip', 'fused_f16x3_kernel.hip', 'fused_f16x2_kernel.hip',
            'sample_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_gemm_kernel.hip']
-# compiled only into measurement variants (tools/build_variant.py <name> -D<flag>): the flag that enables them in api.hip -> sources
-EXPERIMENT_SOURCES = {'-DHR_WITH_REG_KERNEL': ['mlp_reg_bf16x3_kernel.hip', 'mlp_reg_f16x3_kernel.hip', 'mlp_reg_f16x2_kernel.hip'],
-                      '-DHR_WITH_F16F8': ['mlp_f16f8_kernel.hip']}
-
-
-def experiment_sources(flags):
-    """the extra translation units a measurement build with these -D flags needs"""
-    out = [x for f in flags for x in EXPERIMENT_SOURCES.get(f, [])]
-    if '-DHR_F16F8_V2' in flags:                      # second cut of the f16f8 kernel: same entry point, other file
-        out = ['mlp_f16f8v2_kernel.hip' if x == 'mlp_f16f8_kernel.hip' else x for x in out] + ['fused_f16f8_kernel.hip']
-    return out
-HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'mlp_reg_impl.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
+HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by
 # operation (the reference never fuses a multiply with an add across torch ops); the

@@ -60,16 +60,11 @@ struct hr_model {
     // packed MLP
     float4* wpack[HR_MAX_LAYERS] = {};
     void* wsplit[HR_MAX_LAYERS] = {};
-    void* wf8[HR_MAX_LAYERS] = {};         // HR_MLP_F16F8: fp8 tiles of the hidden segments' cross terms (mlp_split_core.inc)
     float* bias[HR_MAX_LAYERS] = {};
     float winv[HR_MAX_LAYERS] = {};       // 2^-s of the packed split weights (HrMlpArgs::winv)
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
     int n_out = 0;
-    void* wstream = nullptr;              // register-resident MLP kernel: the split weights in consumption order (mlp_reg_impl.inc)
-    uint2* chunks = nullptr;              //   {first KB, KBs} per chunk, device
-    int n_chunks = 0;                     //   0: configuration not covered, the LDS-activation kernel runs
-    int opt_mlp_kernel = 0;               // HR_OPT_MLP_KERNEL: 1 = the register-resident kernel (measurement builds with -DHR_WITH_REG_KERNEL; slower)
     // packed grids
     float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
     float* grid_b[3] = {};
@@ -189,12 +184,7 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-#ifdef HR_WITH_F16F8
-    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16F8) return fail(HR_E_INVALID, "unknown mlp_precision");
-#else
-    if (c.mlp_precision == HR_MLP_F16F8) return fail(HR_E_INVALID, "mlp_precision f16f8 is experimental: not in this build of the library");
     if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X2) return fail(HR_E_INVALID, "unknown mlp_precision");
-#endif
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -284,30 +274,6 @@ uint16_t bf16_rne(float f)
 }
 
 // float -> IEEE half bits and back (round to nearest even; overflow -> inf like the hardware conversion)
-// OCP e4m3fn (1-4-3, bias 7, no infinity, max 448), round to nearest even, saturating
-uint8_t f8_e4m3_rne(float f)
-{
-    if (f != f) return 0x7f;
-    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
-    float a = fabsf(f);
-    if (a >= 448.0f) return sign | 0x7e;
-    if (a < ldexpf(1.0f, -10)) return sign;                       // below half of the smallest subnormal (2^-9)
-    int e = 0;
-    (void)frexpf(a, &e);                                           // a = m * 2^e, m in [0.5, 1)
-    int E = e - 1;                                                 // a = 1.xxx * 2^E
-    if (E < -6) E = -6;                                            // subnormal range: fixed quantum 2^-9
-    const float q = ldexpf(1.0f, E - 3);                           // quantum: 3 mantissa bits
-    float n = nearbyintf(a / q);                                   // ties to even (default rounding mode)
-    float v = n * q;
-    if (v >= 448.0f) return sign | 0x7e;
-    if (v < ldexpf(1.0f, -6)) return sign | (uint8_t)n;            // subnormal: mantissa = n (n < 8)
-    int e2 = 0;
-    (void)frexpf(v, &e2);
-    const int E2 = e2 - 1;
-    const int mant = (int)(v / ldexpf(1.0f, E2 - 3)) - 8;
-    return sign | (uint8_t)(((E2 + 7) << 3) | mant);
-}
-
 uint16_t f16_rne(float f)
 {
     const _Float16 h = (_Float16)f;
@@ -495,7 +461,6 @@ int hr_model_finalize(hr_model* m)
     int live_cols[64];
     for (int i = 0, j = 0; i < P_user; ++i)
         if (m->col_map.col[i] >= 0) live_cols[j++] = i;
-    std::vector<uint16_t> stream;          // weights for the register-resident kernel, all layers
     for (int l = 0; l < c.mlp_layers; ++l) {
         const bool last = (l == c.mlp_layers - 1);
         const int N_user = layer_out(c, l), Kt = layer_in(c, l);
@@ -504,7 +469,7 @@ int hr_model_finalize(hr_model* m)
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
         const bool split = (c.mlp_precision != HR_MLP_FP32);
-        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2 || c.mlp_precision == HR_MLP_F16F8);
+        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -530,7 +495,6 @@ int hr_model_finalize(hr_model* m)
         };
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
-        free_dev(reinterpret_cast<float*&>(m->wf8[l]));
         free_dev(m->bias[l]);
         // fp16 modes: the weights of these MLPs are ~1/sqrt(fan_in), so the low half w - half(w) (~2^-12 w) would be a
         // subnormal half with an ABSOLUTE rounding error of 2^-25.  Packing w * 2^s (exact), with s putting the largest
@@ -577,85 +541,6 @@ int hr_model_finalize(hr_model* m)
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
             HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             m->packed_bytes += (int64_t)pk.size() * sizeof(uint16_t);
-#ifdef HR_WITH_F16F8
-            // f16f8: the hidden segment's cross-term operands as e4m3 bytes, per (64-wide block, tile) four 1 KB pieces
-            // [w_lo bytes 0-15][w_lo 16-31][w_hi 2^-12 0-15][w_hi 2^-12 16-31], lane-major; byte t of lane l <-> feature 32 tile + (l & 31),
-            // k = 64 kb + 32 (l >> 5) + t of the segment
-#ifdef HR_F16F8_V2
-            // second cut (mlp_f16f8v2_kernel.hip): only w_lo is packed, per (block, tile) two 1 KB pieces; byte t of lane l <-> feature
-            // 32 tile + (l & 31), k = 64 kb + 16 (t >> 3) + 8 (l >> 5) + (t & 7): the k-order of the lane's four fp16 tiles of the block
-            if (c.mlp_precision == HR_MLP_F16F8 && !first && W == 256) {
-                const int k_seg = skip ? m->k0p : 0;
-                std::vector<uint8_t> p8((size_t)(W / 64) * nt * 2 * 64 * 16, 0);
-                for (int kb = 0; kb < W / 64; ++kb)
-                    for (int t = 0; t < nt; ++t)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 32; ++j) {
-                                const float v = wk(32 * t + (lane & 31), k_seg + 64 * kb + 16 * (j >> 3) + 8 * (lane >> 5) + (j & 7)) * wmul;
-                                const float hi = f16_to_float(f16_rne(v));
-                                const size_t piece = (((size_t)kb * nt + t) * 2 + (j >> 4)) * 64 + lane;
-                                p8[piece * 16 + (j & 15)] = f8_e4m3_rne(v - hi);
-                            }
-                HR_HIP(hipMalloc((void**)&m->wf8[l], p8.size()));
-                HR_HIP(hipMemcpy(m->wf8[l], p8.data(), p8.size(), hipMemcpyHostToDevice));
-                m->packed_bytes += (int64_t)p8.size();
-            }
-#else
-            if (c.mlp_precision == HR_MLP_F16F8 && !first && W == 256) {
-                const int k_seg = skip ? m->k0p : 0;
-                std::vector<uint8_t> p8((size_t)(W / 64) * nt * 4 * 64 * 16, 0);
-                for (int kb = 0; kb < W / 64; ++kb)
-                    for (int t = 0; t < nt; ++t)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 32; ++j) {
-                                const float v = wk(32 * t + (lane & 31), k_seg + 64 * kb + 32 * (lane >> 5) + j) * wmul;
-                                const float hi = f16_to_float(f16_rne(v));
-                                const size_t piece = (((size_t)kb * nt + t) * 4 + (j >> 4)) * 64 + lane;
-                                p8[piece * 16 + (j & 15)] = f8_e4m3_rne(v - hi);
-                                p8[(piece + 2 * 64) * 16 + (j & 15)] = f8_e4m3_rne(hi * (1.0f / 4096.0f));
-                            }
-                HR_HIP(hipMalloc((void**)&m->wf8[l], p8.size()));
-                HR_HIP(hipMemcpy(m->wf8[l], p8.data(), p8.size(), hipMemcpyHostToDevice));
-                m->packed_bytes += (int64_t)p8.size();
-            }
-#endif
-#endif
-#ifdef HR_WITH_REG_KERNEL
-            // the same weights in the order the register-resident kernel consumes them (mlp_reg_impl.inc): per chunk
-            // [k-step][tile of the pair][hi 1 KB, lo 1 KB]; hidden k-steps with the contraction index permuted inside the
-            // 16-block so that an accumulator quad IS the next layer's operand: slot (h, j) <-> 16 s + 8 (j >> 2) + 4 h + (j & 3)
-            if (W == 256) {
-                const int KIN = m->k0p / 16;
-                const bool two_products = (c.mlp_precision == HR_MLP_F16X2);
-                auto put_tile = [&](int tile, bool hidden, int ks) {
-                    const size_t base = stream.size();
-                    stream.resize(base + (two_products ? 512 : 1024), 0);
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int hh = lane >> 5;
-                            const int kk = hidden ? (skip ? m->k0p : 0) + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * ks + 8 * hh + j;
-                            const float v = wk(32 * tile + (lane & 31), kk) * wmul;
-                            const uint16_t hi = half ? f16_rne(v) : bf16_rne(v);
-                            stream[base + lane * 8 + j] = hi;
-                            if (!two_products) stream[base + 512 + lane * 8 + j] = half ? f16_rne(v - f16_to_float(hi)) : bf16_rne(v - bf16_to_float(hi));
-                        }
-                };
-                if (first) {
-                    for (int q = 0; q < 2; ++q)
-                        for (int kt = 0; kt < KIN; ++kt)
-                            for (int j = 0; j < 4; ++j) put_tile(4 * q + j, false, kt);
-                } else {
-                    for (int t0 = 0; t0 < nt; t0 += 2) {
-                        const int ntp = (t0 + 1 < nt) ? 2 : 1;
-                        if (skip)
-                            for (int kt = 0; kt < KIN; ++kt)
-                                for (int j = 0; j < ntp; ++j) put_tile(t0 + j, false, kt);
-                        for (int ks = 0; ks < 16; ++ks)
-                            for (int j = 0; j < ntp; ++j) put_tile(t0 + j, true, ks);
-                    }
-                }
-            }
-#endif
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
@@ -666,30 +551,6 @@ int hr_model_finalize(hr_model* m)
         m->packed_bytes += (int64_t)nb * sizeof(float);
     }
 
-#ifdef HR_WITH_REG_KERNEL
-    free_dev(reinterpret_cast<float*&>(m->wstream));
-    free_dev(reinterpret_cast<float*&>(m->chunks));
-    m->n_chunks = 0;
-    if (!stream.empty()) {
-        unsigned table[2 * 256];
-        int nc = 0;
-        if (c.mlp_precision == HR_MLP_BF16X3) nc = hr_reg_chunks_bf16x3(c, m->k0p, m->n_tiles, table, 256);
-        else if (c.mlp_precision == HR_MLP_F16X3) nc = hr_reg_chunks_f16x3(c, m->k0p, m->n_tiles, table, 256);
-        else if (c.mlp_precision == HR_MLP_F16X2) nc = hr_reg_chunks_f16x2(c, m->k0p, m->n_tiles, table, 256);
-        size_t kb = 0;
-        for (int i = 0; i < nc; ++i) kb += table[2 * i + 1];
-        if (nc > 0 && kb * 1024 == stream.size() * sizeof(uint16_t)) {
-            HR_HIP(hipMalloc((void**)&m->wstream, stream.size() * sizeof(uint16_t)));
-            HR_HIP(hipMemcpy(m->wstream, stream.data(), stream.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            HR_HIP(hipMalloc((void**)&m->chunks, nc * sizeof(uint2)));
-            HR_HIP(hipMemcpy(m->chunks, table, nc * sizeof(uint2), hipMemcpyHostToDevice));
-            m->n_chunks = nc;
-            m->packed_bytes += (int64_t)stream.size() * sizeof(uint16_t) + nc * sizeof(uint2);
-        } else if (nc > 0) {
-            return fail(HR_E_INVALID, "weight stream of %zu bytes does not match its chunk list (%zu KB)", stream.size() * sizeof(uint16_t), kb);
-        }
-    }
-#endif
 
     if (m->is_coarse) {      // coarse level of a cascade: no grids
         HR_HIP(hipDeviceSynchronize());
@@ -856,21 +717,10 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
 static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
-#ifdef HR_WITH_REG_KERNEL
-    if (m->opt_mlp_kernel && a.n_chunks > 0) {   // register-resident kernel (mlp_reg_impl.inc), measurement builds only
-        if (c.mlp_precision == HR_MLP_BF16X3) return hr_launch_mlp_reg_bf16x3(c, a, m->n_cus, st);
-        if (c.mlp_precision == HR_MLP_F16X3) return hr_launch_mlp_reg_f16x3(c, a, m->n_cus, st);
-        if (c.mlp_precision == HR_MLP_F16X2) return hr_launch_mlp_reg_f16x2(c, a, m->n_cus, st);
-    }
-#else
     (void)m;
-#endif
     if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else if (c.mlp_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
-#ifdef HR_WITH_F16F8
-    else if (c.mlp_precision == HR_MLP_F16F8) hr_launch_mlp_f16f8(c, a, st);       // two-kernel plan only (launch_frame: default branch)
-#endif
     else hr_launch_mlp(c, a, st);
 }
 
@@ -882,7 +732,6 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         a.wpack[l] = m->wpack[l];
         a.wsplit[l] = m->wsplit[l];
-        a.wf8[l] = m->wf8[l];
         a.bias[l] = m->bias[l];
         a.winv[l] = m->winv[l];
         a.n_tiles[l] = m->n_tiles[l];
@@ -891,9 +740,6 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.nq = (m->n_out + 3) / 4;
     a.k0p = m->k0p;
     a.trace = nullptr;
-    a.wstream = m->wstream;
-    a.chunks = m->chunks;
-    a.n_chunks = m->n_chunks;
 }
 
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
@@ -977,9 +823,6 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
         case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
-#if defined(HR_WITH_F16F8) && defined(HR_F16F8_V2)
-        case HR_MLP_F16F8: return hr_launch_frame_f16f8(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
-#endif
         default: return false;          // the exact-fp32 MLP (v_mfma_f32_16x16x4_f32) keeps its own kernel
     }
 }
@@ -1090,13 +933,6 @@ int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
     } else if (option == HR_OPT_SAMPLE_WAVES) {
         if (value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 4 or 8");
         m->opt_sample_waves = value;
-    } else if (option == HR_OPT_MLP_KERNEL) {
-        if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_MLP_KERNEL takes 0 or 1");
-#ifndef HR_WITH_REG_KERNEL
-        if (value == 1) return fail(HR_E_INVALID, "the register-resident MLP kernel is an experiment that is not part of this build (tools/build_variant.py reg -DHR_WITH_REG_KERNEL)");
-#endif
-        m->opt_mlp_kernel = value;
-        if (m->coarse) m->coarse->opt_mlp_kernel = value;
     } else {
         return fail(HR_E_INVALID, "unknown or read-only option %d", option);
     }
@@ -1108,11 +944,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (!m || !value) return fail(HR_E_INVALID, "null argument");
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
-    else if (option == HR_OPT_MLP_KERNEL) *value = m->opt_mlp_kernel;
-    else if (option == HR_OPT_MLP_KERNEL_ACTIVE) {
-        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
-        *value = (m->opt_mlp_kernel && m->n_chunks > 0) ? 1 : 0;
-    } else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
+    else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
     } else return fail(HR_E_INVALID, "unknown option %d", option);
@@ -1509,11 +1341,8 @@ void hr_model_destroy(hr_model* m)
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         free_dev(reinterpret_cast<float*&>(m->wpack[l]));
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
-        free_dev(reinterpret_cast<float*&>(m->wf8[l]));
         free_dev(m->bias[l]);
     }
-    free_dev(reinterpret_cast<float*&>(m->wstream));
-    free_dev(reinterpret_cast<float*&>(m->chunks));
     for (int j = 0; j < 3; ++j) {
         free_dev(m->grid_a[j]);
         free_dev(m->grid_b[j]);

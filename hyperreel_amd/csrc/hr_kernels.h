@@ -33,7 +33,6 @@ struct HrMlpArgs {
     float* head;                 // raw output of the last Linear, HQ layout (hr_head_index)
     const float4* wpack[HR_MAX_LAYERS];   // HR_MLP_FP32: fp32 tiles (16-column tiles)
     const void* wsplit[HR_MAX_LAYERS];    // HR_MLP_BF16X3: bf16 hi/lo tiles (32-feature tiles), see mlp_bf16x3_kernel.hip
-    const void* wf8[HR_MAX_LAYERS];       // HR_MLP_F16F8 (experimental): fp8 tiles of the hidden segments' cross terms, see mlp_split_core.inc
     const float* bias[HR_MAX_LAYERS];
     float winv[HR_MAX_LAYERS];   // split kernels: the packed weights of layer L are W * 2^s (fp16 modes: keeps the low halves out of
                                  //   the subnormal range); the epilogue multiplies the accumulator by winv = 2^-s (exact).  1 for bf16
@@ -42,9 +41,6 @@ struct HrMlpArgs {
     int nq;                      // ceil(n_out / 4)
     int k0p;                     // mlp_in padded to a multiple of 16
     unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
-    const void* wstream;         // register-resident kernel (mlp_reg_impl.inc): all layers' split weights in consumption order
-    const uint2* chunks;         //   {first KB, KBs} of each chunk of one tile's pass over the stream
-    int n_chunks;                //   0: the configuration is not covered by that kernel
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -88,16 +84,7 @@ void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stre
 //   W[n = 32*nt + (lane & 31)][k = 16*kt + 8*(lane >> 5) + 0..7], part 0 = hi (bf16(w)), 1 = lo (bf16(w - hi))
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_mlp_f16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // same layouts, fp16 halves
-// register-resident form (mlp_reg_impl.inc): activations in registers, weights streamed through an LDS ring, persistent.
-// hr_reg_chunks_*: the chunk list of the weight stream ({first KB, KBs} pairs; 0 = configuration not covered).
-int hr_reg_chunks_bf16x3(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
-int hr_reg_chunks_f16x3(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
-int hr_reg_chunks_f16x2(const hr_config& cfg, int k0p, const int* n_tiles, unsigned* out, int max_chunks);
-void hr_launch_mlp_reg_bf16x3(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
-void hr_launch_mlp_reg_f16x3(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
-void hr_launch_mlp_reg_f16x2(const hr_config& cfg, const HrMlpArgs& args, int n_cus, hipStream_t stream);
 void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
-void hr_launch_mlp_f16f8(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16 main product + fp8 cross terms (-DHR_WITH_F16F8 builds only)
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 // fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.
 // Returns false when the model does not fit it (nothing launched); probe: only answer.
@@ -107,8 +94,6 @@ bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSa
                            hipStream_t stream);
 bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
                            hipStream_t stream);
-bool hr_launch_frame_f16f8(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
-                           hipStream_t stream);   // experimental builds only
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
 

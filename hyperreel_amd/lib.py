@@ -15,7 +15,7 @@ ABI_VERSION = 18
 
 
 
-HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_KERNEL, HR_OPT_MLP_KERNEL_ACTIVE = 0, 1, 2, 3, 4
+HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE = 0, 1, 2
 
 
 class hr_train_tensors(C.Structure):

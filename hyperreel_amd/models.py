@@ -362,7 +362,7 @@ class HipLightfieldModel(nn.Module):
         self.cfg = cfg
         system = kwargs.get('system')
         self.dataset = kwargs['dataset'] if 'dataset' in kwargs else dataset_scalars_from_system(system)
-        # arithmetic of the MLP GEMMs: 'auto' | 'bf16x3' | 'fp32' (see plan.compile_config)
+        # arithmetic of the MLP GEMMs: 'auto' (= 'f16x3' where its fp16 range is proven at finalize, else 'bf16x3') | 'f16x3' | 'bf16x3' | 'f16x2' | 'fp32' (plan.compile_config)
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
         # execution plan of render() (hr_model_set_option): frame kernel on/off, its sample wavefronts (None: library default)
@@ -371,8 +371,6 @@ class HipLightfieldModel(nn.Module):
         self.use_occupancy = bool(kwargs.get('use_occupancy', False))
         self._occ_key = None
         self.frame_kernel = bool(kwargs.get('frame_kernel', True))
-        self._mlp_kernel_set = False
-        self.mlp_kernel = kwargs.get('mlp_kernel', 'lds')            # 'lds' | 'registers' (HR_OPT_MLP_KERNEL; the latter is an opt-in experiment)
         self.sample_waves = kwargs.get('sample_waves')
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
@@ -567,24 +565,14 @@ class HipLightfieldModel(nn.Module):
     def _apply_options(self):
         L = _lib.load()
         _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_FRAME_KERNEL, int(self.frame_kernel)), 'hr_model_set_option')
-        if self.mlp_kernel not in ('registers', 'lds'):
-            raise ValueError(f"mlp_kernel must be 'registers' or 'lds', not {self.mlp_kernel!r}")
-        if self.mlp_kernel == 'registers':     # an experiment that only measurement builds of the library contain
-            _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_MLP_KERNEL, 1), 'hr_model_set_option')
-        elif self._mlp_kernel_set:
-            _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_MLP_KERNEL, 0), 'hr_model_set_option')
         if self.sample_waves is not None:
             _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_SAMPLE_WAVES, int(self.sample_waves)), 'hr_model_set_option')
 
-    def set_execution(self, frame_kernel=None, sample_waves=None, mlp_kernel=None):
+    def set_execution(self, frame_kernel=None, sample_waves=None):
         """Chooses how render() is laid out on the device (images are bit-identical under every setting):
-        frame_kernel False = always the two-kernel path through the HBM workspace; sample_waves 4 | 8; mlp_kernel
-        'registers' | 'lds' = which kernel evaluates the MLP on the two-kernel path."""
+        frame_kernel False = always the two-kernel path through the HBM workspace; sample_waves 4 | 8."""
         if frame_kernel is not None:
             self.frame_kernel = bool(frame_kernel)
-        if mlp_kernel is not None:
-            self.mlp_kernel = mlp_kernel
-            self._mlp_kernel_set = True
         if sample_waves is not None:
             self.sample_waves = int(sample_waves)
         if self._native is not None:
@@ -595,13 +583,6 @@ class HipLightfieldModel(nn.Module):
         import ctypes as C
         v = C.c_int32(0)
         _lib.check(_lib.load().hr_model_get_option(self.native(), _lib.HR_OPT_FRAME_KERNEL_ACTIVE, C.byref(v)), 'hr_model_get_option')
-        return bool(v.value)
-
-    def mlp_kernel_active(self):
-        """True when the register-resident MLP kernel (csrc/mlp_reg_impl.inc) covers this model and is selected."""
-        import ctypes as C
-        v = C.c_int32(0)
-        _lib.check(_lib.load().hr_model_get_option(self.native(), _lib.HR_OPT_MLP_KERNEL_ACTIVE, C.byref(v)), 'hr_model_get_option')
         return bool(v.value)
 
     def reserve(self, rays_per_chunk):

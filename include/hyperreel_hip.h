@@ -97,9 +97,7 @@ enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
  * accumulation (needs mlp_hidden 256): bf16 halves (~2^-17 relative per product, fp32 range) or fp16 halves (~2^-22,
  * i.e. fp32-grade, but activations must stay below 65504); F16X2 additionally takes the weights as single halfs (two
  * products, 2^-12 relative weight rounding) */
-enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
-       HR_MLP_F16F8 = 4 /* EXPERIMENTAL, measurement builds of the library only (hr_model_create returns HR_E_INVALID otherwise):
-                           fp16 main product, the two cross terms as fp8 (e4m3) MFMA products at twice the rate */ };
+enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
@@ -272,15 +270,8 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         non-NULL `fields`, take the two-kernel path.  0: always two kernels per chunk of rays -- the MLP
  *                         writes the head to an HBM workspace, the sample kernel reads it back.
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8.
- *   HR_OPT_MLP_KERNEL     which kernel evaluates BaseMLP.forward (nlf/nets/mlp.py:159-172) on the two-kernel path when the
- *                         arithmetic is one of the split-precision modes.  0 (default): activations in LDS, weights from L2
- *                         (csrc/mlp_split_core.inc).  1: activations stay in the register file across layers, the weights
- *                         stream through an LDS ring (csrc/mlp_reg_impl.inc) -- same products, the contraction index is
- *                         permuted inside 16-blocks, heads agree to 1e-6 of max |head|; measured slower: an
- *                         experiment that only measurement builds contain (-DHR_WITH_REG_KERNEL); elsewhere 1 is HR_E_INVALID.
- * hr_model_get_option(HR_OPT_FRAME_KERNEL_ACTIVE) answers whether hr_render currently takes the frame kernel, and
- * HR_OPT_MLP_KERNEL_ACTIVE whether the register-resident MLP kernel covers the model (both read-only). */
-enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_KERNEL = 3, HR_OPT_MLP_KERNEL_ACTIVE = 4 };
+ * hr_model_get_option(HR_OPT_FRAME_KERNEL_ACTIVE) answers whether hr_render currently takes the frame kernel (read-only). */
+enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

@@ -131,3 +131,16 @@ def port_leaves(port):
         out[f'model.embedding_model.embeddings.0.net.layers.{mid}.weight'] = w
         out[f'model.embedding_model.embeddings.0.net.layers.{mid}.bias'] = b
     return out
+
+
+def build_host_lib(out, src, deps):
+    """g++ -shared of a host restatement, safe under pytest-xdist: one builder at a time (flock), the library appears atomically."""
+    import fcntl, subprocess
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out + '.lock', 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            tmp = f'{out}.{os.getpid()}.tmp'
+            subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', tmp, src], check=True)
+            os.replace(tmp, out)
+    return out

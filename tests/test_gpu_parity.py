@@ -37,7 +37,7 @@ def fns():
     torch.cuda.empty_cache()
 
 
-PRECISIONS = ['bf16x3', 'f16x3', 'fp32']   # the shipped default (split-bf16 MFMA), the fp16 split, the exact fp32 MFMA path
+PRECISIONS = ['bf16x3', 'f16x3', 'fp32']   # the bf16 split (fp32 exponent range), the fp16 split (what 'auto' picks), the exact fp32 MFMA path
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import Golden, golden_cases, linf, sweep_cases
+from helpers import Golden, build_host_lib, golden_cases, linf, sweep_cases
 from hyperreel_amd import plan
 from hyperreel_oracle import HyperReelOracle, eval_sh_bases_deg2, grid_sample_2d
 
@@ -27,11 +27,9 @@ def fp(a):
 
 @pytest.fixture(scope='module')
 def hm():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     deps = [SRC, os.path.join(HERE, '..', 'hyperreel_amd', 'csrc', 'hr_math.h'),
             os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
-    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-        subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', OUT, SRC], check=True)
+    build_host_lib(OUT, SRC, deps)
     lib = C.CDLL(OUT)
     lib.hm_normalize_time.restype = C.c_float
     lib.hm_normalize_time.argtypes = [C.c_void_p, C.c_float]

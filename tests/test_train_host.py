@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, trainable_sweep_cases
+from helpers import Golden, build_host_lib, trainable_sweep_cases
 from hyperreel_amd import plan
 from torch_port import TorchPort
 
@@ -30,10 +30,8 @@ class GridPlane(C.Structure):          # mirrors HrGridPlane (hyperreel_amd/csrc
 
 @pytest.fixture(scope='module')
 def ht():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     deps = [SRC] + [os.path.join(CSRC, f) for f in ('hr_train.h', 'hr_mask.h', 'hr_math.h', 'hr_grid.h')] + [os.path.join(HERE, '..', 'include', 'hyperreel_hip.h')]
-    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-        subprocess.run(['g++', '-O1', '-ffp-contract=off', '-fno-fast-math', '-shared', '-fPIC', '-o', OUT, SRC], check=True)
+    build_host_lib(OUT, SRC, deps)
     lib = C.CDLL(OUT)
     lib.ht_unsupported.restype = C.c_char_p
     assert lib.ht_sizeof_plane() == C.sizeof(GridPlane)

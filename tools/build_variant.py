@@ -16,7 +16,7 @@ def main(name, extra):
         subprocess.run([B.hipcc(), *B.FLAGS, *extra, '-c', os.path.join(B.CSRC, s), '-o', o], check=True)
         return o
     with ThreadPoolExecutor(8) as ex:
-        objs = list(ex.map(one, list(B.SOURCES) + B.experiment_sources(extra)))
+        objs = list(ex.map(one, list(B.SOURCES)))
     lib = os.path.join(out, f'libhr_{name}.so')
     subprocess.run([B.hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib], check=True)
     print(lib)

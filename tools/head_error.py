@@ -1,5 +1,5 @@
 """Raw-head error of the split-precision MLP modes against the exact fp32-MFMA mode, on rays of the benchmark frame:
-python tools/head_error.py <model> [n_rays] [extra modes, e.g. f16f8 with HR_LIB=tools/_bin/libhr_f16f8.so].  Measurement aid (GPU)."""
+python tools/head_error.py <model> [n_rays] [extra modes].  Measurement aid (GPU)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
