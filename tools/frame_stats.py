@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hyperreel_amd import lib
-lib.LIB_PATH = os.path.join(ROOT, 'tools', '_bin', 'libhr_tuning.so')
+lib.LIB_PATH = os.environ.get('HR_LIB') or os.path.join(ROOT, 'tools', '_bin', 'libhr_tuning.so')
 from hyperreel_amd import config as C, scenes
 from hyperreel_amd.render import build_render_fn
 
