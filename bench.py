@@ -315,7 +315,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rays / (dt / args.steps) / 1e6
-    prec_name = {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2'}[int(model._hc.mlp_precision)]
+    prec_name = model.mlp_precision_active()      # 'auto' resolved by the library's activation-range calibration (hr_model_finalize)
     result = {
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -65,6 +65,11 @@ struct hr_model {
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
     int n_out = 0;
+    int active_precision = HR_MLP_FP32;   // the arithmetic the MLP kernels run: cfg.mlp_precision, with HR_MLP_AUTO resolved (resolve_precision)
+    float act_max[HR_MAX_LAYERS] = {};    // calibration: max |input feature|, max |pre-activation| of hidden Linear l - 1
+    int calibrated = 0;                   // 0: not calibrated (cascade rows / unsupported width), 1: synthetic rays (finalize), 2: the caller's rays
+    unsigned* flags = nullptr;            // sticky device status word (HrMlpArgs::flags)
+    int64_t mlp_bytes = 0;
     // packed grids
     float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
     float* grid_b[3] = {};
@@ -184,7 +189,7 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16X2) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_AUTO) return fail(HR_E_INVALID, "unknown mlp_precision");
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -438,21 +443,13 @@ int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes
     return HR_OK;
 }
 
-int hr_model_finalize(hr_model* m)
+// The MLP's weights re-laid out for the active arithmetic (m->active_precision).  Called by hr_model_finalize and again by
+// hr_model_calibrate when the calibration changes that choice.
+static int pack_mlp(hr_model* m)
 {
-    if (!m) return fail(HR_E_INVALID, "null argument");
-    if (m->coarse) {
-        int rc = hr_model_finalize(m->coarse);
-        if (rc != HR_OK) return rc;
-    }
     const hr_config& c = m->cfg;
-    for (auto& kv : m->expect)
-        if (m->raw.find(kv.first) == m->raw.end())
-            return fail(HR_E_MISSING, "tensor '%s%s' was never uploaded", (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? "mlp1." : "",
-                        (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? kv.first.c_str() + 4 : kv.first.c_str());
-    m->packed_bytes = 0;
     char name[64];
-
+    m->mlp_bytes = 0;
     // ---- MLP: MFMA B-operand tiles (layout documented in hr_kernels.h)
     const int W = c.mlp_hidden;
     m->k0p = (c.mlp_in + 15) & ~15;
@@ -468,8 +465,8 @@ int hr_model_finalize(hr_model* m)
         const bool first = (l == 0);
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
-        const bool split = (c.mlp_precision != HR_MLP_FP32);
-        const bool half = (c.mlp_precision == HR_MLP_F16X3 || c.mlp_precision == HR_MLP_F16X2);
+        const bool split = (m->active_precision != HR_MLP_FP32);
+        const bool half = (m->active_precision == HR_MLP_F16X3 || m->active_precision == HR_MLP_F16X2);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -523,7 +520,7 @@ int hr_model_finalize(hr_model* m)
                             pk[(((size_t)kt * nt + t) * 64 + lane) * 4 + s] = wk(16 * t + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
             HR_HIP(hipMalloc((void**)&m->wpack[l], pk.size() * sizeof(float)));
             HR_HIP(hipMemcpy(m->wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-            m->packed_bytes += (int64_t)pk.size() * sizeof(float);
+            m->mlp_bytes += (int64_t)pk.size() * sizeof(float);
         } else {
             // hi = bf16(w), lo = bf16(w - hi), both round-to-nearest-even (layout: hr_kernels.h)
             std::vector<uint16_t> pk((size_t)(Kp / 16) * nt * 2 * 64 * 8, 0);
@@ -540,7 +537,7 @@ int hr_model_finalize(hr_model* m)
                         }
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
             HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            m->packed_bytes += (int64_t)pk.size() * sizeof(uint16_t);
+            m->mlp_bytes += (int64_t)pk.size() * sizeof(uint16_t);
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
@@ -548,9 +545,112 @@ int hr_model_finalize(hr_model* m)
         HR_HIP(hipMalloc((void**)&m->bias[l], nb * sizeof(float)));
         HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         m->n_tiles[l] = nt;
-        m->packed_bytes += (int64_t)nb * sizeof(float);
+        m->mlp_bytes += (int64_t)nb * sizeof(float);
     }
+    return HR_OK;
+}
 
+// largest activation a model may show in calibration for the fp16 split arithmetic to be used: a factor 8 below the IEEE-half maximum,
+// because calibration sees 4096 rays and a frame has 640 000
+static const float HR_F16_CALIBRATION_LIMIT = 65504.0f / 8.0f;
+
+// Activation range of the MLP on `rays_dev` (NULL: 4096 synthetic rays -- origins uniform in the scene box, unit directions,
+// times in [0, 1)) -> m->act_max, then the arithmetic: HR_MLP_AUTO becomes f16x3 when every input feature and hidden activation
+// stays below HR_F16_CALIBRATION_LIMIT and bf16x3 (fp32 exponent range) otherwise; a FORCED fp16 mode that fails the test is an error.
+static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipStream_t st)
+{
+    const hr_config& c = m->cfg;
+    const int want = c.mlp_precision;
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) m->act_max[l] = 0.0f;
+    m->calibrated = 0;
+    if (c.mlp_layers == 0 || want == HR_MLP_FP32 || want == HR_MLP_BF16X3) {
+        m->active_precision = (c.mlp_layers == 0 && want == HR_MLP_AUTO) ? HR_MLP_F16X3 : want;
+        return HR_OK;
+    }
+    if (want == HR_MLP_AUTO && c.mlp_hidden != 256) {        // the split kernels are written for 256-wide layers
+        m->active_precision = HR_MLP_FP32;
+        return HR_OK;
+    }
+    if (!hr_mlp_range_supported(c))
+        return fail(HR_E_INVALID, "activation-range calibration does not cover mlp_in %d / mlp_hidden %d", c.mlp_in, c.mlp_hidden);
+    float* synth = nullptr;
+    float* d_max = nullptr;
+    if (!rays_dev) {
+        n = 4096;
+        HR_HIP(hipMalloc((void**)&synth, sizeof(float) * n * (m->coarse ? c.casc_row_dim : c.ray_dim)));
+        // where rays start: the model's own box, or (cascade rows, whose first columns are points) the same box
+        hr_launch_synthetic_rays(synth, n, m->coarse ? c.casc_row_dim : c.ray_dim, c.aabb, c.aabb + 3, 0x5eedu, st);
+        rays_dev = synth;
+    }
+    HR_HIP(hipMalloc((void**)&d_max, sizeof(float) * HR_MAX_LAYERS));
+    HR_HIP(hipMemsetAsync(d_max, 0, sizeof(float) * HR_MAX_LAYERS, st));
+    HrRangeArgs ra;
+    ra.rays = rays_dev;
+    ra.n_rays = n;
+    ra.act_max = d_max;
+    char name[64];
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+        ra.w[l] = ra.b[l] = nullptr;
+        if (l < c.mlp_layers) {
+            snprintf(name, sizeof(name), "mlp.%d.weight", l);
+            ra.w[l] = m->raw[name].p;
+            snprintf(name, sizeof(name), "mlp.%d.bias", l);
+            ra.b[l] = m->raw[name].p;
+        }
+    }
+    hr_config kc = m->kcfg;
+    if (m->coarse) kc.ray_dim = c.casc_row_dim;              // the point MLP's "rays" are the rows (launch_cascade_front)
+    hr_launch_mlp_range(kc, ra, st);
+    hipError_t e = hipMemcpyAsync(m->act_max, d_max, sizeof(float) * HR_MAX_LAYERS, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_max);
+    if (synth) (void)hipFree(synth);
+    if (e != hipSuccess) return fail(HR_E_HIP, "activation-range calibration: %s", hipGetErrorString(e));
+    m->calibrated = synth ? 1 : 2;
+    float mx = 0.0f;
+    bool finite = true;
+    for (int l = 0; l < c.mlp_layers; ++l) {
+        if (!std::isfinite(m->act_max[l])) finite = false;
+        mx = fmaxf(mx, m->act_max[l]);
+    }
+    const bool fits = finite && mx < HR_F16_CALIBRATION_LIMIT;
+    if (want == HR_MLP_AUTO) {
+        m->active_precision = fits ? HR_MLP_F16X3 : HR_MLP_BF16X3;
+        return HR_OK;
+    }
+    if (!fits)
+        return fail(HR_E_RANGE, "mlp_precision %s was requested, but the MLP's activations reach %.4g on the calibration rays (limit %.4g = "
+                    "65504 / 8): IEEE-half operands would overflow.  Use HR_MLP_AUTO (falls back to bf16x3) or HR_MLP_BF16X3",
+                    want == HR_MLP_F16X3 ? "f16x3" : "f16x2", (double)mx, (double)HR_F16_CALIBRATION_LIMIT);
+    m->active_precision = want;
+    return HR_OK;
+}
+
+int hr_model_finalize(hr_model* m)
+{
+    if (!m) return fail(HR_E_INVALID, "null argument");
+    if (m->coarse) {
+        int rc = hr_model_finalize(m->coarse);
+        if (rc != HR_OK) return rc;
+    }
+    const hr_config& c = m->cfg;
+    for (auto& kv : m->expect)
+        if (m->raw.find(kv.first) == m->raw.end())
+            return fail(HR_E_MISSING, "tensor '%s%s' was never uploaded", (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? "mlp1." : "",
+                        (m->coarse && kv.first.compare(0, 4, "mlp.") == 0) ? kv.first.c_str() + 4 : kv.first.c_str());
+    m->packed_bytes = 0;
+    char name[64];
+
+    // ---- MLP: which arithmetic (the fp16 split needs every activation below 65504), then MFMA operand tiles
+    if (!m->flags) HR_HIP(hipMalloc((void**)&m->flags, sizeof(unsigned)));
+    HR_HIP(hipMemset(m->flags, 0, sizeof(unsigned)));
+    {
+        int rc = resolve_precision(m, nullptr, 0, nullptr);
+        if (rc != HR_OK) return rc;
+        rc = pack_mlp(m);
+        if (rc != HR_OK) return rc;
+        m->packed_bytes += m->mlp_bytes;
+    }
 
     if (m->is_coarse) {      // coarse level of a cascade: no grids
         HR_HIP(hipDeviceSynchronize());
@@ -662,6 +762,28 @@ int hr_model_finalize(hr_model* m)
 }
 
 // the configuration with every schedule-dependent constant blanked: what hr_model_update_config may not change
+int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float* act_max, void* stream)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_calibrate before hr_model_finalize");
+    if (m->coarse || m->is_coarse) return fail(HR_E_INVALID, "hr_model_calibrate: cascades are calibrated by hr_model_finalize (the point MLP's rows are internal)");
+    if (!rays_dev || n_rays <= 0) return fail(HR_E_INVALID, "hr_model_calibrate needs rays");
+    const int before = m->active_precision;
+    int rc = resolve_precision(m, rays_dev, n_rays, (hipStream_t)stream);
+    if (rc != HR_OK) { m->active_precision = before; return rc; }
+    HR_HIP(hipMemset(m->flags, 0, sizeof(unsigned)));
+    if (m->active_precision != before) {
+        m->packed_bytes -= m->mlp_bytes;
+        rc = pack_mlp(m);
+        if (rc != HR_OK) return rc;
+        m->packed_bytes += m->mlp_bytes;
+        HR_HIP(hipDeviceSynchronize());
+    }
+    if (act_max)
+        for (int l = 0; l < m->cfg.mlp_layers; ++l) act_max[l] = m->act_max[l];
+    return HR_OK;
+}
+
 static hr_config structure_of(const hr_config& in)
 {
     hr_config c = in;
@@ -717,10 +839,9 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
 static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
-    (void)m;
-    if (c.mlp_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
-    else if (c.mlp_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
-    else if (c.mlp_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
+    if (m->active_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
+    else if (m->active_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
+    else if (m->active_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
     else hr_launch_mlp(c, a, st);
 }
 
@@ -740,6 +861,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.nq = (m->n_out + 3) / 4;
     a.k0p = m->k0p;
     a.trace = nullptr;
+    a.flags = m->flags;
 }
 
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
@@ -819,7 +941,7 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
     HrSampleArgs sa;
     fill_sample_args(m, sa, rays, n, rgb);
     sa.head = nullptr;
-    switch (m->cfg.mlp_precision) {
+    switch (m->active_precision) {
         case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
         case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
@@ -944,7 +1066,21 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (!m || !value) return fail(HR_E_INVALID, "null argument");
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
-    else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
+    else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW) {
+        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
+        if (option == HR_OPT_MLP_PRECISION_ACTIVE) *value = m->active_precision;
+        else if (option == HR_OPT_MLP_CALIBRATED) *value = m->calibrated;
+        else {
+            unsigned f = 0;
+            HR_HIP(hipMemcpy(&f, m->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
+            if (m->coarse) {
+                unsigned g = 0;
+                HR_HIP(hipMemcpy(&g, m->coarse->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
+                f |= g;
+            }
+            *value = (int32_t)(f & 1u);
+        }
+    } else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
     } else return fail(HR_E_INVALID, "unknown option %d", option);
@@ -1350,6 +1486,7 @@ void hr_model_destroy(hr_model* m)
     free_dev(m->basis);
     free_dev(m->basis_t);
     free_dev(reinterpret_cast<float*&>(m->slot_col));
+    free_dev(reinterpret_cast<float*&>(m->flags));
     free_dev(m->head);
     free_dev(m->rows);
     free_dev(m->occ);

@@ -1,5 +1,6 @@
 // fp16 three-product instance of the fused frame kernel (fused_impl.inc); see mlp_f16x3_kernel.hip.
 #define HR_SPLIT_E _Float16
+#define HR_SPLIT_RANGE_CHECK 1      // IEEE-half operands: keep the sticky overflow bit (mlp_split_core.inc)
 #define HR_SPLIT_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define HR_FUSED_KERNEL hr_frame_f16x3_kernel
 #define HR_FUSED_LAUNCH hr_launch_frame_f16x3

@@ -41,6 +41,8 @@ struct HrMlpArgs {
     int nq;                      // ceil(n_out / 4)
     int k0p;                     // mlp_in padded to a multiple of 16
     unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
+    unsigned* flags;             // sticky status word of the model: bit 0 = an fp16-split kernel saw an input feature or hidden activation
+                                 //   at or beyond the IEEE-half range (HR_OPT_MLP_OVERFLOW)
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -94,6 +96,19 @@ bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSa
                            hipStream_t stream);
 bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
                            hipStream_t stream);
+
+// activation range of the MLP on a set of rays (range_kernel.hip): act_max[0] = max |input feature|, act_max[l + 1] = max |pre-activation|
+// of hidden Linear l; w / b: the uploaded reference-layout tensors (out, in) / (out)
+struct HrRangeArgs {
+    const float* rays;
+    int64_t n_rays;
+    const float* w[HR_MAX_LAYERS];
+    const float* b[HR_MAX_LAYERS];
+    float* act_max;              // [HR_MAX_LAYERS] floats, zeroed by the caller; atomically maximised
+};
+void hr_launch_mlp_range(const hr_config& cfg, const HrRangeArgs& a, hipStream_t stream);
+bool hr_mlp_range_supported(const hr_config& cfg);
+void hr_launch_synthetic_rays(float* rays, int64_t n, int ray_dim, const float lo[3], const float hi[3], unsigned seed, hipStream_t stream);
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
 

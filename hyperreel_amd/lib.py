@@ -11,11 +11,12 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 
-HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE = 0, 1, 2
+HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_PRECISION_ACTIVE, HR_OPT_MLP_OVERFLOW, HR_OPT_MLP_CALIBRATED = 0, 1, 2, 3, 4, 5
+HR_E_RANGE = -5
 
 
 class hr_train_tensors(C.Structure):
@@ -33,6 +34,7 @@ SYMBOLS = [
     ('hr_model_create_cascade', C.c_int, [C.POINTER(hr_config), C.POINTER(hr_config), C.POINTER(C.c_void_p)]),
     ('hr_model_upload', C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     ('hr_model_finalize', C.c_int, [C.c_void_p]),
+    ('hr_model_calibrate', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p]),
     ('hr_model_update_config', C.c_int, [C.c_void_p, C.POINTER(hr_config), C.c_void_p]),
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
     ('hr_model_set_option', C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -103,7 +105,12 @@ def load():
     return lib
 
 
+class HipRangeError(RuntimeError):
+    """HR_E_RANGE: a forced fp16 MLP arithmetic does not fit the model's activation range."""
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().hr_last_error()
-        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+        cls = HipRangeError if rc == HR_E_RANGE else RuntimeError
+        raise cls(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')

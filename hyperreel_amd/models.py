@@ -585,6 +585,31 @@ class HipLightfieldModel(nn.Module):
         _lib.check(_lib.load().hr_model_get_option(self.native(), _lib.HR_OPT_FRAME_KERNEL_ACTIVE, C.byref(v)), 'hr_model_get_option')
         return bool(v.value)
 
+    def _get_option(self, opt):
+        import ctypes as C
+        v = C.c_int32(0)
+        _lib.check(_lib.load().hr_model_get_option(self.native(), opt, C.byref(v)), 'hr_model_get_option')
+        return int(v.value)
+
+    def mlp_precision_active(self):
+        """The arithmetic the MLP kernels run ('auto' resolved by the library's activation-range calibration)."""
+        return {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2'}[self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)]
+
+    def mlp_overflowed(self):
+        """True when an fp16-split kernel saw an activation at the IEEE-half range on a rendered ray (sticky; synchronises)."""
+        return bool(self._get_option(_lib.HR_OPT_MLP_OVERFLOW))
+
+    def calibrate(self, rays):
+        """Re-decides the MLP arithmetic on the caller's rays (hr_model_calibrate); returns the per-layer activation maxima."""
+        import ctypes as C
+        self.native()
+        rays = self._check_rays(rays)
+        out = (C.c_float * 8)()
+        with torch.cuda.device(rays.device):
+            stream = C.c_void_p(torch.cuda.current_stream(rays.device).cuda_stream)
+            _lib.check(_lib.load().hr_model_calibrate(self.native(), C.c_void_p(rays.data_ptr()), rays.shape[0], out, stream), 'hr_model_calibrate')
+        return [float(v) for v in out[:int(self._hc.mlp_layers)]]
+
     def reserve(self, rays_per_chunk):
         L = _lib.load()
         _lib.check(L.hr_model_reserve(self.native(), int(rays_per_chunk)), 'hr_model_reserve')

@@ -266,7 +266,7 @@ class _Affine:
 
 
 # --------------------------------------------------------------------------- the compiler
-MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3}
+MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3, 'auto': 4}
 
 
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
@@ -683,15 +683,15 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         hc.time_offset = float(0.5 / K)
         if not hc.advect and not _coarse:
             raise NotImplementedError('video net without an advect_points stage (base_times)')
-    # GEMM arithmetic of the MLP.  'auto' = 'f16x3' when the kernel supports the width: three fp16 MFMA products of hi/lo
-    # split operands (11 + 11 mantissa bits, weights pre-scaled by an exact power of two), fp32 accumulate -- raw head
-    # within 1e-6 of the exact fp32 chain (bf16x3: 7e-6, same cost), which is what keeps the reference's threshold
-    # decisions (`dist <= near`, intersect/base.py:194-203) from flipping: on the 800x800 frames of the four benchmark
-    # families no ray of 131 072 is over the 1e-4 bar (tests/test_gpu_parity.py), where bf16x3 flips one sample per
-    # ~150 000 rays of the 64-sample keyframe model.  fp16 halves need activations below 65504 (LeakyReLU MLPs on
-    # positional encodings are O(1-10)); 'bf16x3' keeps the fp32 exponent range, 'fp32' is the exact fp32 MFMA.
+    # GEMM arithmetic of the MLP.  'auto' (HR_MLP_AUTO) lets the library choose when the kernel supports the width: 'f16x3' -- three
+    # fp16 MFMA products of hi/lo split operands (11 + 11 mantissa bits, weights pre-scaled by an exact power of two), fp32 accumulate,
+    # raw head within 1e-6 of the exact fp32 chain (bf16x3: 7e-6, same cost), which is what keeps the reference's threshold decisions
+    # (`dist <= near`, intersect/base.py:194-203) from flipping -- wherever hr_model_finalize's activation-range calibration shows the
+    # MLP's activations to stay below 65504 / 8 (fp16 halves saturate at 65504; the reference's BaseMLP is fp32, nlf/nets/mlp.py:127-172),
+    # and 'bf16x3' (fp32 exponent range) otherwise.  A forced 'f16x3' / 'f16x2' that fails the same test is refused by name
+    # (HR_E_RANGE).  'fp32' is the exact fp32 MFMA; other hidden widths only have that.
     if mlp_precision == 'auto' or hc.mlp_layers == 0:
-        mlp_precision = 'f16x3' if hc.mlp_hidden == 256 else 'fp32'
+        mlp_precision = 'auto' if hc.mlp_hidden == 256 else 'fp32'
     if mlp_precision in ('bf16x3', 'f16x3', 'f16x2') and hc.mlp_hidden != 256:
         raise NotImplementedError(f'{mlp_precision} MLP needs hidden_channels == 256')
     hc.mlp_precision = MLP_PRECISION[mlp_precision]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 18
+#define HR_ABI_VERSION 19
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -45,6 +45,7 @@ extern "C" {
 #define HR_E_STATE (-2)      /* call order: upload after finalize, render before finalize ... */
 #define HR_E_HIP (-3)        /* a HIP runtime call failed */
 #define HR_E_MISSING (-4)    /* finalize: a required tensor was never uploaded */
+#define HR_E_RANGE (-5)      /* finalize / calibrate: a forced fp16 MLP arithmetic would overflow on this model's activations */
 
 /* nlf/activations.py: Identity (:163-178), Sigmoid (:53-69), Tanh (:121-137).  y = act(x*inner+shift)*outer + add.
  * EaseValue (:462-496), w * act(x) + (1 - w) * start_value with the iteration-dependent weight w, is folded by the host
@@ -97,7 +98,12 @@ enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
  * accumulation (needs mlp_hidden 256): bf16 halves (~2^-17 relative per product, fp32 range) or fp16 halves (~2^-22,
  * i.e. fp32-grade, but activations must stay below 65504); F16X2 additionally takes the weights as single halfs (two
  * products, 2^-12 relative weight rounding) */
-enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3 };
+enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
+       /* the library chooses: f16x3 when an activation-range calibration of the uploaded weights (hr_model_finalize: 4096 synthetic
+        * rays; hr_model_calibrate: the caller's rays) keeps every input feature and hidden activation below 65504 / 8, bf16x3
+        * otherwise (fp32 when mlp_hidden != 256).  The same test makes a FORCED f16x3 / f16x2 fail with HR_E_RANGE instead of
+        * rendering infinities (the reference's BaseMLP is fp32, nlf/nets/mlp.py:127-172: any finite activation is legal there) */
+       HR_MLP_AUTO = 4 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
@@ -248,8 +254,16 @@ int hr_model_create_cascade(const hr_config* coarse, const hr_config* fine, hr_m
 int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes);
 
 /* Re-lays the uploaded tensors out for the kernels (channel-last interleaved planes,
- * MFMA-tiled MLP weights).  May be called again after further uploads. */
+ * MFMA-tiled MLP weights).  May be called again after further uploads.  For mlp_precision AUTO / F16X3 / F16X2 it first measures
+ * the MLP's activation range on 4096 synthetic rays (origins uniform in the model's aabb, unit directions) and resolves / checks
+ * the arithmetic (see HR_MLP_AUTO); HR_E_RANGE when a forced fp16 mode does not fit. */
 int hr_model_finalize(hr_model* m);
+
+/* The same decision on the caller's own rays (device memory, n_rays x ray_dim): measures the activation range of the MLP
+ * (BaseMLP.forward, nlf/nets/mlp.py:159-172, evaluated in plain fp32) on them, re-resolves HR_MLP_AUTO and re-packs the MLP
+ * weights if the choice changes.  Synchronises `stream`.  `act_max` (may be NULL) receives mlp_layers floats: the largest
+ * |input feature|, then the largest |pre-activation| of each hidden Linear.  HR_E_RANGE as for hr_model_finalize. */
+int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float* act_max, void* stream);
 
 /* Replaces the model's configuration by one that differs only in schedule-dependent constants -- the `outer` / `add`
  * of the activations (EaseValue), `pe_weight` (WindowedPE) and `isect_mask_off` (mask.stop_iters) -- as INRSystem.set_train_iter does for the reference
@@ -270,8 +284,12 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         non-NULL `fields`, take the two-kernel path.  0: always two kernels per chunk of rays -- the MLP
  *                         writes the head to an HBM workspace, the sample kernel reads it back.
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8.
- * hr_model_get_option(HR_OPT_FRAME_KERNEL_ACTIVE) answers whether hr_render currently takes the frame kernel (read-only). */
-enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2 };
+ * Read-only: HR_OPT_FRAME_KERNEL_ACTIVE whether hr_render currently takes the frame kernel; HR_OPT_MLP_PRECISION_ACTIVE the HR_MLP_*
+ * arithmetic the MLP kernels run (HR_MLP_AUTO resolved); HR_OPT_MLP_CALIBRATED 0 / 1 (finalize's synthetic rays) / 2 (hr_model_calibrate);
+ * HR_OPT_MLP_OVERFLOW the sticky bit the fp16-split kernels set when an input feature or hidden activation of a RENDERED ray reached
+ * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate). */
+enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
+       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

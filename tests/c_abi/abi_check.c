@@ -46,6 +46,7 @@ int main(void)
         if (hr_linear_workspace(0, 4, 4) != 0) return 22;
         if (hr_model_set_occupancy(NULL, NULL, n3, box, NULL) != HR_E_INVALID) return 23;
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
+        if (hr_model_calibrate(NULL, &x, 1, NULL, NULL) != HR_E_INVALID) return 24;
     }
     return 0;
 }

@@ -66,7 +66,7 @@ def test_compile_config_matches_oracle_constants(name):
     if hc.contract_type == 1:
         assert np.float32(hc.c_r0) == np.float32(orc.contract.r0)
         assert np.float32(hc.c_d_scale) == np.float32(1.0 / (1.0 - orc.contract.d0 / orc.contract.d1))
-    assert hc.mlp_precision == 2          # hidden 256 -> split-fp16 (f16x3) MFMA by default
+    assert hc.mlp_precision == 4          # hidden 256 -> HR_MLP_AUTO: the library picks f16x3 / bf16x3 from its activation-range calibration
     assert plan.compile_config(cfg, ds, grid, mlp_precision='fp32').mlp_precision == 0
 
 
