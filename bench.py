@@ -107,6 +107,40 @@ def cpu_baseline(cfg, ds, sd, rays, n_sample):
     return n_sample / dt, dt, idx, out['rgb']
 
 
+def family_figures(names=('technicolor_z_plane', 'neural_3d_z_plane', 'immersive_sphere'), parity_rays=65536):
+    """BASELINE configs[2..4]: the keyframe families' 800x800 frame at their shipped grids (synthetic seeded scenes), default
+    arithmetic and execution plan, one hipGraph replay per frame; parity = rays over 1e-4 against the CPU port of the reference's
+    algorithm on `parity_rays` rays of the same frame (checker code: timed nowhere)."""
+    from hyperreel_amd.render import build_render_fn
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    from torch_port import TorchPort
+    out = {}
+    for name in names:
+        cfg, ds = C.model_config(name), C.dataset_scalars(name)
+        sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+        grid = [int(v) for v in sd['model.color_model.net.gridSize']]
+        f = build_render_fn(cfg, dataset=ds, grid_size=grid)
+        f.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        rays_np = scenes.benchmark_rays(name, 800, 800, frame=7)
+        rays = torch.from_numpy(rays_np).cuda()
+        g, rgb = capture(f.model, rays)
+        d = timed_frames(g.replay, 20, 5, False, None)
+        g.replay()
+        torch.cuda.synchronize()
+        idx = np.sort(np.random.default_rng(0).choice(rays_np.shape[0], parity_rays, replace=False))
+        ref = TorchPort(cfg, ds, sd).render(rays_np[idx], chunk=16384)['rgb']
+        err = np.abs(rgb[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max(-1)
+        Z = cfg['embedding']['embeddings']['ray_prediction_0']['z_channels']
+        out[name] = {'value': round(rays_np.shape[0] / (d / 20) / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(d / 20 * 1e3, 4),
+                     'samples_per_ray': Z, 'grid': grid, 'mlp_gemm': f.model.mlp_precision_active(),
+                     'execution': 'persistent frame kernel (head tile in LDS)' if f.model.frame_kernel_active() else
+                                  'two kernels per 131 072-ray chunk (MLP -> HBM workspace -> sample stage)',
+                     'parity_rays': int(parity_rays), 'parity_vs_oracle_linf': float(err.max()), 'parity_rays_over_1e-4': int((err > 1e-4).sum())}
+        del f, g, rgb, rays
+        torch.cuda.empty_cache()
+    return out
+
+
 def timed_frames(step, steps, warmup, multi, dist):
     for _ in range(warmup):
         step()
@@ -320,7 +354,7 @@ def main():
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
+        'dtype': 'f32 storage / accumulate; MLP GEMM operands: see mlp_gemm', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
         'config': {'workload': f'BASELINE configs[1]: DoNeRF static ({args.model}), {args.height}x{args.width} frame '
                                f'= {args.height * args.width} rays, {Z} samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
                    'rays_per_gpu': rays_per_gpu, 'parallelism': parallelism, 'frame_ms': round(ms_per_step, 4),
@@ -451,7 +485,7 @@ def main():
     if extras:
         def quick(f):
             g, _ = capture(f.model, rays)
-            d = timed_frames(g.replay, 20, 5, False, None)
+            d = min(timed_frames(g.replay, 20, 5, False, None) for _ in range(2))      # two rounds: a 20-frame window is short enough to catch a noisy neighbour
             return B / (d / 20) / 1e6, d / 20 * 1e3
         other = make(args.mlp_precision, not use_frame)
         if other.model.frame_kernel_active() != model.frame_kernel_active():
@@ -519,6 +553,8 @@ def main():
 
     result['grid_dtype'] = args.grid_dtype
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if (args.no_graph or strong) else 'hipGraph replay of one captured frame'
+    result['dtype'] = {'bf16x3': 'f32 storage/accumulate; GEMM operands bf16x3 split', 'f16x3': 'f32 storage/accumulate; GEMM operands f16x3 split',
+                       'f16x2': 'f32 storage/accumulate; GEMM operands f16x2 (weights rounded to half)', 'fp32': 'f32'}[prec_name]
     result['mlp_gemm'] = {'bf16x3': 'bf16x3 split on MFMA, fp32 accumulate (raw head within 7e-6 of the fp32 chain)',
                           'f16x3': 'f16x3 split on MFMA: 11+11-bit halves, weights pre-scaled by an exact power of two, fp32 accumulate (raw head within 1e-6 of the fp32 chain)',
                           'f16x2': 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
@@ -552,6 +588,16 @@ def main():
             result['viewer_path'] = viewer_figures()
         except Exception as e:                                  # never lose the headline line to an extra
             result['viewer_path'] = {'error': repr(e)}
+        try:     # BASELINE configs[2..4]: the keyframe families' frame (technicolor: also "1 GPU train+render", see train_step)
+            result['families'] = family_figures()
+        except Exception as e:
+            result['families'] = {'error': repr(e)}
+        try:     # SURVEY 8f-4 / BASELINE configs[2]: one optimizer step of the training loop (nlf/__init__.py:634-709), batch 16 384
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from train_bench import train_step_figures
+            result['train_step'] = {m: train_step_figures(m, 16384, 15, torch_gpu=False, blas=False) for m in ('donerf_sphere', 'technicolor_z_plane')}
+        except Exception as e:
+            result['train_step'] = {'error': repr(e)}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -40,14 +40,10 @@ def timed(fn, reps, warm=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--model', default='donerf_sphere')
-    ap.add_argument('--batch', type=int, default=16384)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--torch-gpu', action='store_true')
-    args = ap.parse_args()
-
+def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_gpu=False, blas=True):
+    """ms per optimizer step of the HIP training path and of its parts (bench.py quotes this for its `train_step` key)"""
+    import types
+    args = types.SimpleNamespace(model=model_name, batch=batch, steps=steps, torch_gpu=torch_gpu)
     from hyperreel_amd.render import build_render_fn
     from hyperreel_amd.train import SampleStage, grid_parameters, mlp_forward, ray_features
     cfg, ds = C.model_config(args.model), C.dataset_scalars(args.model)
@@ -119,7 +115,8 @@ def main():
                 x = F.leaky_relu(x, 0.01)
         x.backward(d_head)
 
-    ms_mlp_hip, ms_mlp_blas = timed(mlp_hip, args.steps), timed(mlp_blas, args.steps)
+    ms_mlp_hip = timed(mlp_hip, args.steps)
+    ms_mlp_blas = timed(mlp_blas, args.steps) if blas else float('nan')
     out = {'workload': f'{args.model}: training step, batch {args.batch} rays x {hc.z_channels} samples, grid {grid[0]}x{grid[1]}x{grid[2]}',
            'hip_ms_per_step': round(ms_step, 3), 'hip_ms_forward_backward': round(ms_fwd_bwd, 3),
            'hip_ms_sample_stage_forward': round(ms_stage_fwd, 3),
@@ -143,7 +140,19 @@ def main():
         ms_ref = timed(step_ref, max(5, args.steps // 3))
         out['torch_rocm_port_ms_per_step'] = round(ms_ref, 3)
         out['speedup_vs_torch_rocm_port'] = round(ms_ref / ms_step, 2)
-    print(json.dumps(out))
+    if not blas:
+        out.pop('rocblas_ms_mlp_forward_backward')
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='donerf_sphere')
+    ap.add_argument('--batch', type=int, default=16384)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--torch-gpu', action='store_true')
+    args = ap.parse_args()
+    print(json.dumps(train_step_figures(args.model, args.batch, args.steps, args.torch_gpu)))
 
 
 if __name__ == '__main__':
