@@ -10,6 +10,42 @@
 
 #include "../../include/hyperreel_hip.h"
 
+// More than 64 KiB of dynamic LDS has to be opted into per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).
+// `cache`: one static per kernel instantiation; a process that renders on several GPUs (viewer + trainer, DataParallel-style
+// hosts) sets the attribute on each device it launches on.  Returns false when the runtime refuses.
+#include <atomic>
+struct HrLdsOptIn {
+    std::atomic<size_t> have[32];
+};
+inline bool hr_lds_opt_in(HrLdsOptIn& cache, const void* kernel, size_t lds)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& have = cache.have[dev & 31];
+    if (lds <= have.load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    size_t cur = have.load(std::memory_order_relaxed);
+    while (cur < lds && !have.compare_exchange_weak(cur, lds, std::memory_order_release)) {}
+    return true;
+}
+// compute units of the CURRENT device (persistent launches size their grid by it)
+inline int hr_current_device_cus()
+{
+    static std::atomic<int> n[32];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = n[dev & 31].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        n[dev & 31].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------- MLP (mlp_kernel.hip)
 // Weights of layer L are stored as MFMA B-operand tiles for v_mfma_f32_16x16x4_f32:
 //   wpack[L][((kt * n_tiles[L]) + nt) * 64 + lane] = float4{ W[n][k0], W[n][k0+1], W[n][k0+2], W[n][k0+3] }

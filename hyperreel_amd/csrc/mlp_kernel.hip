@@ -161,13 +161,8 @@ __global__ __launch_bounds__(256, 2) void hr_mlp_kernel(const hr_config cfg, con
 template <int NT>
 static void hr_launch_mlp_nt(const hr_config& cfg, const HrMlpArgs& args, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    // more than 64 KiB of dynamic LDS has to be opted into once per kernel
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_mlp_kernel<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        allowed = lds;
-    }
+    static HrLdsOptIn opt;
+    (void)hr_lds_opt_in(opt, reinterpret_cast<const void*>(&hr_mlp_kernel<NT>), lds);
     hipLaunchKernelGGL(hr_mlp_kernel<NT>, dim3(blocks), dim3(256), lds, stream, cfg, args);
 }
 

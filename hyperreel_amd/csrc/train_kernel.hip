@@ -431,17 +431,6 @@ static size_t hr_train_line_bytes(const HrTrainArgs& args)
     return n;
 }
 
-static int hr_train_n_cus()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
-
 template <int ZP>
 static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stream)
 {
@@ -449,14 +438,10 @@ static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stre
     const size_t line_bytes = hr_train_line_bytes(args);
     const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols) + line_bytes;
     if (line_bytes == 0 || lds > 150 * 1024) return false;
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return false;
-        allowed = lds;
-    }
+    static HrLdsOptIn opt;
+    if (!hr_lds_opt_in(opt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP>), lds)) return false;
     const int64_t iters = (args.n_rays + RPB - 1) / RPB;
-    const int cus = hr_train_n_cus();
+    const int cus = hr_current_device_cus();
     hipLaunchKernelGGL(hr_train_gather_bwd_lines_kernel<ZP>, dim3((unsigned)(iters < cus ? iters : cus)), dim3(1024), lds, stream, args.cfg_dev, args);
     return true;
 }
@@ -510,7 +495,7 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
     const int GROUPS = 256 / HR_TRAIN_LPS;
     const int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
     const int64_t nblocks = (args.n_rays + RPB - 1) / RPB;
-    const int64_t resident = 16 * (int64_t)hr_train_n_cus();          // four 256-thread workgroups per CU are resident (128 registers); four rounds of them: the blocks differ in cost
+    const int64_t resident = 16 * (int64_t)hr_current_device_cus();          // four 256-thread workgroups per CU are resident (128 registers); four rounds of them: the blocks differ in cost
     const unsigned bblocks = (unsigned)(nblocks < resident ? nblocks : resident);
     const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
     if (!done) switch (ZP) {
