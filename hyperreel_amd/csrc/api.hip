@@ -1298,6 +1298,9 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
         if (bytes > 0) {
             if (!params->basis) return fail(HR_E_INVALID, "hr_train_forward: params->basis is NULL");
             HR_HIP(hipMemcpyAsync(m->basis, params->basis, bytes, hipMemcpyDeviceToDevice, st));
+            // the render kernels read the column-major copy: keep it in step, so that hr_render after a training step sees the
+            // same basis_mat as the planes refreshed above
+            hr_launch_basis_transpose(m->basis, m->basis_t, m->cfg.app_dim, m->n_basis_cols, m->basis_ld, st);
         }
         if (m->cfg.color_table_views > 0) {       // read in place from the uploaded copy: refresh it
             if (!params->color_table) return fail(HR_E_INVALID, "hr_train_forward: params->color_table is NULL");

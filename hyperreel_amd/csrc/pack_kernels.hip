@@ -253,3 +253,20 @@ void hr_launch_pack_display(const float* rgb, int h, int w, int transpose, int f
     if (n <= 0) return;
     hipLaunchKernelGGL(hr_pack_display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rgb, h, w, transpose, flip, rgba8, out);
 }
+
+
+// basis_mat (app_dim, n_cols) row-major -> the column-major copy the render kernels fold decode matrices from (HrSampleArgs::basis_t)
+__global__ void hr_basis_transpose_kernel(const float* __restrict__ basis, float* __restrict__ basis_t, int app_dim, int n_cols, int ld)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= app_dim * n_cols) return;
+    const int r = i / n_cols, col = i - r * n_cols;
+    basis_t[(size_t)col * ld + r] = basis[i];
+}
+
+void hr_launch_basis_transpose(const float* basis, float* basis_t, int app_dim, int n_cols, int ld, hipStream_t stream)
+{
+    const int n = app_dim * n_cols;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(hr_basis_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, basis, basis_t, app_dim, n_cols, ld);
+}

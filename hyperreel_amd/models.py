@@ -439,7 +439,20 @@ class HipLightfieldModel(nn.Module):
         # net's forward never consults it (`if self.alphaMask is not None and False`, tensorf_no_sample.py:171)
         mask = {k: sd.pop(k) for k in list(sd) if 'alpha_aabb' in k or 'alpha_volume' in k}
         if mask:
-            self.color_model.net.alpha_mask_state = mask
+            net = self.color_model.net
+            net.alpha_mask_state = mask
+            # the occupancy early-reject (use_occupancy) reads net.alpha_volume / net.alpha_aabb: materialise them from the checkpoint's
+            # AlphaGridMask (alphaMask.alpha_volume (1, 1, D, H, W) or flat, alphaMask.alpha_aabb; tensorf_base.py:1139-1168)
+            vol = next((v for k, v in mask.items() if k.endswith('alpha_volume')), None)
+            box = next((v for k, v in mask.items() if k.endswith('alpha_aabb')), None)
+            if vol is not None and box is not None:
+                vol = vol.detach().float()
+                if vol.dim() == 5:
+                    vol = vol[0, 0]
+                if vol.dim() == 3:
+                    dev = net.aabb.device
+                    net.register_buffer('alpha_volume', vol.to(dev).contiguous(), persistent=False)
+                    net.register_buffer('alpha_aabb', box.detach().float().reshape(2, 3).to(dev), persistent=False)
         gs = sd.get('color_model.net.gridSize')
         if gs is not None and [int(x) for x in gs.tolist()] != self.grid_size:
             self.color_model.net.init_svd_volume([int(x) for x in gs.tolist()])
@@ -512,6 +525,8 @@ class HipLightfieldModel(nn.Module):
             self._native = h
             self._occ_key = None                   # a fresh handle holds no occupancy volume
             self._apply_options()
+            if getattr(self, '_reserve', None):
+                _lib.check(L.hr_model_reserve(h, self._reserve), 'hr_model_reserve')
             self._native_grid = self.grid_size
             self._native_box = (self.color_model.net.aabb.data_ptr(), self.color_model.net.aabb._version)
             self._native_cfg = bytes(hc) + (bytes(coarse) if coarse is not None else b'')
@@ -558,6 +573,8 @@ class HipLightfieldModel(nn.Module):
 
     def set_occupancy(self, enable=True):
         """Turns the occupancy early-reject of render() on or off (needs a mask: updateAlphaMask or a checkpoint's)."""
+        if enable and getattr(self.color_model.net, 'alpha_volume', None) is None:
+            raise RuntimeError('set_occupancy(True): the colour net has no alpha mask volume (run updateAlphaMask, or load a checkpoint that carries one)')
         self.use_occupancy = bool(enable)
         if self._native is not None:
             self._sync_occupancy()
@@ -611,8 +628,10 @@ class HipLightfieldModel(nn.Module):
         return [float(v) for v in out[:int(self._hc.mlp_layers)]]
 
     def reserve(self, rays_per_chunk):
+        """Sizes the native workspace; remembered, so that a handle that is re-created (grid growth, cascade schedules) gets it again."""
+        self._reserve = int(rays_per_chunk)
         L = _lib.load()
-        _lib.check(L.hr_model_reserve(self.native(), int(rays_per_chunk)), 'hr_model_reserve')
+        _lib.check(L.hr_model_reserve(self.native(), self._reserve), 'hr_model_reserve')
 
     def device_bytes(self):
         return int(_lib.load().hr_model_device_bytes(self.native()))
@@ -765,6 +784,13 @@ class HipLightfieldModel(nn.Module):
             # regulariser that needs d(field)/d(parameters) is outside the training path (SURVEY 8f-4 covers the colour loss
             # and the plane regularisers).
             out = {k: v.detach() for k, v in out.items()}
+            if not getattr(self, '_warned_detached_fields', False):
+                import warnings
+                self._warned_detached_fields = True
+                warnings.warn('HipLightfieldModel.forward in train mode: the fields ' + ', '.join(sorted(k for k in out if k != 'rgb')) +
+                              ' come from the inference kernels and are DETACHED -- a regulariser that needs their gradient contributes none '
+                              '(differentiable: rgb, and the plane regularisers of hyperreel_amd.train); every such step also re-uploads the '
+                              'weights for the inference pass', RuntimeWarning, stacklevel=2)
             out['rgb'] = self.forward_train(rays)
         return out
 

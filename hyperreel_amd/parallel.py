@@ -123,9 +123,11 @@ class ShardedFramePipeline:
         return self.tiles[self.slot][:self.hi - self.lo]
 
     def _assemble(self, slot):
+        """The full frame of `slot`, ALWAYS a fresh tensor: the slot's buffers are written again two submits later, and a caller that
+        collects frames (video rendering) must not see earlier ones change under it."""
         out = self.full[slot]
         if self.world * self.per == self.n:
-            return out
+            return out[:self.n].clone()
         return torch.cat([out[r * self.per:r * self.per + (self.bounds[r + 1] - self.bounds[r])] for r in range(self.world)], 0)
 
     def submit(self):

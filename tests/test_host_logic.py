@@ -212,6 +212,12 @@ def test_the_models_aabb_buffer_not_the_yaml_drives_the_compiled_box():
     sd['color_model.net.alphaMask.alpha_volume'] = torch.ones(1, 1, 4, 4, 4)
     m.load_state_dict({'model.' + k: v for k, v in sd.items()}, strict=True)
     assert set(m.color_model.net.alpha_mask_state) == {'color_model.net.alphaMask.alpha_aabb', 'color_model.net.alphaMask.alpha_volume'}
+    # ... but the opt-in occupancy early-reject does: the checkpoint's mask becomes the net's volume / box (D, H, W)
+    assert tuple(m.color_model.net.alpha_volume.shape) == (4, 4, 4) and float(m.color_model.net.alpha_volume.min()) == 1.0
+    assert m.color_model.net.alpha_aabb.reshape(-1).tolist() == [-1.5, -1.0, -0.5, 1.0, 1.5, 2.0]
+    fresh = HipLightfieldModel(cfg, dataset=ds, grid_size=[8, 8, 8])
+    with pytest.raises(RuntimeError, match='no alpha mask'):
+        fresh.set_occupancy(True)
     hc = m._compile([8, 8, 8])[1]
     assert list(hc.aabb) == [-1.5, -1.0, -0.5, 1.0, 1.5, 2.0]
     assert list(hc.inv_size) == pytest.approx([2 / 2.5, 2 / 2.5, 2 / 2.5])
