@@ -334,12 +334,23 @@ def main():
         model.render(rays)
         torch.cuda.synchronize()
 
-        def step():
-            tile = pipe.begin()
-            model.render(rays, out=tile)
-            return pipe.submit()
+        if args.no_graph:
+            def step():
+                tile = pipe.begin()
+                model.render(rays, out=tile)
+                return pipe.submit()
+        else:       # one hipGraph per tile buffer: a step is a graph launch + the all-gather enqueue
+            step = pipe.capture(lambda tile: model.render(rays, out=tile))
 
         dt = timed_frames(step, args.steps, args.warmup, multi, dist)
+        # host time per frame: how long the CPU needs to enqueue a step (no synchronisation inside the loop) -- the floor a rank's
+        # frame time cannot go below however little of the frame it renders
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        host_us = (time.perf_counter() - t_h) / args.steps * 1e6
+        torch.cuda.synchronize()
         rgb_full = pipe.flush()
         torch.cuda.synchronize()
         rgb = rgb_full[pipe.lo:pipe.hi]
@@ -551,8 +562,11 @@ def main():
             result['value_f16x2']['parity_vs_oracle_linf'] = float(e2.max())
             result['value_f16x2']['parity_rays_over_1e-4'] = int((e2 > 1e-4).sum())
 
+    if strong:
+        result['host_us_per_frame'] = round(host_us, 1)
     result['grid_dtype'] = args.grid_dtype
-    result['config']['launch'] = 'eager (Python -> hr_render per frame)' if (args.no_graph or strong) else 'hipGraph replay of one captured frame'
+    result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else \
+        ('hipGraph replay of this rank\'s captured render + all-gather enqueued from Python on the side stream' if strong else 'hipGraph replay of one captured frame')
     result['dtype'] = {'bf16x3': 'f32 storage/accumulate; GEMM operands bf16x3 split', 'f16x3': 'f32 storage/accumulate; GEMM operands f16x3 split',
                        'f16x2': 'f32 storage/accumulate; GEMM operands f16x2 (weights rounded to half)', 'fp32': 'f32'}[prec_name]
     result['mlp_gemm'] = {'bf16x3': 'bf16x3 split on MFMA, fp32 accumulate (raw head within 7e-6 of the fp32 chain)',

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -1084,6 +1085,39 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
     } else return fail(HR_E_INVALID, "unknown option %d", option);
+    return HR_OK;
+}
+
+int hr_shard_range(int64_t n_pixels, int32_t rank, int32_t world, int64_t* first, int64_t* count)
+{
+    if (!first || !count || world < 1 || rank < 0 || rank >= world || n_pixels < 0) return fail(HR_E_INVALID, "hr_shard_range: bad arguments");
+    const int64_t base = n_pixels / world, extra = n_pixels % world;
+    *first = (int64_t)rank * base + (rank < extra ? rank : extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return HR_OK;
+}
+
+int hr_allgather_tiles(void* nccl_comm, const float* tile_dev, float* full_dev, int64_t floats_per_rank, void* stream)
+{
+    if (!nccl_comm || !tile_dev || !full_dev || floats_per_rank <= 0) return fail(HR_E_INVALID, "hr_allgather_tiles: null communicator / buffer or empty tile");
+    // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    static allgather_fn fn = nullptr;
+    static bool looked = false;
+    if (!looked) {
+        looked = true;
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");        // the RCCL the process already uses (torch.distributed's, the integrator's)
+        if (!sym) {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h && (sym = dlsym(h, "ncclAllGather"))) break;
+            }
+        }
+        fn = reinterpret_cast<allgather_fn>(sym);
+    }
+    if (!fn) return fail(HR_E_HIP, "hr_allgather_tiles: no RCCL (ncclAllGather) in this process and librccl.so cannot be loaded");
+    const int rc = fn(tile_dev, full_dev, (size_t)floats_per_rank, /* ncclFloat32 */ 7, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) return fail(HR_E_HIP, "ncclAllGather failed with ncclResult_t %d", rc);
     return HR_OK;
 }
 

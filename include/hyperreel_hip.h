@@ -307,6 +307,18 @@ int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,
                      const hr_fields* fields, void* stream);
 
+/* Image-parallel frames: every rank renders a contiguous pixel range of the frame into `tile_dev` and the tiles are
+ * assembled on every rank by ONE all-gather over RCCL / xGMI: full_dev[r * floats_per_rank ..] = rank r's tile_dev[0 .. floats_per_rank).
+ * `nccl_comm` is the caller's ncclComm_t (one process per GPU; the communicator is the integrator's: torch.distributed's, MPI's, ...),
+ * passed as void* so that this header stays free of RCCL types; the collective is enqueued on `stream` (hipGraph-capturable like
+ * hr_render; no host synchronisation).  The library resolves ncclAllGather from the RCCL already loaded into the process (or
+ * librccl.so) on first use -- it has no link-time dependency on it; HR_E_HIP when no RCCL can be found.  The reference has no
+ * counterpart: it shards whole validation images over DDP ranks and never gathers pixels (nlf/__init__.py:896). */
+int hr_allgather_tiles(void* nccl_comm, const float* tile_dev, float* full_dev, int64_t floats_per_rank, void* stream);
+/* pixel range [first, first + count) of rank `rank` of `world` for an image of n_pixels (even contiguous split, the first
+ * n_pixels % world ranks take one pixel more); floats_per_rank for hr_allgather_tiles is 3 * the count of rank 0 (the largest). */
+int hr_shard_range(int64_t n_pixels, int32_t rank, int32_t world, int64_t* first, int64_t* count);
+
 /* rays_dev[n_pixels, ray_dim] for pixels [first_pixel, first_pixel + n_pixels) of the image in
  * row-major order: get_ray_directions_K(centered_pixels=True) + get_rays(normalize=True)
  * (utils/ray_utils.py:98-135) [+ cam_id, time when ray_dim == 8].  Generating the rays on the

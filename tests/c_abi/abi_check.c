@@ -47,6 +47,8 @@ int main(void)
         if (hr_model_set_occupancy(NULL, NULL, n3, box, NULL) != HR_E_INVALID) return 23;
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
         if (hr_model_calibrate(NULL, &x, 1, NULL, NULL) != HR_E_INVALID) return 24;
+        if (hr_allgather_tiles(NULL, &x, &x, 3, NULL) != HR_E_INVALID) return 25;
+        { int64_t f = -1, c = -1; if (hr_shard_range(10, 1, 4, &f, &c) != HR_OK || f != 3 || c != 3) return 26; if (hr_shard_range(10, 4, 4, &f, &c) != HR_E_INVALID) return 27; }
     }
     return 0;
 }
