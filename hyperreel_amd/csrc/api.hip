@@ -17,7 +17,7 @@
 
 // sample wavefronts per workgroup of the frame kernel when the caller does not say (measured: DESIGN.md section 3)
 #ifndef HR_DEFAULT_SAMPLE_WAVES
-#define HR_DEFAULT_SAMPLE_WAVES 8
+#define HR_DEFAULT_SAMPLE_WAVES 0      // the plan's own choice (8)
 #endif
 
 namespace {
@@ -943,9 +943,9 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
     fill_sample_args(m, sa, rays, n, rgb);
     sa.head = nullptr;
     switch (m->active_precision) {
-        case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
-        case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
-        case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->n_cus, probe, st);
+        case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
+        case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
+        case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
         default: return false;          // the exact-fp32 MLP (v_mfma_f32_16x16x4_f32) keeps its own kernel
     }
 }
@@ -1051,10 +1051,10 @@ int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
 {
     if (!m) return fail(HR_E_INVALID, "null model");
     if (option == HR_OPT_FRAME_KERNEL) {
-        if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_FRAME_KERNEL takes 0 or 1");
+        if (value < 0 || value > 2) return fail(HR_E_INVALID, "HR_OPT_FRAME_KERNEL takes 0, 1 or 2");
         m->opt_frame_kernel = value;
     } else if (option == HR_OPT_SAMPLE_WAVES) {
-        if (value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 4 or 8");
+        if (value != 0 && value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 0 (the plan's default), 4 or 8");
         m->opt_sample_waves = value;
     } else {
         return fail(HR_E_INVALID, "unknown or read-only option %d", option);

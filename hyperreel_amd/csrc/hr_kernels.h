@@ -126,12 +126,12 @@ void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 // fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.
 // Returns false when the model does not fit it (nothing launched); probe: only answer.
-bool hr_launch_frame_bf16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
+bool hr_launch_frame_bf16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
                             hipStream_t stream);
-bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
-                           hipStream_t stream);
-bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int n_cus, bool probe,
-                           hipStream_t stream);
+bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
+                            hipStream_t stream);
+bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
+                            hipStream_t stream);
 
 // activation range of the MLP on a set of rays (range_kernel.hip): act_max[0] = max |input feature|, act_max[l + 1] = max |pre-activation|
 // of hidden Linear l; w / b: the uploaded reference-layout tensors (out, in) / (out)

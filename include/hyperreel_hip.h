@@ -276,14 +276,18 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
 
 /* Execution plan of hr_render.  The arithmetic is the same under every setting (bit-identical images); the options choose
  * how it is laid out on the device.
- *   HR_OPT_FRAME_KERNEL   1 (default): models whose 64-ray head tile fits the CU's LDS are rendered by ONE persistent kernel in
- *                         which MLP wavefronts hand the (B, Z*P) head that the reference materialises between
- *                         RayPredictionEmbedding and Intersect (nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259)
- *                         to sample wavefronts of the same workgroup through LDS -- no workspace traffic; models that do
- *                         not fit (wider heads, cascades, the exact-fp32 MLP), and every hr_render_fields call with a
- *                         non-NULL `fields`, take the two-kernel path.  0: always two kernels per chunk of rays -- the MLP
- *                         writes the head to an HBM workspace, the sample kernel reads it back.
- *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8.
+ *   HR_OPT_FRAME_KERNEL   1 (default): models whose head tile fits the CU's LDS are rendered by ONE persistent kernel in which
+ *                         MLP wavefronts hand the (B, Z*P) head that the reference materialises between RayPredictionEmbedding and
+ *                         Intersect (nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259) to sample wavefronts of the
+ *                         same workgroup through LDS -- no workspace traffic (static nets, 64-ray tiles).  Models that do not
+ *                         fit (wider heads, cascades, the exact-fp32 MLP, other plane decompositions), and every hr_render_fields
+ *                         call with a non-NULL `fields`, take the two-kernel path.
+ *                         2: additionally the keyframe families (480-column heads, 960 at 64 samples per ray;
+ *                         nlf/nets/tensorf_dynamic.py:645-839) on 32-ray tiles, two head buffers where they fit: same images, no
+ *                         head workspace traffic, measured as fast as or slower than two kernels (hence not part of 1).
+ *                         0: always two kernels per chunk of rays -- the MLP writes the head to an HBM workspace, the sample
+ *                         kernel reads it back.
+ *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default, 8).
  * Read-only: HR_OPT_FRAME_KERNEL_ACTIVE whether hr_render currently takes the frame kernel; HR_OPT_MLP_PRECISION_ACTIVE the HR_MLP_*
  * arithmetic the MLP kernels run (HR_MLP_AUTO resolved); HR_OPT_MLP_CALIBRATED 0 / 1 (finalize's synthetic rays) / 2 (hr_model_calibrate);
  * HR_OPT_MLP_OVERFLOW the sticky bit the fp16-split kernels set when an input feature or hidden activation of a RENDERED ray reached

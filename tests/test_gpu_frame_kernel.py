@@ -45,13 +45,60 @@ def test_fusable_models_take_the_frame_kernel(case):
     assert fn.model.frame_kernel_active()
 
 
-@pytest.mark.parametrize('case', ['technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
-                                  'sweep/shiny_z_plane_cascaded'])
-def test_wide_heads_and_cascades_keep_the_two_kernel_path(case):
-    """480 head columns x 64 rays (124 KB) + 67.6 KB of activations exceed the CU's 160 KB; cascades run two MLPs."""
-    g, fn = _fns(case)
-    fn.model.set_execution(frame_kernel=True)
+KEYFRAME = ['technicolor_z_plane_small', 'immersive_sphere_small', 'neural_3d_z_plane_small']
+
+
+def test_cascades_keep_the_two_kernel_path():
+    """a point_prediction cascade runs two MLPs with a sample pass between them"""
+    g, fn = _fns('sweep/shiny_z_plane_cascaded')
+    fn.model.set_execution(frame_kernel=2)
     assert not fn.model.frame_kernel_active()
+
+
+@pytest.mark.parametrize('case', KEYFRAME)
+def test_keyframe_families_take_the_32_ray_tile_frame_kernel(case):
+    """TensorVMKeyframeTime heads (nlf/nets/tensorf_dynamic.py:645-839) are 480 columns wide (960 at 64 samples per ray): 32-ray tiles,
+    two head buffers at 32 samples per ray, one at 64.  Measured as fast as or slower than the two-kernel plan (every weight
+    crosses the CU once per 32 rays): not the default -- the plan `frame_kernel=2` asks for (no head workspace traffic)"""
+    g, fn = _fns(case)
+    assert not fn.model.frame_kernel_active()
+    fn.model.set_execution(frame_kernel=2)
+    assert fn.model.frame_kernel_active()
+    fn.model.set_execution(frame_kernel=False)
+    assert not fn.model.frame_kernel_active()
+
+
+@pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
+@pytest.mark.parametrize('case', KEYFRAME)
+def test_keyframe_frame_kernel_equals_two_kernel_path_bit_for_bit(case, precision, grid_dtype):
+    g, fn = _fns(case, precision, grid_dtype)
+    rays = torch.from_numpy(np.concatenate([g.rays] * 3 + [g.rays[:37]], 0)).cuda()       # a few tiles per workgroup, ragged tail
+    two = _render(fn, rays, False)
+    one = _render(fn, rays, 2)
+    assert fn.model.frame_kernel_active()
+    assert torch.equal(one, two), f'{int((one != two).any(-1).sum())} rays differ'
+    for _ in range(3):
+        assert torch.equal(_render(fn, rays, 2), two)
+    if precision != 'f16x2' and grid_dtype == 'fp32':
+        assert np.abs(one[:g.rays.shape[0]].cpu().numpy() - g.rgb).max() <= 1e-4
+
+
+@pytest.mark.parametrize('model', ['technicolor_z_plane', 'immersive_sphere', 'neural_3d_z_plane'])
+def test_keyframe_frame_kernel_full_frame_every_word_and_repeats(model):
+    """the families' 800x800 frames at their shipped grids: 20 000 32-ray tiles over 256 persistent workgroups, every word equal to
+    the two-kernel path, repeated launches reproduce it"""
+    from gpu_common import make_render_fn
+    cfg, ds = C.model_config(model), C.dataset_scalars(model)
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    fn = make_render_fn(cfg, ds, sd)
+    rays = torch.from_numpy(scenes.benchmark_rays(model, 800, 800, frame=7)).cuda()
+    two = _render(fn, rays, False)
+    one = _render(fn, rays, 2)
+    assert fn.model.frame_kernel_active()
+    assert torch.equal(one, two), f'{int((one != two).any(-1).sum())} rays differ'
+    for _ in range(4):
+        assert torch.equal(_render(fn, rays, 2), two)
 
 
 @pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])

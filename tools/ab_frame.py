@@ -15,6 +15,7 @@ ap.add_argument('--model', default='donerf_sphere')
 ap.add_argument('--rounds', type=int, default=3)
 ap.add_argument('--steps', type=int, default=30)
 ap.add_argument('--two-kernel', action='store_true')
+ap.add_argument('--frame-mode', type=int, default=1, help='HR_OPT_FRAME_KERNEL: 1 = where faster, 2 = wherever it fits')
 ap.add_argument('--precision', default='auto')
 ap.add_argument('--grid-dtype', default='fp32')
 ap.add_argument('--sample-waves', type=int, default=0)
@@ -37,7 +38,7 @@ for spec in args.libs:
     hl._lib = None
     hl.LIB_PATH = path
     fn = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=args.precision, grid_dtype=args.grid_dtype,
-                         frame_kernel=not args.two_kernel, sample_waves=args.sample_waves or None)
+                         frame_kernel=(False if args.two_kernel else (2 if args.frame_mode == 2 else True)), sample_waves=args.sample_waves or None)
     fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     fn.model.native()
     g, out = B.capture(fn.model, rays)

@@ -42,7 +42,7 @@ __global__ void k(const float* in, float* out, int iters, unsigned long long* cl
     float s = 0.f;
     for (int j = 0; j < ILP; ++j) s += x[j] + x2[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) clk[blockIdx.x] = c1 - c0;
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 16 + (threadIdx.x >> 6)] = c1 - c0;     // every wavefront's own time: the oldest one is favoured by the arbiter
 }
 
 template <int ILP, int OP>
@@ -54,20 +54,26 @@ static void run(const char* name, int waves_per_simd, const float* in, float* ou
     hipDeviceSynchronize();
     hipLaunchKernelGGL((k<ILP, OP>), dim3(256), dim3(threads), 0, 0, in, out, iters, clk);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> h(256);
-    hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost);
-    double c = 0;
-    for (auto v : h) c += (double)v;
-    c /= 256;
+    const int nw = 4 * waves_per_simd;
+    std::vector<unsigned long long> h(256 * 16);
+    hipMemcpy(h.data(), clk, 256 * 16 * 8, hipMemcpyDeviceToHost);
+    double c_first = 0, c_last = 0;          // the wavefront that finishes first / last on its CU, averaged over the CUs
+    for (int b = 0; b < 256; ++b) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int w = 0; w < nw; ++w) { lo = h[b * 16 + w] < lo ? h[b * 16 + w] : lo; hi = h[b * 16 + w] > hi ? h[b * 16 + w] : hi; }
+        c_first += (double)lo; c_last += (double)hi;
+    }
+    c_first /= 256; c_last /= 256;
     const double n = (double)iters * 16 * ILP;
-    printf("%-12s ILP %d, %d wave(s)/SIMD: %6.2f cycles per instruction per wave, %5.2f per SIMD\n", name, ILP, waves_per_simd, c / n, c / n / waves_per_simd);
+    printf("%-12s ILP %d, %d wave(s)/SIMD: %6.2f cycles per instruction for the fastest wavefront, %6.2f for the slowest; %5.2f per instruction per SIMD\n", name, ILP,
+           waves_per_simd, c_first / n, c_last / n, c_last / n / waves_per_simd);
 }
 
 int main()
 {
     float *in, *out;
     unsigned long long* clk;
-    hipMalloc(&in, 4096); hipMalloc(&out, 4 * 256 * 1024); hipMalloc(&clk, 8 * 256);
+    hipMalloc(&in, 4096); hipMalloc(&out, 4 * 256 * 1024); hipMalloc(&clk, 8 * 256 * 16);
     std::vector<float> h(1024);
     for (int i = 0; i < 1024; ++i) h[i] = 0.5f + 0.001f * i;
     hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice);
