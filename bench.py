@@ -18,7 +18,7 @@ The JSON line also carries
   roofline        the dominant kernel of the step, its launches timed live with HIP events on the launch stream, against the
                   MI355X peak that bounds it (MI355X_MICROARCH.md: 2500 TFLOP/s dense bf16/fp16 MFMA);
   roofline_other  the other kernel: vector-ALU issue (wave-instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles);
-                  the instruction count per launch comes from the committed PMC pass (profiles/r02_counters.json);
+                  the instruction count per launch comes from the committed PMC pass (profiles/r03_counters.json);
   frame_kernel    the same frame through the single persistent frame kernel (head tile handed over in LDS);
   value_fp32_exact  the same frame with the exact fp32-MFMA MLP;
   value_f16x2     the same frame with the opt-in two-product MLP arithmetic, and its own parity against the oracle;
@@ -43,7 +43,9 @@ from hyperreel_amd import scenes  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (measured 2495)
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # wave-instructions per ns: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave-instructions per ns: 256 CUs x 4 SIMDs, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md, wave
+                                     # scheduling), 2.4 GHz.  tools/valu_ilp_ubench.hip on this part: 2.6 cycles per v_fma_f32 per SIMD with four wavefronts,
+                                     # 4.3-4.9 per DPP instruction, 8.3 per transcendental (profiles/r03_valu_ilp_ubench.txt)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -243,6 +245,7 @@ def main():
     ap.add_argument('--lib', default='', help='measurement builds only (tools/build_variant.py): load this library instead of the in-tree one')
     ap.add_argument('--frame-kernel', action='store_true', help='(default where the model fits) the persistent frame kernel, head tile in LDS')
     ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead')
+    ap.add_argument('--frame-mode', type=int, default=1, choices=[1, 2], help='HR_OPT_FRAME_KERNEL: 1 = the frame kernel where it is the faster plan (static nets), 2 = wherever the model fits it (keyframe families on 32-ray tiles)')
     ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
 
@@ -285,7 +288,7 @@ def main():
         f.model.native()
         return f
 
-    use_frame = not args.no_frame_kernel
+    use_frame = False if args.no_frame_kernel else (2 if args.frame_mode == 2 else True)
     fn = make(args.mlp_precision, use_frame)
     model = fn.model
     strong = args.scaling == 'strong' and multi
@@ -426,11 +429,13 @@ def main():
                  'algorithmic_gather_GBs': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays (L2 / Infinity-Cache resident: not an HBM figure)',
                  'note': 'the sample stage is bound by vector-ALU issue, not by bytes: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, '
-                         'profiles/r02_counters.json) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction'}
+                         'profiles/r03_counters.json) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue '
+                         'rate for plain fp32 instructions; the stage\'s mix of DPP, packed and transcendental instructions issues slower: '
+                         'profiles/r03_valu_ilp_ubench.txt)'}
         # counters measured separately with rocprofv3 --pmc (never inside a timed run) and committed under profiles/;
         # attached only when the workload matches the profiled one
         try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters.json')))
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r03_counters.json')))
             w = tr['workload']
             if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
                     and w['mlp_precision'] == prec_name and w['grid_dtype'] == args.grid_dtype):
@@ -439,7 +444,7 @@ def main():
                     if not k:
                         continue
                     r['traffic'] = k.get('traffic_bytes')
-                    r['traffic_unit'] = 'HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_counters.json)'
+                    r['traffic_unit'] = 'HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r03_counters.json)'
                     if 'limiter' in k:
                         r['limiter'] = k['limiter']
                     if 'mfma_busy_frac' in k:
@@ -464,21 +469,20 @@ def main():
                     'mfma_products_per_gemm': n_prod,
                     'note': 'ONE persistent kernel per frame: MLP wavefronts (matrix cores) and sample wavefronts (vector ALU) of the same '
                             'workgroup, head tile in LDS.  frac prices the whole frame against the 16-bit MFMA peak with the algorithmic MLP FLOPs '
-                            f'(<= 1/{n_prod} by construction).  Limits (DESIGN.md 3c, 3d): the sample wavefronts\' dependent-instruction latency at '
-                            '8 of them per CU, and the power manager -- under real matrix operands the shader clock is 1.84 GHz against 2.44 GHz '
-                            'with zero operands (profiles/r02_e_mfma_pipe_ubench.txt), so the products of a frame alone are 0.82 ms at the '
-                            'sustained 1.85 PFLOP/s and overlapping the vector stage with them does not add the two rates; see valu_busy_frac / '
-                            'mfma_busy_frac',
+                            f'(<= 1/{n_prod} by construction).  Limits (DESIGN.md 3c-3e): a wavefront issues a DEPENDENT vector instruction only every '
+                            '9.3 cycles (tools/valu_ilp_ubench.hip) and the register file holds three wavefronts per SIMD next to the 165-VGPR MLP role '
+                            '-- two of them sample wavefronts; and the power manager: under real matrix operands the shader clock is 1.84 GHz against '
+                            '2.44 GHz with zero operands (profiles/r02_e_mfma_pipe_ubench.txt).  See valu_busy_frac / mfma_busy_frac',
                     'sustained_mfma_tflops': 1850.0,
                     'frac_of_sustained_issued': round(n_prod * flops / (fr_ms[0] * 1e-3) / 1e12 / 1850.0, 4)}
             try:
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters_frame_kernel.json')))
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r03_counters_frame_kernel.json')))
                 w = tr['workload']
                 if (w['model'] == args.model and w['rays_per_launch'] == B and w['grid'] == grid and w['mlp_precision'] == prec_name
                         and w['grid_dtype'] == args.grid_dtype and fk in tr):
                     k = tr[fk]
                     r_fr['traffic'] = k.get('traffic_bytes')
-                    r_fr['traffic_unit'] = 'HBM-side bytes per launch = per frame (FETCH_SIZE + WRITE_SIZE, profiles/r02_counters_frame_kernel.json)'
+                    r_fr['traffic_unit'] = 'HBM-side bytes per launch = per frame (FETCH_SIZE + WRITE_SIZE, profiles/r03_counters_frame_kernel.json)'
                     for key in ('valu_busy_frac', 'mfma_busy_frac', 'ta_busy_frac', 'limiter'):
                         if key in k:
                             r_fr[key] = k[key]
@@ -498,7 +502,7 @@ def main():
             g, _ = capture(f.model, rays)
             d = min(timed_frames(g.replay, 20, 5, False, None) for _ in range(2))      # two rounds: a 20-frame window is short enough to catch a noisy neighbour
             return B / (d / 20) / 1e6, d / 20 * 1e3
-        other = make(args.mlp_precision, not use_frame)
+        other = make(args.mlp_precision, (not use_frame) if use_frame != 2 else False)
         if other.model.frame_kernel_active() != model.frame_kernel_active():
             v, ms = quick(other)
             same = bool(torch.equal(other.model.render(rays)['rgb'], rgb))

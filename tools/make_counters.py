@@ -18,7 +18,7 @@ for i in range(1, 6):
         if m and k:
             vals[k][m.group(1)] = float(m.group(2))
 res = {'_about': 'per-launch PMC counters of the render kernels (tools/pmc.sh: separate rocprofv3 --pmc passes, --kernel-trace only; raw pass outputs in '
-                 'profiles/r02_*_pmc_pass*.txt).  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KB, and FETCH_SIZE under-counts '
+                 'profiles/r03_*_pmc_pass*.txt).  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KB, and FETCH_SIZE under-counts '
                  'wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated; Infinity-Cache hits are included in '
                  'these fabric-side counters.  SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE cycles.',
        'workload': {'model': model, 'rays_per_launch': rpl, 'grid': grid, 'mlp_precision': prec, 'grid_dtype': gdt}}
