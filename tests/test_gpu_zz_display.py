@@ -139,9 +139,14 @@ def test_occupancy_early_reject_equals_the_reference_with_its_mask_enabled():
     masked = fn.model.render(rays)['rgb']
     assert np.abs(masked.cpu().numpy() - z['rgb_masked']).max() <= 1e-4
     assert np.abs(z['rgb_masked'] - z['rgb_plain']).max() > 0.1          # the fixture distinguishes the two behaviours
+    # both execution plans reject the same samples with the same arithmetic: bit-identical images
     fn.model.set_execution(frame_kernel=True)
-    if fn.model.frame_kernel_active():
-        assert torch.equal(fn.model.render(rays)['rgb'], masked)
+    assert fn.model.frame_kernel_active()
+    one = fn.model.render(rays)['rgb'].clone()
     fn.model.set_execution(frame_kernel=False)
+    assert not fn.model.frame_kernel_active()
+    two = fn.model.render(rays)['rgb'].clone()
+    assert torch.equal(one, two), f'{int((one != two).any(-1).sum())} rays differ between the plans'
+    assert np.abs(two.cpu().numpy() - z['rgb_masked']).max() <= 1e-4
     fn.model.set_occupancy(False)
     assert np.abs(fn.model.render(rays)['rgb'].cpu().numpy() - z['rgb_plain']).max() <= 1e-4
