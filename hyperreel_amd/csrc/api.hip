@@ -1251,14 +1251,14 @@ static int check_train(hr_model* m, const float* rays, int64_t n)
     return HR_OK;
 }
 
-// per-sample workspace of the backward's phases (8 words per sample); grows on the first step and if the batch grows
+// per-sample workspace of the backward's phases (30 words per sample); grows on the first step and if the batch grows
 static int ensure_tape(hr_model* m, int64_t ns, hipStream_t st)
 {
     if (ns <= m->tape_samples) return HR_OK;
     HR_HIP(hipStreamSynchronize(st));
     free_dev(m->tape);
     m->tape_samples = 0;
-    HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 29 * (size_t)ns));       // HrTrainTape: 8 planes + 18 of taps + 3 of dL/d point
+    HR_HIP(hipMalloc((void**)&m->tape, sizeof(float) * 30 * (size_t)ns));       // HrTrainTape: 8 planes + 18 of taps + 3 of dL/d point + the grouped ray order (n_rays <= ns ints)
     m->tape_samples = ns;
     return HR_OK;
 }
@@ -1385,6 +1385,7 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     a.tape.dts = m->tape + 7 * ns;
     a.tape.taps = m->tape + 8 * ns;
     a.tape.dp = m->tape + 26 * ns;
+    a.tape.perm = reinterpret_cast<int*>(m->tape + 29 * ns);
     a.d_rgb = d_rgb_dev;
     a.d_head = d_head_dev;
     a.d_basis = d_basis;

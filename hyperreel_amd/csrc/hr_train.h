@@ -62,6 +62,18 @@ struct HrTrainTape {
     // device, lane-per-sample phase A only (NULL otherwise): what phase B would recompute per 16-lane group
     float* taps;      // 18 planes of n_rays * Z: per axis x, y, z the grid_sample tap {i0, i1 (int bits), w0, w1, s0, s1}
     float* dp;        // dL / d point, 3 planes of n_rays * Z (phase B -> hr_sample_train_point_bwd)
+    int* perm;        // keyframe nets, device: the batch's ray indices grouped by keyframe row (hr_train_bucket_kernel), n_rays
+};
+
+// Workgroup-private accumulators (LDS, device only) for a texel range [lo, lo + n) of each plane pair's line / time plane: the
+// whole line of a static net, the two keyframe rows a group of rays blends between for a keyframe net.  Taps outside the
+// range, and pairs without an accumulator, go to the global gradient.  `pairs`: the plane pairs this pass differentiates
+// (a keyframe net whose rows do not fit one workgroup's LDS together is walked in two passes; the later one adds to tape.dp).
+struct HrTrainWindow {
+    float* acc[3];
+    int lo[3], n[3];
+    unsigned pairs;
+    int add_dp;
 };
 
 struct HrTrainArgs {
@@ -555,7 +567,7 @@ HR_FN void hr_train_gather(const HrTrainArgs& a, const hr_axis_tap_g* ax, const 
 // (tools/atomic_ubench.hip: 331 vs 19.5 G atomics/s).
 HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrainTaps& t, const hr_axis_tap_g& gx, const hr_axis_tap_g& gy,
                                        const hr_axis_tap_g& gv, const hr_axis_tap_g& at, int ch, const float* M, float* dM, int CA,
-                                       float dfeat, const float* dpre, float* d3, float* line_acc = nullptr)
+                                       float dfeat, const float* dpre, float* d3, const HrTrainWindow* win = nullptr)
 {
     const HrGridPlane& g = a.planes[j];
     const float* A = reinterpret_cast<const float*>(g.a);
@@ -582,11 +594,13 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
     float* GB = a.g_b[j];
     for (int i = 0; i < 4; ++i)
         if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
-    // the line of a static net has a few hundred texels that EVERY sample of the batch hits: on the device the caller can
-    // hand a workgroup-private accumulator (LDS) that it adds to the global one once at the end
+    // the line of a static net has a few hundred texels that EVERY sample of the batch hits, the time plane of a keyframe net
+    // two rows that every sample of a ray at that time hits: on the device the caller can hand a workgroup-private accumulator
+    // (LDS) for such a texel range, which it adds to the global gradient when it moves on
     for (int i = 0; i < t.nb; ++i) {
         if (t.wb[i] == 0.0f) continue;
-        if (line_acc) HR_ATOMIC_ADD_RAY(line_acc + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
+        const int rel = win ? t.ib[i] - win->lo[j] : 0;
+        if (win && win->acc[j] && (unsigned)rel < (unsigned)win->n[j]) HR_ATOMIC_ADD_RAY(win->acc[j] + (size_t)rel * g.tex + ch, dpb * t.wb[i]);
         else HR_ATOMIC_ADD(GB + (size_t)t.ib[i] * g.tex + ch, dpb * t.wb[i]);
     }
     // coordinates: d(weights)/d ix = (s0, s1) per axis
@@ -600,20 +614,20 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
 // dL/d normalised coordinates in dpn[3] (the host walks all channels with stride 1; on the device the 16 lanes of a
 // sample take stride 16 and add their shares up).
 HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, float* dM, int CA,
-                               float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1, float* const* line_acc = nullptr)
+                               float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1, const HrTrainWindow* win = nullptr)
 {
     dpn[0] = 0.0f; dpn[1] = 0.0f; dpn[2] = 0.0f;
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = a.planes[j];
         const int nch = 4 * (g.cd4 + g.ca4);
-        if (nch == 0) continue;
+        if (nch == 0 || (win && !((win->pairs >> j) & 1u))) continue;
         const hr_axis_tap_g& gx = ax[hr_plane_a0(j)];
         const hr_axis_tap_g& gy = ax[hr_plane_a1(j)];
         const hr_axis_tap_g& gv = ax[hr_plane_v(j)];
         const HrTrainTaps t = hr_train_taps(g, gx.t, gy.t, gv.t, at.t);
         float d3[3] = {0.0f, 0.0f, 0.0f};
         for (int ch = ch0; ch < nch; ch += stride)
-            hr_train_gather_bwd_channel(a, j, t, gx, gy, gv, at, ch, M, dM, CA, dfeat, dpre, d3, line_acc ? line_acc[j] : nullptr);
+            hr_train_gather_bwd_channel(a, j, t, gx, gy, gv, at, ch, M, dM, CA, dfeat, dpre, d3, win);
         dpn[hr_plane_a0(j)] += d3[0] * gx.mult;
         dpn[hr_plane_a1(j)] += d3[1] * gy.mult;
         dpn[hr_plane_v(j)] += d3[2] * gv.mult;
@@ -680,12 +694,25 @@ HR_FN HrTrainRay hr_train_ray(const hr_config& c, const float* r)
     return q;
 }
 
+// The keyframe row a ray's time taps start at (the i0 of hr_train_ray's tap_t before clamping, held to [-1, K - 1]): rays with the
+// same row blend between the same two rows of every time plane
+HR_FN int hr_train_time_row(const hr_config& c, const float* r)
+{
+    float base_t = 0.0f;
+    if (c.advect) base_t = hr_base_time(c, r[c.ray_dim - 1]);
+    const int n = c.video ? c.num_keyframes : 2;
+    const float g = c.video ? hr_normalize_time(c, base_t) : 0.0f;
+    const float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+    const float f0 = fminf(fmaxf(floorf(ix), -1.0f), (float)(n - 1));
+    return (int)f0;
+}
+
 // Phase B: the sample of sorted rank k of `ray`.  M / dM: the ray's decode matrix and its gradient accumulator (3 * CA).
 // The host calls it once per sample; on the device the `lanes` (a power of two <= 64, adjacent lanes of one wavefront)
 // threads of a sample call it together with their `lane`, split the channels between them and combine their shares of
 // the point gradient with HR_LANE_SUM.
 HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane = 0,
-                               int lanes = 1, float* const* line_acc = nullptr)
+                               int lanes = 1, const HrTrainWindow* win = nullptr)
 {
     const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total;
     const int64_t s = ray * Z + k, NS = a.n_rays * Z;
@@ -700,7 +727,7 @@ HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t
         hr_axis_tap_g ax[3];
         for (int i = 0; i < 3; ++i) ax[i] = hr_make_tap_g(hr_normalize_coord(c, p[i], i), c.grid[i]);
         float dpn[3];
-        hr_train_gather_bwd(a, ax, q.tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, line_acc);
+        hr_train_gather_bwd(a, ax, q.tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, win);
         for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], lanes) * c.inv_size[i];
     }
     if (lane != 0) return;
@@ -712,7 +739,7 @@ HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t
 // point, contraction or tap arithmetic repeated by every lane -- and the per-sample tail (hr_sample_point_bwd) is
 // hr_sample_train_point_bwd's, one lane per sample.
 HR_FN void hr_sample_train_bwd_taps(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane, int lanes,
-                                    float* const* line_acc)
+                                    const HrTrainWindow* win)
 {
     const int Z = c.z_channels, CA = a.ca_total;
     const int64_t s = ray * Z + k, NS = a.n_rays * Z;
@@ -733,10 +760,11 @@ HR_FN void hr_sample_train_bwd_taps(const hr_config& c, const HrTrainArgs& a, in
         if (c.advect) base_t = hr_base_time(c, a.rays[ray * c.ray_dim + c.ray_dim - 1]);
         const hr_axis_tap_g tap_t = hr_make_tap_g(c.video ? hr_normalize_time(c, base_t) : 0.0f, c.video ? c.num_keyframes : 2);
         float dpn[3];
-        hr_train_gather_bwd(a, ax, tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, line_acc);
+        hr_train_gather_bwd(a, ax, tap_t, M, dM, CA, dfeat, dpre, dpn, lane, lanes, win);
         for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], lanes) * c.inv_size[i];
     }
     if (lane != 0) return;
+    if (win && win->add_dp) { dp[0] += a.tape.dp[s]; dp[1] += a.tape.dp[NS + s]; dp[2] += a.tape.dp[2 * NS + s]; }
     a.tape.dp[s] = dp[0]; a.tape.dp[NS + s] = dp[1]; a.tape.dp[2 * NS + s] = dp[2];
 }
 

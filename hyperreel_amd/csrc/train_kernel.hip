@@ -354,35 +354,82 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
     }
 }
 
-#define HR_TRAIN_LINES_RPB(ZP) (((1024 / HR_TRAIN_LPS) + (ZP) - 1) / (ZP))
-template <int ZP>
-__global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
+// rays per trip: four samples per 16-lane group between the barriers (the per-trip staging of the decode matrices, its barriers and
+// the fold into basis_mat's gradient are then a quarter; measured 1 / 2 / 4 / 8 samples: DoNeRF sample-stage backward 0.84 / 0.80 /
+// 0.78 / 0.77 ms, immersive 1.46 / 1.32 / 1.24 / 1.21, neural_3d 2.56 / 2.32 / 2.19 / 2.14 -- profiles/r03_c_train_experiments.txt)
+#ifndef HR_TRAIN_TRIP_MULT
+#define HR_TRAIN_TRIP_MULT 4
+#endif
+#define HR_TRAIN_LINES_RPB(ZP) (HR_TRAIN_TRIP_MULT * (((1024 / HR_TRAIN_LPS) + (ZP) - 1) / (ZP)))
+// Phase B with the contended part of the gradient in LDS.  Static nets (KEYED = false): the three lines, whole -- a few hundred
+// texels that every sample of the batch hits.  Keyframe nets (KEYED = true): the two rows of each time plane that the rays of
+// one keyframe interval blend between -- the batch's rays are walked in the order of tape.perm (grouped by that row,
+// hr_train_bucket_kernel), every workgroup takes a contiguous range of that order and moves its window (adding it to the global
+// gradient) when the row changes: 12 keyframes x a few hundred texels take the time-plane adds of all 524 288 samples of a batch,
+// as global atomics they were 2-3 ms of the keyframe families' step.  `pairs`: the plane pairs of this pass (HrTrainWindow).
+template <int ZP, bool KEYED>
+__global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a, const unsigned pairs, const int add_dp)
 {
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
-    constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);    // rays per trip: one sample per 16-lane group between the barriers (four were slower: 1.43 vs 1.32 ms)
-    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the three lines | basis_mat's gradient
+    constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the windows | basis_mat's gradient
     const int CA = a.ca_total, Z = c.z_channels;
-    float* line_acc[3];
-    int line_n[3];
+    HrTrainWindow win;
+    win.pairs = pairs;
+    win.add_dp = add_dp;
     float* bacc;
     const int nb = hr_train_basis_rows(c) * a.n_basis_cols;
     {
         float* p = lds + 2 * RPB * 3 * CA;
-        for (int j = 0; j < 3; ++j) { line_acc[j] = p; line_n[j] = a.planes[j].bh * a.planes[j].tex; p += line_n[j]; }
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& g = a.planes[j];
+            const bool on = ((pairs >> j) & 1u) && (g.cd4 + g.ca4) > 0;
+            win.acc[j] = on ? p : nullptr;
+            win.lo[j] = 0;
+            win.n[j] = on ? (KEYED ? 2 * g.bw : g.bh) : 0;
+            p += win.n[j] * g.tex;
+        }
         bacc = p;
         p += nb;
         for (float* q = lds + 2 * RPB * 3 * CA + threadIdx.x; q < p; q += 1024) *q = 0.0f;
     }
+    // add the windows to the global gradient and clear them (the caller has a barrier on both sides)
+    auto flush = [&]() {
+        for (int j = 0; j < 3; ++j) {
+            if (!win.acc[j]) continue;
+            const int tex = a.planes[j].tex, cnt = win.n[j] * tex;
+            float* dst = a.g_b[j] + (int64_t)win.lo[j] * tex;       // a row outside the plane was never added to: stays zero, is never written
+            for (int i = threadIdx.x; i < cnt; i += 1024) {
+                const float v = win.acc[j][i];
+                if (v != 0.0f) { HR_ATOMIC_ADD(dst + i, v); win.acc[j][i] = 0.0f; }
+            }
+        }
+    };
     const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
-    for (int64_t ray0 = (int64_t)blockIdx.x * RPB; ray0 < a.n_rays; ray0 += (int64_t)gridDim.x * RPB) {
+    const int64_t trips = (a.n_rays + RPB - 1) / RPB;
+    // static: trips blockIdx.x, + gridDim.x, ...; keyed: a contiguous range of the grouped order, so that the window moves rarely
+    const int64_t t_begin = KEYED ? (trips * blockIdx.x) / gridDim.x : blockIdx.x;
+    const int64_t t_end = KEYED ? (trips * (blockIdx.x + 1)) / gridDim.x : trips;
+    const int64_t t_step = KEYED ? 1 : gridDim.x;
+    int row = -0x7fffffff;
+    for (int64_t trip = t_begin; trip < t_end; trip += t_step) {
+        const int64_t ray0 = trip * RPB;
         __syncthreads();
+        if (KEYED) {
+            const int r0 = hr_train_time_row(c, a.rays + (int64_t)a.tape.perm[ray0] * c.ray_dim);
+            if (r0 != row) {                       // uniform over the workgroup
+                if (row != -0x7fffffff) flush();
+                row = r0;
+                for (int j = 0; j < 3; ++j) win.lo[j] = r0 * a.planes[j].bw;
+            }
+        }
         for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
             const int r = e / (3 * CA), i = e - r * 3 * CA;
             float v = 0.0f;
             if (ray0 + r < a.n_rays) {
                 float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+                const float* rr = a.rays + (KEYED ? (int64_t)a.tape.perm[ray0 + r] : ray0 + r) * c.ray_dim;
                 if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
                 v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
             }
@@ -393,15 +440,16 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
         for (int si = grp; si < RPB * Z; si += GROUPS) {
             const int r = si / Z, k = si - r * Z;
             if (ray0 + r >= a.n_rays) continue;
-            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
-            else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, line_acc);
+            const int64_t ray = KEYED ? (int64_t)a.tape.perm[ray0 + r] : ray0 + r;
+            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, &win);
+            else hr_sample_train_bwd(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, &win);
         }
         __syncthreads();
         for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
             const int r = e / (3 * CA), i = e - r * 3 * CA;
             if (ray0 + r >= a.n_rays) continue;
             float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* rr = a.rays + (ray0 + r) * c.ray_dim;
+            const float* rr = a.rays + (KEYED ? (int64_t)a.tape.perm[ray0 + r] : ray0 + r) * c.ray_dim;
             if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
             hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e], bacc);
         }
@@ -411,38 +459,84 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
         const float v = bacc[e];
         if (v != 0.0f) HR_ATOMIC_ADD(a.d_basis + e, v);
     }
-    for (int j = 0; j < 3; ++j)
-        for (int i = threadIdx.x; i < line_n[j]; i += 1024) {
-            const float v = line_acc[j][i];
-            if (v != 0.0f) HR_ATOMIC_ADD(a.g_b[j] + i, v);
-        }
+    flush();
 }
 
-// bytes of LDS the lines of a static net need, 0 when the kernel above does not apply (a keyframe net's time planes)
-static size_t hr_train_line_bytes(const HrTrainArgs& args)
+// Keyframe nets: tape.perm = the batch's ray indices grouped by hr_train_time_row (a counting sort in one workgroup: a batch is
+// 16 384 rays; the order inside a group is whatever the LDS counters hand out).  LDS: num_keyframes + 1 counters.
+__global__ __launch_bounds__(1024) void hr_train_bucket_kernel(const hr_config* __restrict__ cfgp, const float* __restrict__ rays, int64_t n, int* __restrict__ perm)
+{
+    const hr_config& c = *cfgp;
+    extern __shared__ int cnt[];
+    const int nb = (c.video ? c.num_keyframes : 2) + 1;         // rows -1 .. K - 1
+    for (int i = threadIdx.x; i < nb; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < n; r += 1024) atomicAdd(&cnt[hr_train_time_row(c, rays + r * c.ray_dim) + 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < nb; ++b) { const int t = cnt[b]; cnt[b] = acc; acc += t; }
+    }
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < n; r += 1024) perm[atomicAdd(&cnt[hr_train_time_row(c, rays + r * c.ray_dim) + 1], 1)] = (int)r;
+}
+
+// LDS bytes of the windows of plane pairs `pairs`; keyed: two rows of each time plane, else the whole lines
+static size_t hr_train_window_bytes(const HrTrainArgs& args, unsigned pairs, bool keyed)
 {
     size_t n = 0;
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = args.planes[j];
-        if (g.cd4 + g.ca4 == 0) continue;
-        if (g.bw != 1) return 0;
-        n += sizeof(float) * (size_t)g.bh * g.tex;
+        if (g.cd4 + g.ca4 == 0 || !((pairs >> j) & 1u)) continue;
+        n += sizeof(float) * (size_t)(keyed ? 2 * g.bw : g.bh) * g.tex;
     }
     return n;
 }
 
 template <int ZP>
-static bool hr_launch_gather_bwd_lines(const HrTrainArgs& args, hipStream_t stream)
+static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
 {
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
-    const size_t line_bytes = hr_train_line_bytes(args);
-    const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols) + line_bytes;
-    if (line_bytes == 0 || lds > 150 * 1024) return false;
-    static HrLdsOptIn opt;
-    if (!hr_lds_opt_in(opt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP>), lds)) return false;
+    bool any = false, keyed = false;
+    for (int j = 0; j < 3; ++j)
+        if (args.planes[j].cd4 + args.planes[j].ca4 > 0) { any = true; keyed = keyed || args.planes[j].bw != 1; }
+    if (!any) return false;
+#ifdef HR_TRAIN_NO_WINDOWS          // measurement builds: the global-atomics kernel for everything
+    return false;
+#endif
+    const size_t base = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
+    const size_t cap = 150 * 1024;
     const int64_t iters = (args.n_rays + RPB - 1) / RPB;
     const int cus = hr_current_device_cus();
-    hipLaunchKernelGGL(hr_train_gather_bwd_lines_kernel<ZP>, dim3((unsigned)(iters < cus ? iters : cus)), dim3(1024), lds, stream, args.cfg_dev, args);
+    const unsigned blocks = (unsigned)(iters < cus ? iters : cus);
+    if (!keyed) {
+        const size_t lds = base + hr_train_window_bytes(args, 7u, false);
+        if (lds > cap) return false;
+        static HrLdsOptIn opt;
+        if (!hr_lds_opt_in(opt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, false>), lds)) return false;
+        hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, false>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, 7u, 0);
+        return true;
+    }
+    // keyframe net: needs the taps on the tape (two passes re-read them) and the grouped order; all pairs in one pass if their
+    // rows fit, else pair 0 (the wide one) and pairs 1 + 2
+    if (!args.tape.taps || !args.tape.dp || !args.tape.perm || args.n_rays > 0x7fffffff || !cfg.video || cfg.num_keyframes < 2 || cfg.num_keyframes > 8192) return false;
+    unsigned passes[2] = {7u, 0u};
+    if (base + hr_train_window_bytes(args, 7u, true) > cap) { passes[0] = 1u; passes[1] = 6u; }
+    size_t lds_max = 0;
+    for (int p = 0; p < 2; ++p) {
+        if (!passes[p]) continue;
+        const size_t lds = base + hr_train_window_bytes(args, passes[p], true);
+        if (lds > cap) return false;
+        lds_max = lds > lds_max ? lds : lds_max;
+    }
+    static HrLdsOptIn kopt;
+    if (!hr_lds_opt_in(kopt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, true>), lds_max)) return false;
+    hipLaunchKernelGGL(hr_train_bucket_kernel, dim3(1), dim3(1024), sizeof(int) * (cfg.num_keyframes + 1), stream, args.cfg_dev, args.rays, args.n_rays, args.tape.perm);
+    for (int p = 0; p < 2; ++p) {
+        if (!passes[p]) continue;
+        const size_t lds = base + hr_train_window_bytes(args, passes[p], true);
+        hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, true>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, passes[p], p);
+    }
     return true;
 }
 
@@ -484,12 +578,12 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
     if (!args.d_rgb) return;
     bool done = false;
     switch (ZP) {
-        case 8: done = hr_launch_gather_bwd_lines<8>(args, stream); break;
-        case 16: done = hr_launch_gather_bwd_lines<16>(args, stream); break;
-        case 32: done = hr_launch_gather_bwd_lines<32>(args, stream); break;
-        case 64: done = hr_launch_gather_bwd_lines<64>(args, stream); break;
-        case 128: done = hr_launch_gather_bwd_lines<128>(args, stream); break;
-        case 256: done = hr_launch_gather_bwd_lines<256>(args, stream); break;
+        case 8: done = hr_launch_gather_bwd_lines<8>(cfg, args, stream); break;
+        case 16: done = hr_launch_gather_bwd_lines<16>(cfg, args, stream); break;
+        case 32: done = hr_launch_gather_bwd_lines<32>(cfg, args, stream); break;
+        case 64: done = hr_launch_gather_bwd_lines<64>(cfg, args, stream); break;
+        case 128: done = hr_launch_gather_bwd_lines<128>(cfg, args, stream); break;
+        case 256: done = hr_launch_gather_bwd_lines<256>(cfg, args, stream); break;
         default: break;
     }
     const int GROUPS = 256 / HR_TRAIN_LPS;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over a short bench run (counters in separate passes; kernel-trace only).
-# usage: tools/pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>_<pass>.csv
+# usage: tools/pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>_<pass>.txt
+#        PMC_CMD="python tools/train_bench.py --model immersive_sphere --steps 3" tools/pmc.sh <tag>   (another command, from the repo root)
 set -u
 tag=$1; shift
 export TMPDIR=/tmp
@@ -15,7 +16,7 @@ for ctrs in \
   "TA_TA_BUSY_sum TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing --no-extras "$@" > /tmp/pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$i -o p -- bash -c "cd $GRAFT_REPO_ROOT && ${PMC_CMD:-python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-stage-timing --no-extras $*}" > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python - "$f" "$ctrs" <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i.txt
