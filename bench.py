@@ -613,7 +613,7 @@ def main():
         try:     # SURVEY 8f-4 / BASELINE configs[2]: one optimizer step of the training loop (nlf/__init__.py:634-709), batch 16 384
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from train_bench import train_step_figures
-            result['train_step'] = {m: train_step_figures(m, 16384, 15, torch_gpu=False, blas=False) for m in ('donerf_sphere', 'technicolor_z_plane')}
+            result['train_step'] = {m: train_step_figures(m, 16384, 15, torch_gpu=False, blas=False) for m in ('donerf_sphere', 'technicolor_z_plane', 'neural_3d_z_plane', 'immersive_sphere')}
         except Exception as e:
             result['train_step'] = {'error': repr(e)}
 
