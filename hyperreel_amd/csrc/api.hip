@@ -159,7 +159,9 @@ int validate(const hr_config& c, bool coarse = false)
     if (c.isect_type == HR_ISECT_VOXEL_GRID && c.z_channels % 3) return fail(HR_E_INVALID, "voxel_grid needs z_channels divisible by 3");
     if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID && (c.dvg_axes < 1 || c.dvg_axes > 3 || c.z_channels % c.dvg_axes))
         return fail(HR_E_INVALID, "deformable_voxel_grid needs 1..3 start normals dividing z_channels");
-    if (c.contract_type < HR_CONTRACT_IDENTITY || c.contract_type > HR_CONTRACT_AFFINE) return fail(HR_E_INVALID, "unknown contract_type");
+    if (c.contract_type < HR_CONTRACT_IDENTITY || c.contract_type > HR_CONTRACT_DONERF) return fail(HR_E_INVALID, "unknown contract_type");
+    if (c.contract_type == HR_CONTRACT_DONERF && !(c.c_pow_fac > 0.0f && c.c_pow_power > 0.0f && c.c_pow_inv_power > 0.0f))
+        return fail(HR_E_INVALID, "donerf contraction needs positive c_pow_fac / c_pow_power / c_pow_inv_power");
     if (c.contract_type == HR_CONTRACT_AFFINE)
         for (int i = 0; i < 3; ++i)
             if (c.c_aff_size[i] == 0.0f) return fail(HR_E_INVALID, "affine contraction with an empty box");

@@ -199,13 +199,25 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out, int 
 }
 
 // ---------------------------------------------------------------- contraction (nlf/contract.py)
+// torch.pow(x, scalar) as ATen evaluates it on float32 (pow_tensor_scalar_optimized_kernel): 0.5 -> sqrt, 2 -> x * x, else powf
+HR_FN float hr_pow_scalar(float x, float e)
+{
+    if (e == 0.5f) return HR_SQRT(x);
+    if (e == 2.0f) return x * x;
+    return powf(x, e);
+}
+
 // inverse_contract_distance: MIPNeRFContract contract.py:143-158 (identity distance_activation);
-// BBoxContract :78-79 / ZDepthContract :104-105 (d * fac)
+// BBoxContract :78-79 / ZDepthContract :104-105 (d * fac); DoNeRFContract :226-230
 HR_FN float hr_inverse_contract_distance(const hr_config& c, float distance)
 {
     if (c.contract_type == HR_CONTRACT_AFFINE) return distance * c.c_aff_fac;
     distance = (distance * 0.5f) * 2.0f;             // x/2*2, exact either way
     distance = fminf(fmaxf(distance, -2.0f), 2.0f);
+    if (c.contract_type == HR_CONTRACT_DONERF) {
+        const float sgn0 = (distance > 0.0f) ? 1.0f : ((distance < 0.0f) ? -1.0f : 0.0f);
+        return HR_DIV(hr_pow_scalar(fabsf(distance) + 1e-8f, c.c_pow_power) * sgn0, c.c_pow_fac);
+    }
     float t = 2.0f - fabsf(distance);
     float inv = HR_DIV(t, c.c_d_scale) + c.c_d_inv_end;
     float sgn = (distance > 0.0f) ? 1.0f : ((distance < 0.0f) ? -1.0f : 0.0f);
@@ -220,6 +232,12 @@ HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, f
         q[0] = HR_DIVP(px - c.c_aff_min[0], c.c_aff_size[0]);
         q[1] = HR_DIVP(py - c.c_aff_min[1], c.c_aff_size[1]);
         q[2] = HR_DIVP(pz - c.c_aff_min[2], c.c_aff_size[2]);
+        return;
+    }
+    if (c.contract_type == HR_CONTRACT_DONERF) {     // contract.py:238-240: (p / |p|) * (|p| fac + 1e-8)^(1/power); 0/0 at the origin, as there
+        const float dn = HR_SQRTP(px * px + py * py + pz * pz);
+        const float s = hr_pow_scalar(dn * c.c_pow_fac + 1e-8f, c.c_pow_inv_power);
+        q[0] = HR_DIVP(px, dn) * s; q[1] = HR_DIVP(py, dn) * s; q[2] = HR_DIVP(pz, dn) * s;
         return;
     }
     px = HR_DIVP(px, c.c_r0); py = HR_DIVP(py, c.c_r0); pz = HR_DIVP(pz, c.c_r0);

@@ -132,6 +132,8 @@ HR_FN float hr_inverse_contract_distance_grad(const hr_config& c, float distance
 {
     if (c.contract_type == HR_CONTRACT_AFFINE) return c.c_aff_fac;
     if (distance < -2.0f || distance > 2.0f) return 0.0f;           // clamp
+    if (c.contract_type == HR_CONTRACT_DONERF)                      // d/dd sign(d) (|d| + 1e-8)^power / fac
+        return c.c_pow_power * powf(fabsf(distance) + 1e-8f, c.c_pow_power - 1.0f) / c.c_pow_fac;
     if (fabsf(distance) < 1.0f) return c.c_d0;
     const float inv = (2.0f - fabsf(distance)) / c.c_d_scale + c.c_d_inv_end;
     return c.c_d0 / (inv * inv * c.c_d_scale);
@@ -142,6 +144,20 @@ HR_FN void hr_contract_point_bwd(const hr_config& c, float px, float py, float p
 {
     if (c.contract_type == HR_CONTRACT_AFFINE) {
         dp[0] = dq[0] / c.c_aff_size[0]; dp[1] = dq[1] / c.c_aff_size[1]; dp[2] = dq[2] / c.c_aff_size[2];
+        return;
+    }
+    if (c.contract_type == HR_CONTRACT_DONERF) {
+        // q = u s(n), u = p / n, s = (n fac + 1e-8)^(1/power), s' = fac / power * (n fac + 1e-8)^(1/power - 1)
+        const float n = sqrtf(px * px + py * py + pz * pz);
+        const float b = n * c.c_pow_fac + 1e-8f;
+        const float s = powf(b, c.c_pow_inv_power);
+        const float sp = c.c_pow_fac * c.c_pow_inv_power * powf(b, c.c_pow_inv_power - 1.0f);
+        const float ux = px / n, uy = py / n, uz = pz / n;
+        const float ud = ux * dq[0] + uy * dq[1] + uz * dq[2];
+        const float k = s / n;
+        dp[0] = k * (dq[0] - ux * ud) + sp * ux * ud;
+        dp[1] = k * (dq[1] - uy * ud) + sp * uy * ud;
+        dp[2] = k * (dq[2] - uz * ud) + sp * uz * ud;
         return;
     }
     const float x = px / c.c_r0, y = py / c.c_r0, z = pz / c.c_r0;

@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 

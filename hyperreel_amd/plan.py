@@ -36,7 +36,7 @@ PE = {None: 0, 'windowed': 1, 'basic': 2}
 ISECT = {'z_plane': 0, 'sphere': 1, 'cylinder': 2, 'sphere_new': 3, 'cylinder_new': 4, 'euclidean_distance_unified': 5,
          'voxel_grid': 6, 'deformable_voxel_grid': 7}
 ISECT_Z_CHANNELS = {0: 1, 1: 4, 2: 4, 3: 8, 4: 8, 5: 1, 6: 1, 7: 4}     # z_vals channels each type reads per sample
-CONTRACT = {'identity': 0, 'mipnerf': 1, 'bbox': 2, 'z_depth': 2}   # bbox and z_depth share the affine kernel path
+CONTRACT = {'identity': 0, 'mipnerf': 1, 'bbox': 2, 'z_depth': 2, 'donerf': 3}   # bbox and z_depth share the affine kernel path
 DENSITY = {'relu': 0, 'softplus': 1, 'relu_abs': 2}
 SHADING = {'RGB': 0, 'SH': 1}
 
@@ -74,6 +74,7 @@ class hr_config(C.Structure):
         ('c_r0', C.c_float), ('c_r_inv_end', C.c_float), ('c_r_scale', C.c_float),
         ('c_d0', C.c_float), ('c_d_inv_end', C.c_float), ('c_d_scale', C.c_float),
         ('c_aff_min', C.c_float * 3), ('c_aff_size', C.c_float * 3), ('c_aff_fac', C.c_float),
+        ('c_pow_fac', C.c_float), ('c_pow_power', C.c_float), ('c_pow_inv_power', C.c_float),
         ('advect', C.c_int32), ('use_spatial_flow', C.c_int32), ('flow_fac', C.c_float), ('flow_inv_fac', C.c_float),
         ('flow_kmax', C.c_float), ('flow_act', hr_act),
         ('point_offset', C.c_int32), ('offset_act', hr_act),
@@ -204,6 +205,26 @@ def _absent_field():
     return f
 
 
+def torch_pow_f32(x, exponent):
+    """torch.pow(float32 tensor, python scalar) on CPU: ATen special-cases the exponents 0.5, 2, 3, -0.5, -1, -2
+    (pow_tensor_scalar_optimized_kernel) and evaluates the rest as float32 powf."""
+    x = np.asarray(x, F32)
+    e = float(exponent)
+    if e == 0.5:
+        return np.sqrt(x).astype(F32)
+    if e == 2.0:
+        return (x * x).astype(F32)
+    if e == 3.0:
+        return (x * x * x).astype(F32)
+    if e == -0.5:
+        return (F32(1.0) / np.sqrt(x)).astype(F32)
+    if e == -1.0:
+        return (F32(1.0) / x).astype(F32)
+    if e == -2.0:
+        return (F32(1.0) / (x * x)).astype(F32)
+    return np.power(x, F32(e)).astype(F32)
+
+
 def torch_linspace_f32(start, end, steps):
     """torch.linspace for float32 on CPU: two-sided evaluation around the midpoint."""
     start, end = F32(start), F32(end)
@@ -241,6 +262,33 @@ class _MipNerf:
         t = (inv - F32(inv_end)) * F32(scale)
         out = d / F32(1.0) if np.abs(d) < 1.0 else np.sign(d) * (F32(2.0) - t)
         return F32((F32(out) / F32(2.0)) * F32(2.0))
+
+
+class _DoNeRF:
+    """Setup-time arithmetic of DoNeRFContract (nlf/contract.py:195-240): fac and power are python / numpy doubles there and enter
+    the float32 tensor ops as float32 scalars."""
+
+    def __init__(self, c, ds):
+        if c.get('use_dataset_bounds', False):
+            r0 = c.get('contract_start_radius', max(ds['depth_range'][0] * 1.75, 1.0))
+            r1 = c.get('contract_end_radius', ds['depth_range'][1] * 1.5)
+        else:
+            r0 = c.get('contract_start_radius', None)
+            r1 = c.get('contract_end_radius', 10000.0)
+        if r0 is None:
+            self.power = float(c.get('power', 2.0))
+            self.fac = float(np.power(2.0, self.power) / r1)
+        else:
+            self.fac = 1.0 / r0
+            self.power = float(np.log(r1 / r0) / np.log(2.0))
+        self.inv_power = 1.0 / self.power
+        if 'distance_activation' in c:
+            raise NotImplementedError('contract.distance_activation is outside the hot-path scope')
+
+    def contract_distance(self, distance):             # contract.py:232-236, on a 0-dim float32 tensor
+        d = F32(distance) * F32(self.fac)
+        d = torch_pow_f32(np.abs(d) + F32(1e-8), self.inv_power) * np.sign(d)
+        return F32((F32(d) / F32(2.0)) * F32(2.0))
 
 
 class _Affine:
@@ -498,6 +546,9 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
             inv_end = contract.d0 / contract.d1
             hc.c_d_inv_end = float(inv_end)
             hc.c_d_scale = float(1.0 / (1.0 - inv_end))
+        elif ct == 'donerf':
+            contract = _DoNeRF(ic['contract'], dataset)
+            hc.c_pow_fac, hc.c_pow_power, hc.c_pow_inv_power = float(contract.fac), float(contract.power), float(contract.inv_power)
         elif hc.contract_samples:
             hc.contract_samples = 0          # IdentityContract.inverse_contract_distance is the identity
     cdist = contract.contract_distance if (hc.contract_samples and contract is not None) else (lambda v: F32(v))

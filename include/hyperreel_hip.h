@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 19
+#define HR_ABI_VERSION 20
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -91,7 +91,9 @@ enum {
 };
 /* nlf/contract.py: IdentityContract (:53-62), MIPNeRFContract (:113-192); BBoxContract (:65-87) and
  * ZDepthContract (:90-111) are both the affine map p -> (p - c_aff_min) / c_aff_size, d -> d / c_aff_fac */
-enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1, HR_CONTRACT_AFFINE = 2 };
+enum { HR_CONTRACT_IDENTITY = 0, HR_CONTRACT_MIPNERF = 1, HR_CONTRACT_AFFINE = 2,
+       /* DoNeRFContract (contract.py:195-240): p -> p / |p| * (|p| fac + 1e-8)^(1/power), d -> sign(d) (|d| + 1e-8)^power / fac */
+       HR_CONTRACT_DONERF = 3 };
 enum { HR_DENSITY_RELU = 0, HR_DENSITY_SOFTPLUS = 1, HR_DENSITY_RELU_ABS = 2 };
 enum { HR_SHADING_RGB = 0, HR_SHADING_SH = 1 };
 /* arithmetic of the MLP GEMMs: exact fp32 MFMA, or three 16-bit MFMA products of the hi/lo split operands with fp32
@@ -161,6 +163,7 @@ typedef struct hr_config {
     float c_d0, c_d_inv_end, c_d_scale;  /* distance: start distance, d0/d1, 1/(1-d0/d1) */
     float c_aff_min[3], c_aff_size[3];   /* affine: bbox_min, bbox_max - bbox_min (z_depth: 0, fac) */
     float c_aff_fac;                     /* affine: inverse_contract_distance(d) = d * fac */
+    float c_pow_fac, c_pow_power, c_pow_inv_power;   /* donerf: fac, power, 1/power as the reference holds them (float32 of its python floats) */
     /* ---- advect (nlf/embedding/point.py:780-831, utils/flow_utils.py:10-35) */
     int32_t advect;
     int32_t use_spatial_flow;

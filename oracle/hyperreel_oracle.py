@@ -280,6 +280,69 @@ class ZDepthContract(_AffineContract):
         return (p / F32(self.fac)).astype(F32)
 
 
+def _torch_pow(x, exponent):
+    """torch.pow(float32 tensor, python scalar) on CPU: exponents 0.5 / 2 / 3 / -0.5 / -1 / -2 are sqrt / products / reciprocals
+    (ATen pow_tensor_scalar_optimized_kernel), the rest float32 powf."""
+    x = np.asarray(x, F32)
+    e = float(exponent)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        if e == 0.5:
+            return np.sqrt(x).astype(F32)
+        if e == 2.0:
+            return (x * x).astype(F32)
+        if e == 3.0:
+            return (x * x * x).astype(F32)
+        if e == -0.5:
+            return (F32(1.0) / np.sqrt(x)).astype(F32)
+        if e == -1.0:
+            return (F32(1.0) / x).astype(F32)
+        if e == -2.0:
+            return (F32(1.0) / (x * x)).astype(F32)
+        return np.power(x, F32(e)).astype(F32)
+
+
+class DoNeRFContract:
+    """nlf/contract.py:195-240."""
+
+    def __init__(self, cfg, dataset):
+        self.contract_samples = bool(cfg.get('contract_samples', False))
+        if cfg.get('use_dataset_bounds', False):
+            r0 = cfg.get('contract_start_radius', max(dataset['depth_range'][0] * 1.75, 1.0))
+            r1 = cfg.get('contract_end_radius', dataset['depth_range'][1] * 1.5)
+        else:
+            r0 = cfg.get('contract_start_radius', None)
+            r1 = cfg.get('contract_end_radius', 10000.0)
+        if r0 is None:
+            self.power = float(cfg.get('power', 2.0))
+            self.fac = float(np.power(2.0, self.power) / r1)
+        else:
+            self.fac = 1.0 / r0
+            self.power = float(np.log(r1 / r0) / np.log(2.0))
+        if 'distance_activation' in cfg:
+            raise NotImplementedError('distance_activation is outside the hot-path scope')
+
+    def inverse_contract_distance(self, distance):     # contract.py:226-230
+        distance = (_f(distance) / F32(2.0)) * F32(2.0)    # identity activation
+        distance = np.clip(distance, F32(-2.0), F32(2.0))
+        return (_torch_pow(np.abs(distance) + F32(1e-8), self.power) * np.sign(distance) / F32(self.fac)).astype(F32)
+
+    def contract_distance(self, distance):             # contract.py:232-236
+        distance = _f(distance) * F32(self.fac)
+        distance = _torch_pow(np.abs(distance) + F32(1e-8), 1.0 / self.power) * np.sign(distance)
+        return ((distance / F32(2.0)) * F32(2.0)).astype(F32)
+
+    def contract_points(self, points):                 # contract.py:238-240
+        dists = np.sqrt(np.sum(points * points, axis=-1, keepdims=True, dtype=F32))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return ((points / dists) * _torch_pow(dists * F32(self.fac) + F32(1e-8), 1.0 / self.power)).astype(F32)
+
+    def contract_points_and_distance(self, rays_o, points, distance):   # BaseContract, contract.py:43-50
+        o_c = self.contract_points(rays_o)
+        p_c = self.contract_points(points)
+        diff = p_c - o_c[..., None, :]
+        return p_c, np.sqrt(np.sum(diff * diff, axis=-1, keepdims=True, dtype=F32))
+
+
 def make_contract(cfg, dataset):
     if cfg is None:
         return IdentityContract()
@@ -294,6 +357,8 @@ def make_contract(cfg, dataset):
         return BBoxContract(cfg, dataset)
     if t == 'z_depth':
         return ZDepthContract(cfg, dataset)
+    if t == 'donerf':
+        return DoNeRFContract(cfg, dataset)
     raise NotImplementedError(f'contract {t} is outside the hot-path scope')
 
 

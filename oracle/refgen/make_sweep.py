@@ -101,6 +101,14 @@ def _v_z_depth(cfg):
     ic.contract = {'type': 'z_depth', 'contract_samples': True, 'contract_end_radius': 6.0}
 
 
+def _v_donerf_contract(cfg):                  # DoNeRFContract (contract.py:195-240) with the dataset's bounds: power = log2(r1 / r0), a general powf
+    _isect(cfg).contract = {'type': 'donerf', 'contract_samples': True, 'use_dataset_bounds': True}
+
+
+def _v_donerf_contract_pow2(cfg):             # ... and with its defaults: power 2 (torch.pow takes x * x / sqrt), fac = 4 / end radius
+    _isect(cfg).contract = {'type': 'donerf', 'contract_samples': True, 'contract_end_radius': 40.0}
+
+
 def _v_voxel_outward(cfg):
     ic = _isect(cfg)
     ic.outward_facing = True
@@ -142,6 +150,8 @@ VARIANTS = [
     ('variant_sphere_new_origins_only', 'immersive_sphere_new', _v_sphere_new_origins_only),
     ('variant_z_depth_contract', 'llff_z_plane', _v_z_depth),
     ('variant_voxel_outward', 'donerf_voxel', _v_voxel_outward),
+    ('variant_donerf_contract', 'donerf_sphere', _v_donerf_contract),
+    ('variant_donerf_contract_pow2', 'donerf_cylinder', _v_donerf_contract_pow2),
     ('variant_mask_off_unsorted', 'donerf_sphere', _v_mask_off_unsorted),
     # inside the activation / encoding warm-up windows (EaseValue, activations.py:462-496; WindowedPE, pe.py:166-208)
     ('variant_ease_iter2000', 'donerf_sphere', None, 2000),
@@ -222,6 +232,11 @@ def main(only=None, force=False):
             print(f'{name:36s} the reference raises: {coverage[name]["reason"]}')
             continue
         rgb = out['rgb'].numpy().astype(np.float32)
+        dropped = 0
+        if np.isnan(rgb).any():         # DoNeRFContract.contract_points is 0 / 0 for a ray that starts at the centre: the reference returns NaN
+            keep = ~np.isnan(rgb).any(axis=1)
+            dropped = int((~keep).sum())
+            rays, rgb = np.ascontiguousarray(rays[keep]), np.ascontiguousarray(rgb[keep])
         if force:
             sys.path.insert(0, os.path.join(ROOT, 'oracle'))
             from hyperreel_oracle import HyperReelOracle
@@ -237,6 +252,8 @@ def main(only=None, force=False):
                   'checksum': scenes.state_dict_checksum(sd)}
         if iteration is not None:
             recipe['iter'] = iteration
+        if dropped:
+            recipe['dropped_nan_rays'] = dropped
         np.savez_compressed(os.path.join(OUT, name + '.npz'), rays=rays, rgb=rgb,
                             recipe=np.frombuffer(json.dumps(recipe).encode(), dtype=np.uint8))
         coverage[name] = {'status': 'golden', 'rgb_std': float(rgb.std())}

@@ -63,6 +63,9 @@ class TorchPort:
 
     def _contract_points(self, p, c=None):                  # nlf/contract.py:178-192 (mipnerf), :84-85 / :110-111 (affine)
         c = self.o.contract if c is None else c
+        if hasattr(c, 'power'):                              # DoNeRFContract, contract.py:238-240
+            d = torch.norm(p, dim=-1, keepdim=True)
+            return (p / d) * torch.pow(d * c.fac + 1e-8, 1.0 / c.power)
         if hasattr(c, 'bbox_min'):
             lo = torch.from_numpy(c.bbox_min).to(self.dev)
             return (p - lo) / (torch.from_numpy(c.bbox_max).to(self.dev) - lo)
@@ -76,6 +79,9 @@ class TorchPort:
 
     def _inv_contract_distance(self, z, c=None):            # nlf/contract.py:143-158 (mipnerf), :78-79 / :104-105 (affine)
         c = self.o.contract if c is None else c
+        if hasattr(c, 'power'):                              # DoNeRFContract, contract.py:226-230
+            z = ((z / 2.0) * 2.0).clamp(-2.0, 2.0)
+            return torch.pow(torch.abs(z) + 1e-8, c.power) * torch.sign(z) / c.fac
         if not hasattr(c, 'r0'):
             return z * float(c.fac) if hasattr(c, 'fac') else z
         inv_end = c.d0 / c.d1

@@ -14,7 +14,10 @@ CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_sm
          # inside the EaseValue / WindowedPE warm-up windows: the derivative carries the schedule weights
          'sweep/variant_ease_iter2000', 'sweep/variant_ease_iter6000', 'sweep/variant_pe_window_iter3000',
          # voxel-grid and closest-point intersections, per-ray colour scale, z-depth contraction
-         'sweep/donerf_voxel', 'sweep/catacaustics_distance', 'sweep/variant_z_depth_contract']
+         'sweep/donerf_voxel', 'sweep/catacaustics_distance', 'sweep/variant_z_depth_contract',
+         # DoNeRFContract (general powf).  Not its power-2 fixture: that one has masked samples AT the centre, where contract_points is 0 / 0 --
+         # harmless in the forward (masked), but torch.autograd carries the NaN into every MLP gradient of the reference, so there is nothing to match
+         'sweep/variant_donerf_contract']
 
 
 def _reference_grads(g, rays, G, white):

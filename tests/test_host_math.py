@@ -71,7 +71,9 @@ def test_features_and_embedding_match_oracle(hm, case):
     hm.hm_embed(C.byref(hc), fp(rays), fp(head), n, fp(dist), fp(pts), valid.ctypes.data_as(IP), fp(bt))
     d_ref = x['distances'].reshape(n, Z)
     assert float(np.max(np.abs(dist - d_ref) / (1 + np.abs(d_ref)))) <= 1e-6
-    assert float(np.max(np.abs(pts - x['points']) / (1 + np.abs(x['points'])))) <= 1e-6
+    # DoNeRFContract.contract_points is 0 / 0 for a point at the centre (a masked sample at distance 0): NaN in the reference, here and there
+    both_nan = np.isnan(pts) & np.isnan(x['points'])
+    assert float(np.max(np.where(both_nan, 0.0, np.abs(pts - x['points']) / (1 + np.abs(x['points']))))) <= 1e-6
     if 'base_times' in x:
         assert linf(bt, x['base_times'][:, 0, 0]) == 0.0
     col = orc.color(x)

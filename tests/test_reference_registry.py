@@ -66,3 +66,27 @@ def test_registered_in_the_reference_dicts_and_built_like_inrsystem_builds_it(sh
     a = bytes(model._compile(grid)[1])
     b = bytes(plan.compile_config(C.model_config(name), ds, grid))
     assert a == b
+
+
+def test_the_reference_cannot_run_a_per_sample_color_transform_head(shim):
+    """VERDICT r2 listed per-sample `color_transform` heads (tensorf_no_sample.py:226-229 -> transform_color_all,
+    utils/tensorf_utils.py:283-306) as a leftover.  The reference's own function reshapes the (B, Z, 9) head to (B, 3, 3): it raises
+    for every Z > 1 and returns a (B, B, 3) tensor for Z = 1 -- there is no behaviour to reproduce, so plan.py keeps rejecting the
+    head by name.  The per-camera TABLE (`color_transform` embedding -> transform_color_one) is the runnable form and is
+    supported."""
+    with shim.cpu_mode():
+        from utils.tensorf_utils import transform_color_all
+    B = 5
+    for Z in (2, 32):
+        with pytest.raises(RuntimeError):
+            transform_color_all(torch.rand(B, Z, 3), torch.rand(B, Z, 9), torch.rand(B, Z, 3))
+    assert tuple(transform_color_all(torch.rand(B, 1, 3), torch.rand(B, 1, 9), torch.rand(B, 1, 3)).shape) == (B, B, 3)
+    from hyperreel_amd import scenes  # noqa: F401
+    cfg = C.model_config('donerf_sphere')
+    pred = [e for e in cfg['embedding']['embeddings'].values() if e.get('type') == 'ray_prediction'][0]
+    del pred['outputs']['color_scale']               # tensorf_no_sample.py:222-229: color_scale takes precedence
+    pred['outputs']['color_transform'] = {'channels': 9}
+    fields = cfg['embedding']['embeddings']['extract_fields']['fields']
+    fields[fields.index('color_scale')] = 'color_transform'
+    with pytest.raises(NotImplementedError, match='color_transform'):
+        plan.compile_model(C.to_cfg(C.to_plain(cfg)), C.dataset_scalars('donerf_sphere'), [8, 8, 8])
