@@ -357,6 +357,118 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
 // rays per trip: four samples per 16-lane group between the barriers (the per-trip staging of the decode matrices, its barriers and
 // the fold into basis_mat's gradient are then a quarter; measured 1 / 2 / 4 / 8 samples: DoNeRF sample-stage backward 0.84 / 0.80 /
 // 0.78 / 0.77 ms, immersive 1.46 / 1.32 / 1.24 / 1.21, neural_3d 2.56 / 2.32 / 2.19 / 2.14 -- profiles/r03_c_train_experiments.txt)
+// ---- phase B of the shipped decompositions ([8, 4, 4]: PC = 1, [8, 0, 0]: PC = 2), taps on the tape.
+// The generic path (hr_sample_train_bwd_taps) walks the three plane pairs one after the other with 16 lanes each -- pairs 1 and 2
+// have 8 channels, so half the lanes idle twice -- and keeps three run-time plane descriptors live: ~200 uniform values against ~100
+// scalar registers, i.e. 263 of its 896 VALU instructions per sample step were v_readlane_b32 restoring spilled scalars, ~190 more
+// 64-bit address arithmetic.  Here a lane has two SLOTS with compile-time texel sizes: slot A = channel `lane` of pair 0 (uniform
+// descriptor, scalar base + 32-bit offsets), slot B = channel `lane & 7` of pair 1 (lanes 0-7) or pair 2 (lanes 8-15), whose
+// descriptor is per-lane data fixed for the whole kernel.  One load round, one atomic round, one lane reduction per sample.
+struct HrBwdSlot {
+    const float* A;     // plane texels
+    const float* B;     // line / time-plane texels
+    float* GA;          // their gradients
+    float* GB;
+    float* acc;         // workgroup-private window of GB in LDS (nullptr: none), texels [lo, lo + n)
+    int lo, n;
+    int aw, bw;         // plane width; time-plane width (line: unused)
+    int ch;             // this lane's channel of the texel
+    int mslot;          // appearance slot of the channel in the ray's decode matrix, -1: a density channel
+};
+
+template <int TEX, bool KEYED>
+__device__ __forceinline__ void hr_bwd_slot(const HrBwdSlot& q, const hr_axis_tap_g& gx, const hr_axis_tap_g& gy, const hr_axis_tap_g& gv,
+                                            const hr_axis_tap& at, const float* M, float* dM, int CA, float dfeat, const float* dpre, float* d3)
+{
+    // taps (hr_train_taps) and texels (hr_train_gather_bwd_channel), same arithmetic in the same order
+    const float wa0 = gx.t.w0 * gy.t.w0, wa1 = gx.t.w1 * gy.t.w0, wa2 = gx.t.w0 * gy.t.w1, wa3 = gx.t.w1 * gy.t.w1;
+    const unsigned ia0 = (unsigned)((gy.t.i0 * q.aw + gx.t.i0) * TEX + q.ch), ia1 = (unsigned)((gy.t.i0 * q.aw + gx.t.i1) * TEX + q.ch);
+    const unsigned ia2 = (unsigned)((gy.t.i1 * q.aw + gx.t.i0) * TEX + q.ch), ia3 = (unsigned)((gy.t.i1 * q.aw + gx.t.i1) * TEX + q.ch);
+    int ib[4];
+    float wb[4];
+    if (KEYED) {
+        ib[0] = at.i0 * q.bw + gv.t.i0; ib[1] = at.i0 * q.bw + gv.t.i1; ib[2] = at.i1 * q.bw + gv.t.i0; ib[3] = at.i1 * q.bw + gv.t.i1;
+        wb[0] = gv.t.w0 * at.w0; wb[1] = gv.t.w1 * at.w0; wb[2] = gv.t.w0 * at.w1; wb[3] = gv.t.w1 * at.w1;
+    } else {
+        ib[0] = gv.t.i0; ib[1] = gv.t.i1; ib[2] = 0; ib[3] = 0;
+        wb[0] = gv.t.w0; wb[1] = gv.t.w1; wb[2] = 0.0f; wb[3] = 0.0f;
+    }
+    const float a00 = q.A[ia0], a01 = q.A[ia1], a10 = q.A[ia2], a11 = q.A[ia3];
+    const float b0 = q.B[(unsigned)(ib[0] * TEX + q.ch)], b1 = q.B[(unsigned)(ib[1] * TEX + q.ch)];
+    float b2 = 0.0f, b3 = 0.0f;
+    if (KEYED) { b2 = q.B[(unsigned)(ib[2] * TEX + q.ch)]; b3 = q.B[(unsigned)(ib[3] * TEX + q.ch)]; }
+    const float pa = fmaf(a11, wa3, fmaf(a10, wa2, fmaf(a01, wa1, a00 * wa0)));
+    const float pb = fmaf(b3, wb[3], fmaf(b2, wb[2], fmaf(b1, wb[1], b0 * wb[0])));
+    const float f = pa * pb;
+    float u;
+    if (q.mslot < 0) {
+        u = dfeat;
+    } else {
+        u = dpre[0] * M[q.mslot] + dpre[1] * M[CA + q.mslot] + dpre[2] * M[2 * CA + q.mslot];
+        HR_ATOMIC_ADD_RAY(dM + q.mslot, dpre[0] * f); HR_ATOMIC_ADD_RAY(dM + CA + q.mslot, dpre[1] * f); HR_ATOMIC_ADD_RAY(dM + 2 * CA + q.mslot, dpre[2] * f);
+    }
+    if (u == 0.0f) return;
+    const float dpa = u * pb, dpb = u * pa;
+    if (wa0 != 0.0f) HR_ATOMIC_ADD(q.GA + ia0, dpa * wa0);
+    if (wa1 != 0.0f) HR_ATOMIC_ADD(q.GA + ia1, dpa * wa1);
+    if (wa2 != 0.0f) HR_ATOMIC_ADD(q.GA + ia2, dpa * wa2);
+    if (wa3 != 0.0f) HR_ATOMIC_ADD(q.GA + ia3, dpa * wa3);
+#pragma unroll
+    for (int i = 0; i < (KEYED ? 4 : 2); ++i) {
+        if (wb[i] == 0.0f) continue;
+        const int rel = ib[i] - q.lo;
+        if (q.acc && (unsigned)rel < (unsigned)q.n) HR_ATOMIC_ADD_RAY(q.acc + (unsigned)(rel * TEX + q.ch), dpb * wb[i]);
+        else HR_ATOMIC_ADD(q.GB + (unsigned)(ib[i] * TEX + q.ch), dpb * wb[i]);
+    }
+    d3[0] += dpa * ((a00 * gx.s0 + a01 * gx.s1) * gy.t.w0 + (a10 * gx.s0 + a11 * gx.s1) * gy.t.w1);
+    d3[1] += dpa * ((a00 * gx.t.w0 + a01 * gx.t.w1) * gy.s0 + (a10 * gx.t.w0 + a11 * gx.t.w1) * gy.s1);
+    if (!KEYED) d3[2] += dpb * (b0 * gv.s0 + b1 * gv.s1);
+    else d3[2] += dpb * ((b0 * gv.s0 + b1 * gv.s1) * at.w0 + (b2 * gv.s0 + b3 * gv.s1) * at.w1);
+}
+
+// one sample, its 16 lanes together.  `sa` / `sb`: this lane's slots (sb per-lane); `on_a` / `on_b`: the pass differentiates pair 0 / pairs 1 + 2
+template <bool KEYED, int PC>
+__device__ __forceinline__ void hr_bwd_class_sample(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane,
+                                                    const HrBwdSlot& sa, const HrBwdSlot& sb, bool on_a, bool on_b, int add_dp, const hr_axis_tap& at)
+{
+    const int Z = c.z_channels, CA = a.ca_total;
+    const int64_t NS = a.n_rays * Z;
+    const unsigned s = (unsigned)(ray * Z + k);
+    const float dfeat = a.tape.dfeat[s];
+    const float dpre[3] = {a.tape.dpre[s], a.tape.dpre[NS + s], a.tape.dpre[2 * NS + s]};
+    float dp[3] = {0.f, 0.f, 0.f};
+    if (dfeat != 0.0f || dpre[0] != 0.0f || dpre[1] != 0.0f || dpre[2] != 0.0f) {     // only samples that were valid
+        hr_axis_tap_g ax[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float* t = a.tape.taps + (int64_t)(6 * i) * NS;
+            ax[i].t.i0 = __builtin_bit_cast(int, t[s]);
+            ax[i].t.i1 = __builtin_bit_cast(int, t[NS + s]);
+            ax[i].t.w0 = t[2 * NS + s]; ax[i].t.w1 = t[3 * NS + s];
+            ax[i].s0 = t[4 * NS + s]; ax[i].s1 = t[5 * NS + s];
+            ax[i].mult = 0.5f * (float)(c.grid[i] - 1);
+        }
+        float dpn[3] = {0.f, 0.f, 0.f};
+        if (on_a) {                                  // pair 0: plane (x, y), line / time plane along z
+            float d3[3] = {0.f, 0.f, 0.f};
+            hr_bwd_slot<16, KEYED>(sa, ax[0], ax[1], ax[2], at, M, dM, CA, dfeat, dpre, d3);
+            dpn[0] += d3[0] * ax[0].mult; dpn[1] += d3[1] * ax[1].mult; dpn[2] += d3[2] * ax[2].mult;
+        }
+        if (PC == 1 && on_b) {                       // pair 1 (lanes 0-7): plane (x, z), line along y; pair 2 (lanes 8-15): plane (y, z), line along x
+            const bool p1 = lane < 8;
+            hr_axis_tap_g gx = p1 ? ax[0] : ax[1], gv = p1 ? ax[1] : ax[0];
+            float d3[3] = {0.f, 0.f, 0.f};
+            hr_bwd_slot<8, KEYED>(sb, gx, ax[2], gv, at, M, dM, CA, dfeat, dpre, d3);
+            const float cx = d3[0] * gx.mult, cz = d3[1] * ax[2].mult, cv = d3[2] * gv.mult;
+            dpn[0] += p1 ? cx : cv; dpn[1] += p1 ? cv : cx; dpn[2] += cz;
+        }
+        for (int i = 0; i < 3; ++i) dp[i] = HR_LANE_SUM(dpn[i], HR_TRAIN_LPS) * c.inv_size[i];
+    }
+    if (lane != 0) return;
+    if (add_dp) { dp[0] += a.tape.dp[s]; dp[1] += a.tape.dp[NS + s]; dp[2] += a.tape.dp[2 * NS + s]; }
+    a.tape.dp[s] = dp[0]; a.tape.dp[NS + s] = dp[1]; a.tape.dp[2 * NS + s] = dp[2];
+}
+
 #ifndef HR_TRAIN_TRIP_MULT
 #define HR_TRAIN_TRIP_MULT 4
 #endif
@@ -367,18 +479,19 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
 // hr_train_bucket_kernel), every workgroup takes a contiguous range of that order and moves its window (adding it to the global
 // gradient) when the row changes: 12 keyframes x a few hundred texels take the time-plane adds of all 524 288 samples of a batch,
 // as global atomics they were 2-3 ms of the keyframe families' step.  `pairs`: the plane pairs of this pass (HrTrainWindow).
-template <int ZP, bool KEYED>
+template <int ZP, bool KEYED, int PC>
 __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a, const unsigned pairs, const int add_dp)
 {
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
-    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the windows | basis_mat's gradient
+    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | the windows | basis_mat's gradient | [RPB][4] time taps (PC != 0)
     const int CA = a.ca_total, Z = c.z_channels;
     HrTrainWindow win;
     win.pairs = pairs;
     win.add_dp = add_dp;
     float* bacc;
+    float* s_tt;
     const int nb = hr_train_basis_rows(c) * a.n_basis_cols;
     {
         float* p = lds + 2 * RPB * 3 * CA;
@@ -393,7 +506,26 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
         bacc = p;
         p += nb;
         for (float* q = lds + 2 * RPB * 3 * CA + threadIdx.x; q < p; q += 1024) *q = 0.0f;
+        s_tt = p;                                  // [RPB][4] the rays' time taps (class path)
     }
+    // class path: this lane's two slots (see HrBwdSlot)
+    const int lane16 = threadIdx.x % HR_TRAIN_LPS;
+    HrBwdSlot sa, sb;
+    {
+        const HrGridPlane& g0 = a.planes[0];
+        sa.A = reinterpret_cast<const float*>(g0.a); sa.B = reinterpret_cast<const float*>(g0.b); sa.GA = a.g_a[0]; sa.GB = a.g_b[0];
+        sa.acc = win.acc[0]; sa.lo = 0; sa.n = win.n[0]; sa.aw = g0.aw; sa.bw = g0.bw;
+        sa.ch = lane16; sa.mslot = lane16 < 8 ? -1 : lane16 - 8;
+        const int jb = lane16 < 8 ? 1 : 2;
+        const HrGridPlane& g1 = a.planes[1];
+        const HrGridPlane& g2 = a.planes[2];
+        sb.A = reinterpret_cast<const float*>(jb == 1 ? g1.a : g2.a); sb.B = reinterpret_cast<const float*>(jb == 1 ? g1.b : g2.b);
+        sb.GA = jb == 1 ? a.g_a[1] : a.g_a[2]; sb.GB = jb == 1 ? a.g_b[1] : a.g_b[2];
+        sb.acc = jb == 1 ? win.acc[1] : win.acc[2]; sb.lo = 0; sb.n = jb == 1 ? win.n[1] : win.n[2];
+        sb.aw = jb == 1 ? g1.aw : g2.aw; sb.bw = jb == 1 ? g1.bw : g2.bw;
+        sb.ch = lane16 & 7; sb.mslot = (lane16 & 7) < 4 ? -1 : (jb == 1 ? 8 : 12) + (lane16 & 7) - 4;
+    }
+    const bool on_a = (pairs & 1u) != 0, on_b = (pairs & 6u) == 6u;
     // add the windows to the global gradient and clear them (the caller has a barrier on both sides)
     auto flush = [&]() {
         for (int j = 0; j < 3; ++j) {
@@ -422,7 +554,20 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
                 if (row != -0x7fffffff) flush();
                 row = r0;
                 for (int j = 0; j < 3; ++j) win.lo[j] = r0 * a.planes[j].bw;
+                sa.lo = r0 * sa.bw;
+                sb.lo = r0 * sb.bw;
             }
+        }
+        if (PC != 0 && threadIdx.x < RPB) {        // the rays' time taps (hr_train_ray's tap_t), once per trip instead of once per sample
+            hr_axis_tap t = {0, 0, 0.0f, 0.0f};
+            if (ray0 + threadIdx.x < a.n_rays) {
+                const int64_t ray = KEYED ? (int64_t)a.tape.perm[ray0 + threadIdx.x] : ray0 + threadIdx.x;
+                float base_t = 0.0f;
+                if (c.advect) base_t = hr_base_time(c, a.rays[ray * c.ray_dim + c.ray_dim - 1]);
+                t = hr_make_tap(c.video ? hr_normalize_time(c, base_t) : 0.0f, c.video ? c.num_keyframes : 2);
+            }
+            s_tt[4 * threadIdx.x] = __builtin_bit_cast(float, t.i0); s_tt[4 * threadIdx.x + 1] = __builtin_bit_cast(float, t.i1);
+            s_tt[4 * threadIdx.x + 2] = t.w0; s_tt[4 * threadIdx.x + 3] = t.w1;
         }
         for (int e = threadIdx.x; e < RPB * 3 * CA; e += 1024) {
             const int r = e / (3 * CA), i = e - r * 3 * CA;
@@ -441,7 +586,12 @@ __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const h
             const int r = si / Z, k = si - r * Z;
             if (ray0 + r >= a.n_rays) continue;
             const int64_t ray = KEYED ? (int64_t)a.tape.perm[ray0 + r] : ray0 + r;
-            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, &win);
+            if (PC != 0) {
+                hr_axis_tap at;
+                at.i0 = __builtin_bit_cast(int, s_tt[4 * r]); at.i1 = __builtin_bit_cast(int, s_tt[4 * r + 1]);
+                at.w0 = s_tt[4 * r + 2]; at.w1 = s_tt[4 * r + 3];
+                hr_bwd_class_sample<KEYED, PC>(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, sa, sb, on_a, on_b, add_dp, at);
+            } else if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, &win);
             else hr_sample_train_bwd(c, a, ray, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, &win);
         }
         __syncthreads();
@@ -493,10 +643,42 @@ static size_t hr_train_window_bytes(const HrTrainArgs& args, unsigned pairs, boo
     return n;
 }
 
+// 1: the [8, 4, 4] decomposition, 2: [8, 0, 0] (what hr_bwd_class_sample is compiled for), 0: anything else
+static int hr_train_plane_class(const HrTrainArgs& a, const hr_config& cfg)
+{
+    const HrGridPlane* pl = a.planes;
+    auto ok = [&](int j, int cd4, int off) {
+        return pl[j].cd4 == cd4 && pl[j].ca4 == cd4 && pl[j].tex == 8 * cd4 && pl[j].app_off == off &&
+               (int64_t)pl[j].aw * pl[j].ah * pl[j].tex < (1ll << 30) && (int64_t)pl[j].bw * pl[j].bh * pl[j].tex < (1ll << 30);
+    };
+    if (!a.tape.taps || !a.tape.dp || a.n_rays * cfg.z_channels >= (1ll << 30) || !ok(0, 2, 0)) return 0;
+    if (ok(1, 1, 8) && ok(2, 1, 12) && a.ca_total == 16) return 1;
+    if (pl[1].cd4 + pl[1].ca4 == 0 && pl[2].cd4 + pl[2].ca4 == 0 && a.ca_total == 8) return 2;
+    return 0;
+}
+
+template <int ZP, bool KEYED>
+static void hr_launch_lines_kernel(int pc, unsigned blocks, size_t lds, hipStream_t stream, const HrTrainArgs& args, unsigned pairs, int add_dp)
+{
+    if (pc == 1) hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, KEYED, 1>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, pairs, add_dp);
+    else if (pc == 2) hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, KEYED, 2>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, pairs, add_dp);
+    else hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, KEYED, 0>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, pairs, add_dp);
+}
+template <int ZP, bool KEYED>
+static bool hr_lines_opt_in(int pc, size_t lds)
+{
+    static HrLdsOptIn opt[3];
+    const void* fn = pc == 1 ? reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, KEYED, 1>)
+                   : pc == 2 ? reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, KEYED, 2>)
+                             : reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, KEYED, 0>);
+    return hr_lds_opt_in(opt[pc], fn, lds);
+}
+
 template <int ZP>
 static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
 {
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
+    const int pc = hr_train_plane_class(args, cfg);
     bool any = false, keyed = false;
     for (int j = 0; j < 3; ++j)
         if (args.planes[j].cd4 + args.planes[j].ca4 > 0) { any = true; keyed = keyed || args.planes[j].bw != 1; }
@@ -504,7 +686,7 @@ static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& 
 #ifdef HR_TRAIN_NO_WINDOWS          // measurement builds: the global-atomics kernel for everything
     return false;
 #endif
-    const size_t base = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
+    const size_t base = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols + 4 * RPB);
     const size_t cap = 150 * 1024;
     const int64_t iters = (args.n_rays + RPB - 1) / RPB;
     const int cus = hr_current_device_cus();
@@ -512,9 +694,8 @@ static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& 
     if (!keyed) {
         const size_t lds = base + hr_train_window_bytes(args, 7u, false);
         if (lds > cap) return false;
-        static HrLdsOptIn opt;
-        if (!hr_lds_opt_in(opt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, false>), lds)) return false;
-        hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, false>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, 7u, 0);
+        if (!hr_lines_opt_in<ZP, false>(pc, lds)) return false;
+        hr_launch_lines_kernel<ZP, false>(pc, blocks, lds, stream, args, 7u, 0);
         return true;
     }
     // keyframe net: needs the taps on the tape (two passes re-read them) and the grouped order; all pairs in one pass if their
@@ -529,13 +710,12 @@ static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& 
         if (lds > cap) return false;
         lds_max = lds > lds_max ? lds : lds_max;
     }
-    static HrLdsOptIn kopt;
-    if (!hr_lds_opt_in(kopt, reinterpret_cast<const void*>(&hr_train_gather_bwd_lines_kernel<ZP, true>), lds_max)) return false;
+    if (!hr_lines_opt_in<ZP, true>(pc, lds_max)) return false;
     hipLaunchKernelGGL(hr_train_bucket_kernel, dim3(1), dim3(1024), sizeof(int) * (cfg.num_keyframes + 1), stream, args.cfg_dev, args.rays, args.n_rays, args.tape.perm);
     for (int p = 0; p < 2; ++p) {
         if (!passes[p]) continue;
         const size_t lds = base + hr_train_window_bytes(args, passes[p], true);
-        hipLaunchKernelGGL((hr_train_gather_bwd_lines_kernel<ZP, true>), dim3(blocks), dim3(1024), lds, stream, args.cfg_dev, args, passes[p], p);
+        hr_launch_lines_kernel<ZP, true>(pc, blocks, lds, stream, args, passes[p], p);
     }
     return true;
 }
