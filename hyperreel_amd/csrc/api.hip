@@ -103,6 +103,8 @@ struct hr_model {
     int occ_n[3] = {};
     float occ_lo[3] = {}, occ_inv[3] = {};
     // execution plan of hr_render (hr_model_set_option)
+    int frame_row = -1;                  // hr_render_frame: >= 0 while a call renders from frame_line[] (-1: general path)
+    float* frame_line[3] = {nullptr, nullptr, nullptr};   // the frame's blended keyframe rows, one line per time plane (float32 texels)
     int opt_frame_kernel = 1;              // measured equal-or-faster than the two-kernel path where it applies, at 1/20 of the HBM traffic
     int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
     int n_cus = 0;
@@ -750,6 +752,13 @@ int hr_model_finalize(hr_model* m)
         HR_HIP(hipMemcpy(m->slot_col, sc.data(), sc.size() * sizeof(int), hipMemcpyHostToDevice));
         m->basis_ld = ld;
     }
+    // hr_render_frame: one line per time plane for the frame's blended keyframe rows (float32 texels)
+    for (int j = 0; j < 3; ++j) {
+        free_dev(m->frame_line[j]);
+        const HrGridPlane& p = m->planes[j];
+        if (c.video && c.grid_dtype != HR_GRID_FP16 && p.bw > 1 && p.cd4 + p.ca4 > 0)
+            HR_HIP(hipMalloc((void**)&m->frame_line[j], sizeof(float) * (size_t)p.bw * p.tex));
+    }
     HR_HIP(hipDeviceSynchronize());
     HR_HIP(hipGetLastError());
     m->finalized = true;
@@ -867,6 +876,20 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.flags = m->flags;
 }
 
+// Plane pair j as the render kernels get it.  Inside hr_render_frame on a keyframe net all rays of the call share one time, and that time
+// sits on a keyframe row (advect_points quantises it, utils/flow_utils.py:10-35): the time plane is then handed over as the LINE that
+// row is -- the gather's line form, 2 taps instead of 4 (the other row's weight is the 1e-7 left by rounding, see hr_render_frame).
+static HrGridPlane render_plane(const hr_model* m, int j)
+{
+    HrGridPlane g = m->planes[j];
+    if (m->frame_row >= 0 && m->frame_line[j]) {
+        g.b = m->frame_line[j];
+        g.bh = g.bw;
+        g.bw = 1;
+    }
+    return g;
+}
+
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
 {
     a.cfg_dev = m->kcfg_dev;
@@ -876,7 +899,7 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.n_rays = n;
     a.rgb = rgb;
     a.fields = hr_fields();
-    for (int j = 0; j < 3; ++j) a.planes[j] = m->planes[j];
+    for (int j = 0; j < 3; ++j) a.planes[j] = render_plane(m, j);
     a.basis = m->basis;
     a.basis_t = m->basis_t;
     a.slot_col = m->slot_col;
@@ -1000,6 +1023,42 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream)
 {
     return hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
+}
+
+int hr_render_frame(hr_model* m, const float* rays_dev, int64_t n_rays, float time, float* rgb_dev, void* stream)
+{
+    if (!m) return fail(HR_E_INVALID, "null model");
+    const hr_config& c = m->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    m->frame_row = -1;
+    if (c.video && c.num_keyframes >= 2 && !m->coarse && !m->is_coarse && c.grid_dtype != HR_GRID_FP16 && m->finalized) {
+        // the time tap of every ray of the frame, as hr_sample_body computes it from the ray's last column (host restatement of
+        // hr_base_time, hr_normalize_time and hr_make_tap, csrc/hr_math.h; float32 throughout)
+        float base_t = 0.0f;
+        if (c.advect) {
+            float tt = time * c.flow_fac;
+            tt = fminf(fmaxf(tt, 0.0f), c.flow_kmax);
+            base_t = rintf(tt - 1e-5f) * c.flow_inv_fac;
+        }
+        const float g = (base_t * c.time_scale + c.time_offset) * 2.0f - 1.0f;
+        const int n = c.num_keyframes;
+        const float ix = ((g + 1.0f) / 2.0f) * (float)(n - 1);
+        const float f0 = floorf(ix), f1 = f0 + 1.0f;
+        const int i0 = (int)f0, i1 = i0 + 1;
+        const bool ok0 = i0 >= 0 && i0 < n, ok1 = i1 >= 0 && i1 < n;
+        const float w0 = ok0 ? f1 - ix : 0.0f, w1 = ok1 ? ix - f0 : 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& p = m->planes[j];
+            if (p.bw <= 1 || p.cd4 + p.ca4 == 0) continue;
+            const int row_floats = p.bw * p.tex;
+            if (!m->frame_line[j]) continue;
+            hr_launch_blend_rows(reinterpret_cast<const float*>(p.b), m->frame_line[j], row_floats, ok0 ? i0 : 0, ok1 ? i1 : 0, w0, w1, st);
+            m->frame_row = 0;
+        }
+    }
+    const int rc = hr_render_fields(m, rays_dev, n_rays, rgb_dev, nullptr, stream);
+    m->frame_row = -1;
+    return rc;
 }
 
 int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n[3], const float aabb[6], void* stream)
@@ -1533,7 +1592,7 @@ void hr_model_destroy(hr_model* m)
     free_dev(reinterpret_cast<float*&>(m->occ_cells));
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
-    for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); }
+    for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); free_dev(m->frame_line[j]); }
     free_dev(m->tape);
     hr_model_destroy(m->coarse);
     delete m;

@@ -168,6 +168,7 @@ struct HrLayoutJob { const float* src; float* dst; int C, H, W, tex, c_off; };
 struct HrLayoutBatch { HrLayoutJob job[12]; int n; };
 void hr_launch_layout_batch(const HrLayoutBatch& b, bool to_packed, hipStream_t stream);
 void hr_launch_basis_transpose(const float* basis, float* basis_t, int app_dim, int n_cols, int ld, hipStream_t stream);
+void hr_launch_blend_rows(const float* b, float* line, int row_floats, int i0, int i1, float w0, float w1, hipStream_t stream);
 void hr_launch_interleave(const float* src, void* dst, int half, int C, int H, int W, int tex, int c_off, hipStream_t stream);
 
 

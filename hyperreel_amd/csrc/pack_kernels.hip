@@ -270,3 +270,18 @@ void hr_launch_basis_transpose(const float* basis, float* basis_t, int app_dim, 
     if (n <= 0) return;
     hipLaunchKernelGGL(hr_basis_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, basis, basis_t, app_dim, n_cols, ld);
 }
+
+// hr_render_frame: the two keyframe rows a frame's time blends between, folded into one line per time plane:
+// line[x][ch] = B[row0][x][ch] * w0 + B[row1][x][ch] * w1 (float32 texels)
+__global__ __launch_bounds__(256) void hr_blend_rows_kernel(const float* __restrict__ b, float* __restrict__ line, int n, int i0, int i1, float w0, float w1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    line[i] = fmaf(b[(size_t)i1 * n + i], w1, b[(size_t)i0 * n + i] * w0);
+}
+
+void hr_launch_blend_rows(const float* b, float* line, int row_floats, int i0, int i1, float w0, float w1, hipStream_t stream)
+{
+    if (row_floats <= 0) return;
+    hipLaunchKernelGGL(hr_blend_rows_kernel, dim3((unsigned)((row_floats + 255) / 256)), dim3(256), 0, stream, b, line, row_floats, i0, i1, w0, w1);
+}

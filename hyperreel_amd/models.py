@@ -661,10 +661,12 @@ class HipLightfieldModel(nn.Module):
         # the C ABI takes no row stride: extra columns are cut (6-column nets ignore camera id / time, rendering.py)
         return rays[:, :hc.ray_dim].contiguous().float()
 
-    def render(self, rays, want=(), out=None):
+    def render(self, rays, want=(), out=None, frame_time=None):
         """rays (B, 6|8) on the HIP device -> dict with 'rgb' (B,3) and any of
         'distances' (B,Z), 'points' (B,Z,3), 'sigma' (B,Z), 'render_weights' (B,Z),
-        'head' (B,Z*P) listed in `want`.  out: an existing (B,3) float32 device tensor to render into."""
+        'head' (B,Z*P) listed in `want`.  out: an existing (B,3) float32 device tensor to render into.
+        frame_time: the caller's statement that every ray carries this time (one frame of a keyframe net): hr_render_frame, which reads
+        one row of each time plane instead of blending two (images agree with the general path to ~1e-6, not bit for bit)."""
         import ctypes as C
         h = self.native()
         self._sync_occupancy()
@@ -679,8 +681,11 @@ class HipLightfieldModel(nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(rays.device).cuda_stream)
         with torch.cuda.device(rays.device):
             if not want:
-                _lib.check(L.hr_render(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()), stream),
-                           'hr_render')
+                if frame_time is not None:
+                    _lib.check(L.hr_render_frame(h, C.c_void_p(rays.data_ptr()), B, float(frame_time), C.c_void_p(out['rgb'].data_ptr()), stream),
+                               'hr_render_frame')
+                else:
+                    _lib.check(L.hr_render(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()), stream), 'hr_render')
                 return out
             f = hr_fields()
             shapes = {'distances': (B, Z), 'points': (B, Z, 3), 'sigma': (B, Z), 'render_weights': (B, Z),
@@ -723,7 +728,7 @@ class HipLightfieldModel(nn.Module):
     def render_camera(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None):
         """The viewer's frame path (utils/gui_utils.py:139-212, nlf/__init__.py:754-807) without
         its host round trips: pose -> rays -> rgb, all on the device and on the current stream."""
-        return self.render(self.generate_rays(pose, K, width, height, time, cam_id, pixel_range))['rgb']
+        return self.render(self.generate_rays(pose, K, width, height, time, cam_id, pixel_range), frame_time=time)['rgb']
 
     def pack_display(self, rgb, height, width, transpose=False, flip=False, rgba8=True):
         """The viewer's hand-over (utils/gui_utils.py:174-205) on the device: rgb (H*W, 3) as rendered -> the displayed

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 20
+#define HR_ABI_VERSION 21
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -311,6 +311,14 @@ int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n
 
 /* rgb_dev[n,3] = render_fn(rays_dev[n,ray_dim])['rgb']  (eval mode: clamped to [0,1]). */
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
+/* hr_render for ONE FRAME of a keyframe net: the caller states that the last column of every ray is `time` (what
+ * get_coords_from_camera builds for a frame, datasets/base.py:485-518; the viewer and validation_video render frame by frame,
+ * nlf/__init__.py:754-893).  advect_points quantises a ray's time to its keyframe (utils/flow_utils.py:10-35), so all samples of
+ * the frame read the same ROW of every time plane: the library hands that row to the gather as a line (2 taps instead of 4).  The
+ * row's neighbour enters hr_render's sum with the ~1e-7 weight that rounding leaves; here it does not: images agree with hr_render's
+ * to ~1e-6, not bit for bit.  Static nets, cascades and times that are not on a keyframe row take hr_render's path unchanged.
+ * Rays whose time differs from `time` are rendered at `time`'s keyframe row (undefined with respect to the reference). */
+int hr_render_frame(hr_model* m, const float* rays_dev, int64_t n_rays, float time, float* rgb_dev, void* stream);
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,
                      const hr_fields* fields, void* stream);
 

@@ -21,6 +21,7 @@ int main(void)
     printf("error text: %s\n", hr_last_error());
     hr_model_destroy(NULL);                                           /* no-op by contract */
     if (hr_render(NULL, NULL, 0, NULL, NULL) != HR_E_INVALID) return 5;
+    if (hr_render_frame(NULL, NULL, 0, 0.5f, NULL, NULL) != HR_E_INVALID) return 5;
     /* every other entry point refuses bad arguments before it touches the device */
     {
         hr_train_tensors t;
