@@ -3,7 +3,7 @@
 // point_prediction cascades, heads too wide for the LDS hand-over, the exact-fp32 MLP.
 #include "sample_core.inc"
 
-template <int ZP, bool HALF, int PC>
+template <int ZP, bool HALF, int PC, int NB>
 __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_sample_kernel(const hr_config* __restrict__ cfgp, const HrSampleArgs a)
 {
     // the configuration lives in device memory (2 KB: too large to index dynamically as a by-value kernel argument
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
 #ifdef HR_TUNING
     unsigned long long sph__[12] = {};
 #endif
-    hr_sample_body<ZP, HALF, 1, 4, PC>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
+    hr_sample_body<ZP, HALF, 1, NB, PC>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
 }
 
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)
@@ -96,10 +96,18 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     // the shipped [8, 4, 4] / [8, 0, 0] decompositions get the class-specialised gather of their texel format (sample_core.inc); ZP >= 8
     // keeps a quad inside one ray, video nets additionally need two keyframes
     const int pclass = (args.rows_out == nullptr && (!cfg.video || cfg.num_keyframes >= 2)) ? hr_plane_class(args.planes, 0, args.ca_total) : 0;
+    // every second factor a line (static nets; a keyframe net inside hr_render_frame): the gather compiled for two line taps
+    bool all_lines = pclass != 0;
+    for (int j = 0; j < 3; ++j)
+        if (args.planes[j].cd4 + args.planes[j].ca4 > 0 && args.planes[j].bw != 1) all_lines = false;
+#define HR_LAUNCH_SAMPLES_N(Z_, H_, P_, N_) \
+    do { \
+        if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, H_, P_, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((hr_sample_kernel<Z_, H_, P_, N_>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+    } while (0)
 #define HR_LAUNCH_SAMPLES_T(Z_, H_, P_) \
     do { \
-        if (big_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_sample_kernel<Z_, H_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((hr_sample_kernel<Z_, H_, P_>), dim3(blocks), dim3(256), lds, stream, args2.cfg_dev, args2); \
+        if (P_ != 0 && all_lines) HR_LAUNCH_SAMPLES_N(Z_, H_, P_, (P_ != 0 ? 2 : 4)); else HR_LAUNCH_SAMPLES_N(Z_, H_, P_, 4); \
     } while (0)
 #define HR_LAUNCH_SAMPLES(Z_) \
     do { \
@@ -120,4 +128,5 @@ void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream
     }
 #undef HR_LAUNCH_SAMPLES
 #undef HR_LAUNCH_SAMPLES_T
+#undef HR_LAUNCH_SAMPLES_N
 }

@@ -380,9 +380,13 @@ def test_device_ray_generation_matches_ray_utils(fns):
         part = fn.model.generate_rays(pose, K, W, H, time=0.25 if video else None, pixel_range=(500, 1500)).cpu().numpy()
         assert np.array_equal(part, got[500:1500])
         a = fn.model.render_camera(pose, K, W, H, time=0.25 if video else None)
-        b = fn.model.render(torch.from_numpy(got).cuda())['rgb']
+        rays_t = torch.from_numpy(got).cuda()
+        # render_camera of a keyframe net states the frame's time (hr_render_frame: bit-identical to render(rays, frame_time=t), within
+        # 5e-6 of the general path); a static net takes hr_render either way
+        b = fn.model.render(rays_t, frame_time=0.25 if video else None)['rgb']
         torch.cuda.synchronize()
         assert torch.equal(a, b)
+        assert float((fn.model.render(rays_t)['rgb'] - a).abs().max()) <= (5e-6 if video else 0.0)
 
 
 def _round_grids_to_half(sd):
