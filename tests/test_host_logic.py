@@ -127,6 +127,27 @@ def test_shard_bounds():
     assert shard_bounds(3, 8)[-1] == 3
 
 
+def test_the_c_abi_splits_a_frame_like_the_python_side():
+    """hr_shard_range (what a non-Python host calls per rank) against parallel.shard_bounds: the same contiguous split for every
+    world size, ragged or not; the gather's slot is rank 0's share (the largest)."""
+    import ctypes
+    from hyperreel_amd import lib as hlib
+    from hyperreel_amd.parallel import shard_bounds
+    L = hlib.load()
+    first, count = ctypes.c_int64(), ctypes.c_int64()
+    for n in (0, 1, 7, 640000, 640003, 1 << 33):
+        for world in (1, 2, 3, 4, 8):
+            b = shard_bounds(n, world)
+            counts = []
+            for rank in range(world):
+                hlib.check(L.hr_shard_range(n, rank, world, ctypes.byref(first), ctypes.byref(count)), 'hr_shard_range')
+                assert (first.value, first.value + count.value) == (b[rank], b[rank + 1]), (n, world, rank)
+                counts.append(count.value)
+            assert counts[0] == max(counts) and sum(counts) == n
+    assert L.hr_shard_range(10, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0      # rank out of range: an error, not a range
+    assert L.hr_shard_range(10, 0, 0, ctypes.byref(first), ctypes.byref(count)) != 0
+
+
 def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     """The drop-in boundary is a C ABI: the header compiles as C99 and a C program can call the library (no GPU needed
     for the calls made here)."""
