@@ -313,11 +313,13 @@ int hr_model_set_occupancy(hr_model* m, const float* volume_dev, const int32_t n
 int hr_render(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, void* stream);
 /* hr_render for ONE FRAME of a keyframe net: the caller states that the last column of every ray is `time` (what
  * get_coords_from_camera builds for a frame, datasets/base.py:485-518; the viewer and validation_video render frame by frame,
- * nlf/__init__.py:754-893).  advect_points quantises a ray's time to its keyframe (utils/flow_utils.py:10-35), so all samples of
- * the frame read the same ROW of every time plane: the library hands that row to the gather as a line (2 taps instead of 4).  The
- * row's neighbour enters hr_render's sum with the ~1e-7 weight that rounding leaves; here it does not: images agree with hr_render's
- * to ~1e-6, not bit for bit.  Static nets, cascades and times that are not on a keyframe row take hr_render's path unchanged.
- * Rays whose time differs from `time` are rendered at `time`'s keyframe row (undefined with respect to the reference). */
+ * nlf/__init__.py:754-893).  Every sample of the frame then blends the SAME two keyframe rows of each time plane with the same
+ * weights (TensorVMKeyframeTime's grid_sample over (position, time), nlf/nets/tensorf_dynamic.py:287-371): the library folds them
+ * into one line per time plane on `stream` first and the gather reads lines, as it does for a static net (2 taps instead of 4 per
+ * plane pair and sample).  The blend is re-associated -- (b00 wt0 + b10 wt1) wx0 + ... instead of b00 (wx0 wt0) + ... -- so images
+ * agree with hr_render's to ~1e-6, not bit for bit.  Static nets, cascades and float16 texels take hr_render's path unchanged.
+ * Rays whose time differs from `time` are rendered with `time`'s rows (undefined with respect to the reference).  The lines are
+ * per-model scratch: frames of one model at different times must not be in flight on different streams at once. */
 int hr_render_frame(hr_model* m, const float* rays_dev, int64_t n_rays, float time, float* rgb_dev, void* stream);
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev,
                      const hr_fields* fields, void* stream);
