@@ -155,12 +155,69 @@ __global__ __launch_bounds__(256) void hr_layout_batch_kernel(const HrLayoutBatc
     }
 }
 
+// The same through LDS, for jobs of up to HR_LAYOUT_MAX_C channels: a workgroup takes HR_LAYOUT_TILE consecutive texels of a job, reads
+// them the way the source is laid out (planar: one run of the tile per channel; packed: the job's C channels of each texel, C * 4
+// contiguous bytes) and writes them the way the destination is.  The direct form above reads ONE float of a 64-byte texel per lane on
+// the packed side: 81 us for the 46 MB of the 600^3 scene's gradients (1.1 TB/s); this one 16-byte..64-byte runs on both sides.
+#define HR_LAYOUT_TILE 256
+#define HR_LAYOUT_MAX_C 32
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void hr_layout_tiled_kernel(const HrLayoutBatch b)
+{
+    extern __shared__ float tile[];                // [C][HR_LAYOUT_TILE + 8]  (row stride = 8 mod 32 banks: the channel-fastest phase spreads 8 channels x 8 texels over all banks)
+    const HrLayoutJob j = b.job[blockIdx.y];
+    const int64_t hw = (int64_t)j.H * j.W;
+    const int64_t tiles = (hw + HR_LAYOUT_TILE - 1) / HR_LAYOUT_TILE;
+    const int C = j.C;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t yx0 = t * HR_LAYOUT_TILE;
+        const int nt = (int)((hw - yx0 < HR_LAYOUT_TILE) ? hw - yx0 : HR_LAYOUT_TILE);
+        __syncthreads();
+        if (TO_PACKED) {
+            for (int e = threadIdx.x; e < C * HR_LAYOUT_TILE; e += 256) {          // planar source: x fastest
+                const int c = e / HR_LAYOUT_TILE, x = e - c * HR_LAYOUT_TILE;
+                if (x < nt) tile[c * (HR_LAYOUT_TILE + 8) + x] = j.src[(int64_t)c * hw + yx0 + x];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < C * nt; e += 256) {                      // packed destination: channel fastest
+                const int x = e / C, c = e - x * C;
+                j.dst[(yx0 + x) * j.tex + j.c_off + c] = tile[c * (HR_LAYOUT_TILE + 8) + x];
+            }
+        } else {
+            for (int e = threadIdx.x; e < C * nt; e += 256) {                      // packed source: channel fastest
+                const int x = e / C, c = e - x * C;
+                tile[c * (HR_LAYOUT_TILE + 8) + x] = j.src[(yx0 + x) * j.tex + j.c_off + c];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < C * HR_LAYOUT_TILE; e += 256) {          // planar destination: x fastest
+                const int c = e / HR_LAYOUT_TILE, x = e - c * HR_LAYOUT_TILE;
+                if (x < nt) j.dst[(int64_t)c * hw + yx0 + x] = tile[c * (HR_LAYOUT_TILE + 8) + x];
+            }
+        }
+    }
+}
+
 void hr_launch_layout_batch(const HrLayoutBatch& b, bool to_packed, hipStream_t stream)
 {
     if (b.n <= 0) return;
-    int64_t most = 0;
-    for (int i = 0; i < b.n; ++i) most = most > (int64_t)b.job[i].C * b.job[i].H * b.job[i].W ? most : (int64_t)b.job[i].C * b.job[i].H * b.job[i].W;
+    int64_t most = 0, most_hw = 0;
+    int max_c = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const int64_t hw = (int64_t)b.job[i].H * b.job[i].W;
+        most = most > hw * b.job[i].C ? most : hw * b.job[i].C;
+        most_hw = most_hw > hw ? most_hw : hw;
+        max_c = max_c > b.job[i].C ? max_c : b.job[i].C;
+    }
     if (most <= 0) return;
+    if (max_c <= HR_LAYOUT_MAX_C) {
+        int64_t blocks = (most_hw + HR_LAYOUT_TILE - 1) / HR_LAYOUT_TILE;
+        if (blocks > 1024) blocks = 1024;
+        const dim3 grid((unsigned)blocks, (unsigned)b.n);
+        const size_t lds = sizeof(float) * (size_t)max_c * (HR_LAYOUT_TILE + 8);
+        if (to_packed) hipLaunchKernelGGL(hr_layout_tiled_kernel<true>, grid, dim3(256), lds, stream, b);
+        else hipLaunchKernelGGL(hr_layout_tiled_kernel<false>, grid, dim3(256), lds, stream, b);
+        return;
+    }
     int64_t blocks = (most + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks, (unsigned)b.n);
