@@ -240,7 +240,7 @@ void analyse_live_columns(hr_model* m)
     }
     mark(c.f_color_scale, 0, 3);
     mark(c.f_color_shift, 0, 3);
-    mark(c.f_color_scale_global, 0, 3);
+    mark(c.f_color_scale_global, 0, c.f_color_scale_global.channels == 9 ? 9 : 3);    // 9: the head is a 3x3 `color_transform_global`
     mark(c.f_color_shift_global, 0, 3);
     if (c.advect && c.use_spatial_flow) mark(c.f_spatial_flow, 0, 3);
     const char* e = getenv("HR_PRUNE");

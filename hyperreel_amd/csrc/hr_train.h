@@ -878,7 +878,20 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
     if (a.white_bg) { const float bg = 1.0f - acc_w; c0 += bg; c1 += bg; c2 += bg; }
     const float cpre[3] = {c0, c1, c2};          // the composited colour before the per-ray scale / shift
     float gscale[3] = {1.0f, 1.0f, 1.0f};
-    if (c.f_color_scale_global.offset >= 0) {    // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
+    const bool head_transform = c.f_color_scale_global.offset >= 0 && c.f_color_scale_global.channels == 9;
+    float thead[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (head_transform) {                        // transform_color_one, the matrix from the head (`color_transform_global`)
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+        for (int i = 0; i < 9; ++i) thead[i] = hr_apply_act(fs.act, head[fs.offset + i]);
+        const float n0 = c0 + ((c0 * thead[0] + c1 * thead[1]) + c2 * thead[2]);
+        const float n1 = c1 + ((c0 * thead[3] + c1 * thead[4]) + c2 * thead[5]);
+        const float n2 = c2 + ((c0 * thead[6] + c1 * thead[7]) + c2 * thead[8]);
+        c0 = n0 + hr_apply_act(fh.act, head[fh.offset + 0]);
+        c1 = n1 + hr_apply_act(fh.act, head[fh.offset + 1]);
+        c2 = n2 + hr_apply_act(fh.act, head[fh.offset + 2]);
+    }
+    else if (c.f_color_scale_global.offset >= 0) {    // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
         const hr_head_field& fs = c.f_color_scale_global;
         const hr_head_field& fh = c.f_color_shift_global;
         for (int i = 0; i < 3; ++i) gscale[i] = hr_apply_act(fs.act, head[fs.offset + i]) + 1.0f;
@@ -906,7 +919,20 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
     float g[3] = {a.d_rgb[ray * 3 + 0], a.d_rgb[ray * 3 + 1], a.d_rgb[ray * 3 + 2]};
     float* dhead = a.d_head + ray * (int64_t)Z * P;
     for (int i = 0; i < Z * P; ++i) dhead[i] = 0.0f;
-    if (c.f_color_scale_global.offset >= 0) {
+    if (head_transform) {
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+        float gn[3] = {g[0], g[1], g[2]};
+        for (int i = 0; i < 3; ++i) {
+            dhead[fh.offset + i] += g[i] * hr_act_grad(fh.act, head[fh.offset + i]);
+            for (int j = 0; j < 3; ++j) {
+                dhead[fs.offset + 3 * i + j] += g[i] * cpre[j] * hr_act_grad(fs.act, head[fs.offset + 3 * i + j]);
+                gn[j] += g[i] * thead[3 * i + j];
+            }
+        }
+        g[0] = gn[0]; g[1] = gn[1]; g[2] = gn[2];
+    }
+    else if (c.f_color_scale_global.offset >= 0) {
         const hr_head_field& fs = c.f_color_scale_global;
         const hr_head_field& fh = c.f_color_shift_global;
         for (int i = 0; i < 3; ++i) {

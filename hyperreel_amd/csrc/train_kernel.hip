@@ -183,7 +183,19 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
     float gscale[3] = {1.0f, 1.0f, 1.0f};
     float tcol[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cam = 0;
-    if (c.f_color_scale_global.offset >= 0) {      // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
+    const bool head_transform = c.f_color_scale_global.offset >= 0 && c.f_color_scale_global.channels == 9;
+    if (head_transform) {                          // transform_color_one, the matrix from the head (`color_transform_global`): sample 0's nine values
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tcol[i] = hr_apply_act(fs.act, head[fs.offset + i]);
+        const float n0 = c0 + ((c0 * tcol[0] + c1 * tcol[1]) + c2 * tcol[2]);
+        const float n1 = c1 + ((c0 * tcol[3] + c1 * tcol[4]) + c2 * tcol[5]);
+        const float n2 = c2 + ((c0 * tcol[6] + c1 * tcol[7]) + c2 * tcol[8]);
+        c0 = n0 + hr_apply_act(fh.act, head[fh.offset + 0]);
+        c1 = n1 + hr_apply_act(fh.act, head[fh.offset + 1]);
+        c2 = n2 + hr_apply_act(fh.act, head[fh.offset + 2]);
+    } else if (c.f_color_scale_global.offset >= 0) {      // scale_shift_color_one (tensorf_utils.py:275-281): sample 0's head values
         const hr_head_field& fs = c.f_color_scale_global;
         const hr_head_field& fh = c.f_color_shift_global;
 #pragma unroll
@@ -214,7 +226,21 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
     float* dhk = dhead + (lane_ok ? k : 0) * P;
     if (lane_ok)
         for (int i = 0; i < P; ++i) dhk[i] = 0.0f;
-    if (c.f_color_scale_global.offset >= 0) {
+    if (head_transform) {
+        const hr_head_field& fs = c.f_color_scale_global;
+        const hr_head_field& fh = c.f_color_shift_global;
+        float gn[3] = {g[0], g[1], g[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (lane_ok && k == 0) dhk[fh.offset + i] += g[i] * hr_act_grad(fh.act, head[fh.offset + i]);     // sample 0's row is this lane's own
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (lane_ok && k == 0) dhk[fs.offset + 3 * i + j] += g[i] * cpre[j] * hr_act_grad(fs.act, head[fs.offset + 3 * i + j]);
+                gn[j] += g[i] * tcol[3 * i + j];
+            }
+        }
+        g[0] = gn[0]; g[1] = gn[1]; g[2] = gn[2];
+    } else if (c.f_color_scale_global.offset >= 0) {
         const hr_head_field& fs = c.f_color_scale_global;
         const hr_head_field& fh = c.f_color_shift_global;
 #pragma unroll

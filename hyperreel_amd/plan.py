@@ -464,10 +464,16 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
         if not has('color_shift_global'):
             raise ValueError('color_scale_global without color_shift_global')
         hc.f_color_scale_global, hc.f_color_shift_global = heads['color_scale_global'], heads['color_shift_global']
-    elif has('color_transform_global'):
-        raise NotImplementedError("head 'color_transform_global' is outside the hot-path scope")
+    elif has('color_transform_global'):              # tensorf_no_sample.py:242-243 -> transform_color_one: a 3x3 per ray from the head
+        if not has('color_shift_global'):
+            raise ValueError('color_transform_global without color_shift_global')
+        if heads['color_transform_global'].channels != 9:
+            raise ValueError('color_transform_global needs 9 channels')
+        # carried in the scale field: 9 channels = the row-major matrix (hr_write_pixel, csrc/sample_core.inc)
+        hc.f_color_scale_global, hc.f_color_shift_global = heads['color_transform_global'], heads['color_shift_global']
     for k in ('f_color_scale', 'f_color_shift', 'f_color_scale_global', 'f_color_shift_global'):
-        if getattr(hc, k).offset >= 0 and getattr(hc, k).channels != 3:
+        ok = (3, 9) if (k == 'f_color_scale_global' and not has('color_scale_global')) else (3,)
+        if getattr(hc, k).offset >= 0 and getattr(hc, k).channels not in ok:
             raise ValueError(f'{k[2:]} needs 3 channels')
     if has('weights_shift'):
         raise NotImplementedError("head 'weights_shift' is outside the hot-path scope")

@@ -136,7 +136,8 @@ typedef struct hr_config {
     hr_head_field f_color_scale;
     hr_head_field f_color_shift;
     hr_head_field f_spatial_flow;
-    hr_head_field f_color_scale_global;  /* scale_shift_color_one, utils/tensorf_utils.py:275-281 (sample 0's values) */
+    hr_head_field f_color_scale_global;  /* scale_shift_color_one, utils/tensorf_utils.py:275-281 (sample 0's values); with 9 channels: the head
+                                          * `color_transform_global`, a row-major 3x3 for transform_color_one (:308-320) */
     hr_head_field f_color_shift_global;
     /* ---- intersect (nlf/intersect/base.py:142-259, z.py, primitive.py) */
     int32_t isect_type;                  /* HR_ISECT_* */

@@ -109,6 +109,16 @@ def _v_donerf_contract_pow2(cfg):             # ... and with its defaults: power
     _isect(cfg).contract = {'type': 'donerf', 'contract_samples': True, 'contract_end_radius': 40.0}
 
 
+def _v_color_transform_global_head(cfg):      # transform_color_one fed from the MLP head instead of the per-camera table (tensorf_no_sample.py:242-243)
+    out = _pred(cfg).outputs
+    spec = out.pop('color_scale_global')
+    out['color_transform_global'] = C.to_cfg({**C.to_plain(spec), 'channels': 9}) if hasattr(C, 'to_cfg') else spec
+    out['color_transform_global']['channels'] = 9
+    for e in cfg.embedding.embeddings.values():
+        if e.get('type') == 'extract_fields':
+            e.fields = [('color_transform_global' if f == 'color_scale_global' else f) for f in e.fields]
+
+
 def _v_voxel_outward(cfg):
     ic = _isect(cfg)
     ic.outward_facing = True
@@ -150,6 +160,7 @@ VARIANTS = [
     ('variant_sphere_new_origins_only', 'immersive_sphere_new', _v_sphere_new_origins_only),
     ('variant_z_depth_contract', 'llff_z_plane', _v_z_depth),
     ('variant_voxel_outward', 'donerf_voxel', _v_voxel_outward),
+    ('variant_color_transform_global_head', 'catacaustics_distance', _v_color_transform_global_head),
     ('variant_donerf_contract', 'donerf_sphere', _v_donerf_contract),
     ('variant_donerf_contract_pow2', 'donerf_cylinder', _v_donerf_contract_pow2),
     ('variant_mask_off_unsorted', 'donerf_sphere', _v_mask_off_unsorted),

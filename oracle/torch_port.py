@@ -388,8 +388,8 @@ class TorchPort:
         if 'color_scale_global' in x:                       # scale_shift_color_one, tensorf_utils.py:275-281
             out = out * (x['color_scale_global'][:, 0, :] + 1.0) + x['color_shift_global'][:, 0, :]
         elif 'color_transform_global' in x:                 # transform_color_one, tensorf_utils.py:308-320
-            T = x['color_transform_global'].reshape(B, 3, 3)
-            out = out + (T * out[:, None, :]).sum(-1) + x['color_shift_global']
+            T = x['color_transform_global'].reshape(B, -1, 3, 3)[:, 0]        # a per-camera table row, or sample 0's nine head values
+            out = out + (T * out[:, None, :]).sum(-1) + x['color_shift_global'].reshape(B, -1, 3)[:, 0]
         return out if train else out.clamp(0, 1)
 
     @torch.no_grad()

@@ -17,7 +17,9 @@ CASES = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_sm
          'sweep/donerf_voxel', 'sweep/catacaustics_distance', 'sweep/variant_z_depth_contract',
          # DoNeRFContract (general powf).  Not its power-2 fixture: that one has masked samples AT the centre, where contract_points is 0 / 0 --
          # harmless in the forward (masked), but torch.autograd carries the NaN into every MLP gradient of the reference, so there is nothing to match
-         'sweep/variant_donerf_contract']
+         'sweep/variant_donerf_contract',
+         # transform_color_one fed from the head (`color_transform_global`, 9 channels of sample 0)
+         'sweep/variant_color_transform_global_head']
 
 
 def _reference_grads(g, rays, G, white):

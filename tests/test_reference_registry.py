@@ -72,8 +72,8 @@ def test_the_reference_cannot_run_a_per_sample_color_transform_head(shim):
     """VERDICT r2 listed per-sample `color_transform` heads (tensorf_no_sample.py:226-229 -> transform_color_all,
     utils/tensorf_utils.py:283-306) as a leftover.  The reference's own function reshapes the (B, Z, 9) head to (B, 3, 3): it raises
     for every Z > 1 and returns a (B, B, 3) tensor for Z = 1 -- there is no behaviour to reproduce, so plan.py keeps rejecting the
-    head by name.  The per-camera TABLE (`color_transform` embedding -> transform_color_one) is the runnable form and is
-    supported."""
+    head by name.  The runnable forms -- the per-camera TABLE (`color_transform` embedding) and the per-ray head
+    `color_transform_global`, both through transform_color_one -- are supported."""
     with shim.cpu_mode():
         from utils.tensorf_utils import transform_color_all
     B = 5
