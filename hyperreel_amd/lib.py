@@ -11,11 +11,12 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 
 HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_PRECISION_ACTIVE, HR_OPT_MLP_OVERFLOW, HR_OPT_MLP_CALIBRATED = 0, 1, 2, 3, 4, 5
+HR_OPT_PLAN_ACTIVE, HR_OPT_PLAN_FAULT, HR_OPT_DUO_CONSUMERS, HR_OPT_DUO_PARTS, HR_OPT_DUO_MLP_WAVES, HR_OPT_DUO_MODE = 6, 7, 8, 9, 10, 11
 HR_E_RANGE = -5
 
 
@@ -67,6 +68,7 @@ SYMBOLS = [
     ('hr_stage_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('hr_stage_samples', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_debug_trace_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ('hr_debug_duo_times', C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ('hr_model_device_bytes', C.c_int64, [C.c_void_p]),
     ('hr_model_destroy', None, [C.c_void_p]),
 ]

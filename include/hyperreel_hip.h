@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 21
+#define HR_ABI_VERSION 22
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -297,7 +297,8 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * HR_OPT_MLP_OVERFLOW the sticky bit the fp16-split kernels set when an input feature or hidden activation of a RENDERED ray reached
  * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate). */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
-       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5 };
+       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_PLAN_ACTIVE = 6, HR_OPT_PLAN_FAULT = 7,
+       HR_OPT_DUO_CONSUMERS = 8, HR_OPT_DUO_PARTS = 9, HR_OPT_DUO_MLP_WAVES = 10, HR_OPT_DUO_MODE = 11 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 
@@ -451,6 +452,12 @@ int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
  * s_memtime stamps per wave (4 waves per workgroup, workgroups of 64 or 128 rays); only the
  * split-precision kernel records stamps. */
 int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsigned long long* trace_dev, void* stream);
+
+/* Profiling aid for the co-resident pair (HR_OPT_FRAME_KERNEL 3): s_memrealtime stamps (100 MHz) of the LAST launch pair --
+ * out8[0..3] = { first producer workgroup started, last producer workgroup ended, first consumer workgroup started, last consumer
+ * workgroup ended } -- i.e. whether, and for how long, the two kernels really ran at the same time; out8[4..7] = { shader cycles
+ * (s_memtime), 100 MHz ticks } of producer workgroup 0 and of consumer workgroup 0: the clock each ran at.  Synchronises the device. */
+int hr_debug_duo_times(hr_model* m, unsigned long long* out8);
 
 /* bytes of device memory held by the model (packed grids + weights + workspace) */
 int64_t hr_model_device_bytes(const hr_model* m);
