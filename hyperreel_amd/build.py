@@ -13,8 +13,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_build')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
 SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'fused_bf16x3_kernel.hip', 'fused_f16x3_kernel.hip', 'fused_f16x2_kernel.hip',
-           'sample_kernel.hip', 'sampleq_kernel.hip', 'range_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_gemm_kernel.hip']
-HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'sample_core.inc', 'fused_impl.inc', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
+           'sample_kernel.hip', 'sampleq_kernel.hip', 'range_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_det_kernel.hip', 'train_gemm_kernel.hip']
+HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'sample_core.inc', 'fused_impl.inc', 'train_kernel.hip', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by
 # operation (the reference never fuses a multiply with an add across torch ops); the
@@ -80,6 +80,11 @@ def build(force=False, verbose=False, extra_flags=()):
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    # objects of translation units that are no longer part of the library do not travel with the tree
+    keep = {os.path.basename(_obj(s)) for s in SOURCES}
+    for f in os.listdir(LIB_DIR):
+        if f.endswith('.o') and f not in keep:
+            os.remove(os.path.join(LIB_DIR, f))
     with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(compile_one, todo))
     with open(stamp, 'w') as f:

@@ -95,6 +95,9 @@ struct hr_model {
     hr_config* ucfg_dev = nullptr;
     float* grad_a[3] = {};
     float* grad_b[3] = {};
+    long long* grad_fx = nullptr;        // deterministic training (HR_OPT_TRAIN_DETERMINISTIC): ONE 64-bit fixed-point buffer for every accumulator of a step
+    size_t grad_fx_elems = 0;
+    int opt_train_det = 0;
     float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
     int64_t tape_samples = 0;
     // occupancy early-reject (hr_model_set_occupancy)
@@ -114,7 +117,7 @@ struct hr_model {
     unsigned* duo_sync = nullptr;         // [HR_DUO_CTL_WORDS ticket words | one flag per tile]
     float* duo_head = nullptr;            // HQ layout, duo_cap rays
     int64_t duo_cap = 0;                  // rays one launch pair can take (multiple of 64)
-    int opt_duo_consumers = 0, opt_duo_parts = 0, opt_duo_mlp_waves = 0;     // 0: the plan's defaults
+    int opt_duo_consumers = 0, opt_duo_mlp_waves = 0;     // 0: the plan's defaults
     int opt_duo_mode = 0;                 // measurement: 1 = both kernels on ONE stream (producer, then consumer), 2 = producer only, 3 = consumer only (on the flags the last pair left)
 };
 
@@ -203,7 +206,7 @@ int validate(const hr_config& c, bool coarse = false)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
     if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_AUTO) return fail(HR_E_INVALID, "unknown mlp_precision");
-    if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_hidden != 256)
+    if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_AUTO && c.mlp_hidden != 256)      // (AUTO resolves to fp32 there)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
     if (c.color_table_views < 0) return fail(HR_E_INVALID, "negative color_table_views");
@@ -588,37 +591,53 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
         return fail(HR_E_INVALID, "activation-range calibration does not cover mlp_in %d / mlp_hidden %d", c.mlp_in, c.mlp_hidden);
     float* synth = nullptr;
     float* d_max = nullptr;
+    hipError_t e = hipSuccess;
     if (!rays_dev) {
         n = 4096;
-        HR_HIP(hipMalloc((void**)&synth, sizeof(float) * n * (m->coarse ? c.casc_row_dim : c.ray_dim)));
-        // where rays start: the model's own box, or (cascade rows, whose first columns are points) the same box
-        hr_launch_synthetic_rays(synth, n, m->coarse ? c.casc_row_dim : c.ray_dim, c.aabb, c.aabb + 3, 0x5eedu, st);
-        rays_dev = synth;
-    }
-    HR_HIP(hipMalloc((void**)&d_max, sizeof(float) * HR_MAX_LAYERS));
-    HR_HIP(hipMemsetAsync(d_max, 0, sizeof(float) * HR_MAX_LAYERS, st));
-    HrRangeArgs ra;
-    ra.rays = rays_dev;
-    ra.n_rays = n;
-    ra.act_max = d_max;
-    char name[64];
-    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
-        ra.w[l] = ra.b[l] = nullptr;
-        if (l < c.mlp_layers) {
-            snprintf(name, sizeof(name), "mlp.%d.weight", l);
-            ra.w[l] = m->raw[name].p;
-            snprintf(name, sizeof(name), "mlp.%d.bias", l);
-            ra.b[l] = m->raw[name].p;
+        const int rd = m->coarse ? c.casc_row_dim : c.ray_dim;
+        e = hipMalloc((void**)&synth, sizeof(float) * n * rd);
+        if (e == hipSuccess) {
+            // where rays start.  Cascade rows (first columns: points): the model's box.  Rays: half of them inside the box, half in a box
+            // three times as large about the same centre -- cameras usually stand OUTSIDE the scene box, and ray parameterisations
+            // such as the Pluecker moment o x d grow with |o| (a caller who knows the real cameras passes rays: hr_model_calibrate)
+            float lo3[3], hi3[3];
+            for (int i = 0; i < 3; ++i) {
+                const float mid = 0.5f * (c.aabb[i] + c.aabb[3 + i]), half = 0.5f * (c.aabb[3 + i] - c.aabb[i]);
+                lo3[i] = mid - 3.0f * half;
+                hi3[i] = mid + 3.0f * half;
+            }
+            hr_launch_synthetic_rays(synth, n / 2, rd, c.aabb, c.aabb + 3, 0x5eedu, st);
+            if (m->coarse) hr_launch_synthetic_rays(synth + (size_t)(n / 2) * rd, n - n / 2, rd, c.aabb, c.aabb + 3, 0x5eeeu, st);
+            else hr_launch_synthetic_rays(synth + (size_t)(n / 2) * rd, n - n / 2, rd, lo3, hi3, 0x5eeeu, st);
+            rays_dev = synth;
         }
     }
-    hr_config kc = m->kcfg;
-    if (m->coarse) kc.ray_dim = c.casc_row_dim;              // the point MLP's "rays" are the rows (launch_cascade_front)
-    hr_launch_mlp_range(kc, ra, st);
-    hipError_t e = hipMemcpyAsync(m->act_max, d_max, sizeof(float) * HR_MAX_LAYERS, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_max, sizeof(float) * HR_MAX_LAYERS);
+    if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, sizeof(float) * HR_MAX_LAYERS, st);
+    if (e == hipSuccess) {
+        HrRangeArgs ra;
+        ra.rays = rays_dev;
+        ra.n_rays = n;
+        ra.act_max = d_max;
+        char name[64];
+        for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+            ra.w[l] = ra.b[l] = nullptr;
+            if (l < c.mlp_layers) {
+                snprintf(name, sizeof(name), "mlp.%d.weight", l);
+                ra.w[l] = m->raw[name].p;
+                snprintf(name, sizeof(name), "mlp.%d.bias", l);
+                ra.b[l] = m->raw[name].p;
+            }
+        }
+        hr_config kc = m->kcfg;
+        if (m->coarse) kc.ray_dim = c.casc_row_dim;              // the point MLP's "rays" are the rows (launch_cascade_front)
+        hr_launch_mlp_range(kc, ra, st);
+        e = hipMemcpyAsync(m->act_max, d_max, sizeof(float) * HR_MAX_LAYERS, hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_max);
+    if (d_max) (void)hipFree(d_max);
     if (synth) (void)hipFree(synth);
-    if (e != hipSuccess) return fail(HR_E_HIP, "activation-range calibration: %s", hipGetErrorString(e));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(HR_E_HIP, "activation-range calibration: %s", hipGetErrorString(e)); }
     m->calibrated = synth ? 1 : 2;
     float mx = 0.0f;
     bool finite = true;
@@ -788,9 +807,16 @@ int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float
     if (!m->finalized) return fail(HR_E_STATE, "hr_model_calibrate before hr_model_finalize");
     if (m->coarse || m->is_coarse) return fail(HR_E_INVALID, "hr_model_calibrate: cascades are calibrated by hr_model_finalize (the point MLP's rows are internal)");
     if (!rays_dev || n_rays <= 0) return fail(HR_E_INVALID, "hr_model_calibrate needs rays");
-    const int before = m->active_precision;
+    const int before = m->active_precision, calibrated_before = m->calibrated;
+    float act_before[HR_MAX_LAYERS];
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) act_before[l] = m->act_max[l];
     int rc = resolve_precision(m, rays_dev, n_rays, (hipStream_t)stream);
-    if (rc != HR_OK) { m->active_precision = before; return rc; }
+    if (rc != HR_OK) {                         // the model stays exactly as it was
+        m->active_precision = before;
+        m->calibrated = calibrated_before;
+        for (int l = 0; l < HR_MAX_LAYERS; ++l) m->act_max[l] = act_before[l];
+        return rc;
+    }
     HR_HIP(hipMemset(m->flags, 0, sizeof(unsigned)));
     if (m->active_precision != before) {
         m->packed_bytes -= m->mlp_bytes;
@@ -995,7 +1021,6 @@ static bool duo_applies(hr_model* m)
     HrSampleArgs sa;
     fill_sample_args(m, sa, nullptr, 64, nullptr);
     HrDuoArgs q{};
-    q.parts = m->opt_duo_parts > 0 ? m->opt_duo_parts : 4;
     q.n_tiles = 1; q.n_queues = 1; q.producers = 1;
     if (!hr_launch_duo_consumer(m->kcfg, sa, q, m->opt_duo_consumers, m->n_cus, true, nullptr)) return false;
     return hr_launch_duo_producer_f16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, true, nullptr);
@@ -1039,6 +1064,14 @@ static bool launch_duo(hr_model* m, const float* rays, int64_t n, float* rgb, hi
 {
     if (!duo_applies(m)) return false;
     if (n <= 0) return true;
+    // Not inside a stream capture: a replayed hipGraph runs the two kernel nodes one after the other (measured on ROCm 7.2, with and
+    // without DEBUG_CLR_GRAPH_PACKET_CAPTURE: the consumer starts ~15 us after the producer has ENDED) and in an order it chooses --
+    // the consumer first means 0.3 s of waiting and a faulted frame.  A captured call takes the plans that are one stream's work.
+    if (m->opt_duo_mode == 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (cs != hipStreamCaptureStatusNone) return false;
+    }
     const int64_t cap = ensure_duo(m, n, st);
     if (cap <= 0) return false;
     const hr_config& c = m->cfg;
@@ -1057,7 +1090,6 @@ static bool launch_duo(hr_model* m, const float* rays, int64_t n, float* rgb, hi
         q.n_tiles = (int)((nn + 63) / 64);
         q.producers = q.n_tiles < m->n_cus ? q.n_tiles : m->n_cus;
         q.n_queues = q.producers < 8 ? q.producers : 8;
-        q.parts = m->opt_duo_parts > 0 ? m->opt_duo_parts : 4;
         // every polled word is zeroed before every launch pair (a memset node when captured: replayed first)
         const int mode = m->opt_duo_mode;
         if (hipMemsetAsync(m->duo_sync, 0, sizeof(unsigned) * (size_t)(HR_DUO_CTL_WORDS + (mode == 3 ? 0 : q.n_tiles)), st) != hipSuccess) return false;
@@ -1237,14 +1269,14 @@ int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
     } else if (option == HR_OPT_DUO_CONSUMERS) {
         if (value < 0 || value > 8) return fail(HR_E_INVALID, "HR_OPT_DUO_CONSUMERS takes 0 (the plan's default) .. 8 sample workgroups per CU");
         m->opt_duo_consumers = value;
-    } else if (option == HR_OPT_DUO_PARTS) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_DUO_PARTS takes 0 (the plan's default), 1, 2, 4 or 8 tickets per 64-ray tile");
-        m->opt_duo_parts = value;
     } else if (option == HR_OPT_DUO_MODE) {
         if (value < 0 || value > 3) return fail(HR_E_INVALID, "HR_OPT_DUO_MODE takes 0 .. 3");
         m->opt_duo_mode = value;
+    } else if (option == HR_OPT_TRAIN_DETERMINISTIC) {
+        if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_TRAIN_DETERMINISTIC takes 0 or 1");
+        m->opt_train_det = value;
     } else if (option == HR_OPT_DUO_MLP_WAVES) {
-        if (value != 0 && value != 3 && value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_DUO_MLP_WAVES takes 0 (the plan's default), 4, 8, or 3 (four wavefronts, three-slot weight ring)");
+        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 8) return fail(HR_E_INVALID, "HR_OPT_DUO_MLP_WAVES takes 0 (the plan's default), 4, 8, or 3 (four wavefronts, three-slot weight ring)");
         m->opt_duo_mlp_waves = value;
     } else if (option == HR_OPT_SAMPLE_WAVES) {
         if (value != 0 && value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 0 (the plan's default), 4 or 8");
@@ -1261,9 +1293,9 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
     else if (option == HR_OPT_DUO_CONSUMERS) *value = m->opt_duo_consumers;
-    else if (option == HR_OPT_DUO_PARTS) *value = m->opt_duo_parts;
     else if (option == HR_OPT_DUO_MLP_WAVES) *value = m->opt_duo_mlp_waves;
     else if (option == HR_OPT_DUO_MODE) *value = m->opt_duo_mode;
+    else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
     else if (option == HR_OPT_PLAN_FAULT) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         unsigned f = 0;
@@ -1601,7 +1633,46 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         HR_HIP(hipMemsetAsync(grads->color_table, 0, sizeof(float) * 12 * (size_t)m->cfg.color_table_views, st));
         a.d_color_table = grads->color_table;
     }
-    hr_launch_train(m->cfg, a, st);
+    if (m->opt_train_det) {
+        // deterministic mode: every accumulator of the step is a 64-bit fixed-point word of ONE scratch buffer (integer atomics: the
+        // totals do not depend on the order of the adds); converted to the float buffers the rest of the step reads
+        size_t need = 0, off_a[3] = {}, off_b[3] = {}, n_a[3] = {}, n_b[3] = {};
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& g = m->planes[j];
+            if (g.tex == 0) continue;
+            n_a[j] = (size_t)g.aw * g.ah * g.tex; n_b[j] = (size_t)g.bw * g.bh * g.tex;
+            off_a[j] = need; need += n_a[j];
+            off_b[j] = need; need += n_b[j];
+        }
+        const size_t n_basis = basis_bytes / sizeof(float), off_basis = need;
+        need += n_basis;
+        const size_t n_ct = m->cfg.color_table_views > 0 ? 12 * (size_t)m->cfg.color_table_views : 0, off_ct = need;
+        need += n_ct;
+        if (need > m->grad_fx_elems) {
+            HR_HIP(hipStreamSynchronize(st));
+            if (m->grad_fx) (void)hipFree(m->grad_fx);
+            m->grad_fx = nullptr; m->grad_fx_elems = 0;
+            HR_HIP(hipMalloc((void**)&m->grad_fx, sizeof(long long) * need));
+            m->grad_fx_elems = need;
+        }
+        HR_HIP(hipMemsetAsync(m->grad_fx, 0, sizeof(long long) * need, st));
+        HrTrainArgs ad = a;
+        for (int j = 0; j < 3; ++j) {
+            ad.g_a[j] = n_a[j] ? reinterpret_cast<float*>(m->grad_fx + off_a[j]) : nullptr;
+            ad.g_b[j] = n_b[j] ? reinterpret_cast<float*>(m->grad_fx + off_b[j]) : nullptr;
+        }
+        ad.d_basis = reinterpret_cast<float*>(m->grad_fx + off_basis);
+        ad.d_color_table = n_ct ? reinterpret_cast<float*>(m->grad_fx + off_ct) : nullptr;
+        hr_launch_train_det(m->cfg, &ad, sizeof(ad), st);
+        for (int j = 0; j < 3; ++j) {
+            if (n_a[j]) hr_launch_fixed_to_float(m->grad_fx + off_a[j], m->grad_a[j], (int64_t)n_a[j], st);
+            if (n_b[j]) hr_launch_fixed_to_float(m->grad_fx + off_b[j], m->grad_b[j], (int64_t)n_b[j], st);
+        }
+        hr_launch_fixed_to_float(m->grad_fx + off_basis, d_basis, (int64_t)n_basis, st);
+        if (n_ct) hr_launch_fixed_to_float(m->grad_fx + off_ct, grads->color_table, (int64_t)n_ct, st);
+    } else {
+        hr_launch_train(m->cfg, a, st);
+    }
     HrLayoutBatch batch = {};                      // packed texel gradients -> the reference's (C, H, W) tensors, one launch
     for (int j = 0; j < 3; ++j) {
         const HrGridPlane& g = m->planes[j];
@@ -1753,6 +1824,7 @@ void hr_model_destroy(hr_model* m)
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); free_dev(m->frame_line[j]); }
     free_dev(m->tape);
+    if (m->grad_fx) (void)hipFree(m->grad_fx);
     if (m->duo_stream) { (void)hipStreamSynchronize(m->duo_stream); (void)hipStreamDestroy(m->duo_stream); }
     if (m->duo_fork) (void)hipEventDestroy(m->duo_fork);
     if (m->duo_join) (void)hipEventDestroy(m->duo_join);

@@ -199,11 +199,13 @@ HR_FN int hr_ray_features(const hr_config& c, const float* ray, float* out, int 
 }
 
 // ---------------------------------------------------------------- contraction (nlf/contract.py)
-// torch.pow(x, scalar) as ATen evaluates it on float32 (pow_tensor_scalar_optimized_kernel): 0.5 -> sqrt, 2 -> x * x, else powf
+// torch.pow(x, scalar) as ATen evaluates it on float32 (pow_tensor_scalar_optimized_kernel): 0.5 -> sqrt, 2 -> x * x, 3 -> x * x * x, else powf
+// (its negative special cases -0.5 / -1 / -2 cannot occur: validate() requires positive powers)
 HR_FN float hr_pow_scalar(float x, float e)
 {
     if (e == 0.5f) return HR_SQRT(x);
     if (e == 2.0f) return x * x;
+    if (e == 3.0f) return (x * x) * x;
     return powf(x, e);
 }
 

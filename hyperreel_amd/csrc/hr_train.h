@@ -25,11 +25,38 @@
 #include "hr_grid.h"
 #include "hr_math.h"
 
-#if defined(__HIPCC__)
+// Gradient accumulators (texel gradients, basis_mat's, the colour table's, the per-ray decode-matrix gradient in LDS) are `hr_acc_t`.
+// Default build: float, hardware fp32 atomics -- fast, and the sum depends on the order the memory system retires them in (two runs of
+// the same step differ in the last bits).  HR_TRAIN_DET (train_det_kernel.hip, HR_OPT_TRAIN_DETERMINISTIC): 64-bit FIXED POINT
+// (2^-40 units: +-8.4e6 at 9e-13 resolution) through integer atomics -- integer addition is associative, so every run of a step
+// produces the same bits whatever the order; the totals are converted to float once, after the last add.
+#if defined(__HIPCC__) && defined(HR_TRAIN_DET)
+typedef long long hr_acc_t;
+#define HR_ACC_ONE 1099511627776.0f                 // 2^40
+__device__ __forceinline__ long long hr_to_fixed(float v) { return __float2ll_rn(v * HR_ACC_ONE); }
+#define HR_ACC_VALUE(x) ((float)((double)(x) * (1.0 / 1099511627776.0)))
+#define HR_ATOMIC_ADD(p, v) (void)atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)hr_to_fixed(v))
+#define HR_ATOMIC_ADD_ACC(p, x) (void)atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(x))      // an accumulated total onto another (exact)
+#define HR_ATOMIC_ADD_RAY(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) long long*)(p), hr_to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define HR_ACC_ZERO 0ll
+#elif defined(__HIPCC__)
+typedef float hr_acc_t;
+#define HR_ACC_VALUE(x) (x)
+#define HR_ACC_ZERO 0.0f
 #define HR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#define HR_ATOMIC_ADD_ACC(p, x) unsafeAtomicAdd((p), (x))
 // per-ray / per-workgroup accumulators in LDS, shared by the sample threads: the pointer IS an LDS address, say so (a pointer
 // picked from a runtime-indexed array otherwise becomes a flat atomic)
 #define HR_ATOMIC_ADD_RAY(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+typedef float hr_acc_t;
+#define HR_ACC_VALUE(x) (x)
+#define HR_ACC_ZERO 0.0f
+#define HR_ATOMIC_ADD(p, v) (*(p) += (v))
+#define HR_ATOMIC_ADD_ACC(p, x) (*(p) += (x))
+#define HR_ATOMIC_ADD_RAY(p, v) (*(p) += (v))
+#endif
+#if defined(__HIPCC__)
 // sum of v over the `lanes` adjacent lanes that work on one sample (all of them active), returned to every one of them
 __device__ __forceinline__ float hr_lane_sum(float v, int lanes)
 {
@@ -44,8 +71,6 @@ __device__ __forceinline__ float hr_lane_sum(float v, int lanes)
 }
 #define HR_LANE_SUM(v, lanes) hr_lane_sum((v), (lanes))
 #else
-#define HR_ATOMIC_ADD(p, v) (*(p) += (v))
-#define HR_ATOMIC_ADD_RAY(p, v) (*(p) += (v))
 #define HR_LANE_SUM(v, lanes) (v)
 #endif
 
@@ -70,7 +95,7 @@ struct HrTrainTape {
 // range, and pairs without an accumulator, go to the global gradient.  `pairs`: the plane pairs this pass differentiates
 // (a keyframe net whose rows do not fit one workgroup's LDS together is walked in two passes; the later one adds to tape.dp).
 struct HrTrainWindow {
-    float* acc[3];
+    hr_acc_t* acc[3];
     int lo[3], n[3];
     unsigned pairs;
     int add_dp;
@@ -85,15 +110,15 @@ struct HrTrainArgs {
     const float* d_rgb;         // (n, 3) dL/d rgb; NULL: forward only
     float* d_head;              // (n, Z * P) dL/d head, written
     HrGridPlane planes[3];      // packed parameter values (fp32 texels)
-    float* g_a[3];              // packed gradient accumulators, same texel layout as planes[j].a / .b
-    float* g_b[3];
+    hr_acc_t* g_a[3];           // packed gradient accumulators, same texel layout as planes[j].a / .b
+    hr_acc_t* g_b[3];
     const float* basis;         // (app_dim, n_basis_cols)
-    float* d_basis;             // accumulated
+    hr_acc_t* d_basis;          // accumulated
     int n_basis_cols;
     int ca_total;
     int white_bg;               // this step's background decision: white_bg or (training and rand < 0.5), :236
     const float* color_table;   // (color_table_views, 12) per-camera [3x3 | shift] (ColorTransformEmbedding) or NULL
-    float* d_color_table;       // accumulated
+    hr_acc_t* d_color_table;    // accumulated
     HrTrainTape tape;
 };
 
@@ -582,7 +607,7 @@ HR_FN void hr_train_gather(const HrTrainArgs& a, const hr_axis_tap_g* ax, const 
 // run per atomic instruction, which the memory system retires 17x faster than 64 lanes on 64 different cache lines
 // (tools/atomic_ubench.hip: 331 vs 19.5 G atomics/s).
 HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrainTaps& t, const hr_axis_tap_g& gx, const hr_axis_tap_g& gy,
-                                       const hr_axis_tap_g& gv, const hr_axis_tap_g& at, int ch, const float* M, float* dM, int CA,
+                                       const hr_axis_tap_g& gv, const hr_axis_tap_g& at, int ch, const float* M, hr_acc_t* dM, int CA,
                                        float dfeat, const float* dpre, float* d3, const HrTrainWindow* win = nullptr)
 {
     const HrGridPlane& g = a.planes[j];
@@ -606,8 +631,8 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
     }
     if (u == 0.0f) return;
     const float dpa = u * pb, dpb = u * pa;
-    float* GA = a.g_a[j];
-    float* GB = a.g_b[j];
+    hr_acc_t* GA = a.g_a[j];
+    hr_acc_t* GB = a.g_b[j];
     for (int i = 0; i < 4; ++i)
         if (t.wa[i] != 0.0f) HR_ATOMIC_ADD(GA + (size_t)t.ia[i] * g.tex + ch, dpa * t.wa[i]);
     // the line of a static net has a few hundred texels that EVERY sample of the batch hits, the time plane of a keyframe net
@@ -629,7 +654,7 @@ HR_FN void hr_train_gather_bwd_channel(const HrTrainArgs& a, int j, const HrTrai
 // Backward gather of one sample, channels `ch0, ch0 + stride, ...` of every plane pair: returns this caller's share of
 // dL/d normalised coordinates in dpn[3] (the host walks all channels with stride 1; on the device the 16 lanes of a
 // sample take stride 16 and add their shares up).
-HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, float* dM, int CA,
+HR_FN void hr_train_gather_bwd(const HrTrainArgs& a, const hr_axis_tap_g* ax, const hr_axis_tap_g& at, const float* M, hr_acc_t* dM, int CA,
                                float dfeat, const float* dpre, float* dpn, int ch0 = 0, int stride = 1, const HrTrainWindow* win = nullptr)
 {
     dpn[0] = 0.0f; dpn[1] = 0.0f; dpn[2] = 0.0f;
@@ -676,7 +701,7 @@ HR_FN float hr_train_decode_coef(const hr_config& c, const HrTrainArgs& a, const
 // dM[cc][pos] of one ray -> basis_mat gradient.  `acc`: a workgroup-private copy of the whole gradient (LDS, device only) that
 // the workgroup adds to the global one once at the end -- as global atomics these adds are 48 (RGB) or 432 (SH) per ray onto
 // the same few hundred bytes from every ray of the batch: 0.5 of phase B's 0.9 ms on the DoNeRF scene
-HR_FN void hr_train_fold_basis(const hr_config& c, const HrTrainArgs& a, const float* sh, int cc, int pos, float v, float* acc = nullptr)
+HR_FN void hr_train_fold_basis(const hr_config& c, const HrTrainArgs& a, const float* sh, int cc, int pos, float v, hr_acc_t* acc = nullptr)
 {
     if (v == 0.0f) return;
     const int col = hr_train_slot_col(a, pos);
@@ -727,7 +752,7 @@ HR_FN int hr_train_time_row(const hr_config& c, const float* r)
 // The host calls it once per sample; on the device the `lanes` (a power of two <= 64, adjacent lanes of one wavefront)
 // threads of a sample call it together with their `lane`, split the channels between them and combine their shares of
 // the point gradient with HR_LANE_SUM.
-HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane = 0,
+HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, hr_acc_t* dM, int lane = 0,
                                int lanes = 1, const HrTrainWindow* win = nullptr)
 {
     const int Z = c.z_channels, P = c.preds_per_z, CA = a.ca_total;
@@ -754,7 +779,7 @@ HR_FN void hr_sample_train_bwd(const hr_config& c, const HrTrainArgs& a, int64_t
 // Phase B on the device when phase A left the taps on the tape: the 16 lanes of a sample only do what is per channel -- no
 // point, contraction or tap arithmetic repeated by every lane -- and the per-sample tail (hr_sample_point_bwd) is
 // hr_sample_train_point_bwd's, one lane per sample.
-HR_FN void hr_sample_train_bwd_taps(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, float* dM, int lane, int lanes,
+HR_FN void hr_sample_train_bwd_taps(const hr_config& c, const HrTrainArgs& a, int64_t ray, int k, const float* M, hr_acc_t* dM, int lane, int lanes,
                                     const HrTrainWindow* win)
 {
     const int Z = c.z_channels, CA = a.ca_total;
@@ -945,7 +970,7 @@ HR_FN void hr_ray_train(const hr_config& c, const HrTrainArgs& a, int64_t ray)
         int id = (int)rintf(r[c.ray_dim - 2]);
         id = id < 0 ? 0 : (id > c.color_table_views - 1 ? c.color_table_views - 1 : id);
         const float* e = a.color_table + 12 * id;
-        float* de = a.d_color_table + 12 * id;
+        hr_acc_t* de = a.d_color_table + 12 * id;
         float gn[3] = {g[0], g[1], g[2]};
         for (int i = 0; i < 3; ++i) {
             HR_ATOMIC_ADD(de + 9 + i, g[i] * hr_act_grad(c.color_table_s_act, e[9 + i]));

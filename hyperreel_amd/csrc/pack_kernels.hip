@@ -342,3 +342,18 @@ void hr_launch_blend_rows(const float* b, float* line, int row_floats, int i0, i
     if (row_floats <= 0) return;
     hipLaunchKernelGGL(hr_blend_rows_kernel, dim3((unsigned)((row_floats + 255) / 256)), dim3(256), 0, stream, b, line, row_floats, i0, i1, w0, w1);
 }
+
+// 64-bit fixed-point gradient totals of the deterministic training build (hr_train.h: 2^-40 units) -> float, once, after the last add
+__global__ __launch_bounds__(256) void hr_fixed_to_float_kernel(const long long* __restrict__ src, float* __restrict__ dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = (float)((double)src[i] * (1.0 / 1099511627776.0));
+}
+
+void hr_launch_fixed_to_float(const long long* src, float* dst, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(hr_fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
+}

@@ -15,8 +15,14 @@
 //   phase C (intersection backward): one thread per (ray, sample), elementwise.
 #include "hr_kernels.h"
 #include "hr_mask.h"
-#include "hr_train.h"
 #include "sample_core.inc"      // the render kernels' lane-per-sample building blocks (sort, cooperative gather)
+// The deterministic build of the sample-stage training kernels (train_det_kernel.hip: HR_TRAIN_DET, hr_acc_t = 64-bit fixed point, see
+// hr_train.h) compiles this file a second time: everything that depends on hr_acc_t lives in its own namespace there, the exports that
+// do not (rows, features, occupancy) are compiled once, in the default build.
+#ifdef HR_TRAIN_DET
+namespace hr_det {
+#endif
+#include "hr_train.h"
 
 // Phase A walks a ray serially and is bound by the latency of that walk (every sample's gather waits on its point), not by
 // issue slots: a batch of 16 384 rays in full wavefronts is ONE wavefront per CU with nothing to hide the latency behind.
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
         }
     } else if (a.color_table) {
         const float* e = a.color_table + 12 * cam;
-        float* de = a.d_color_table + 12 * cam;
+        hr_acc_t* de = a.d_color_table + 12 * cam;
         float gn[3] = {g[0], g[1], g[2]};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -335,11 +341,12 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 256 / HR_TRAIN_LPS;
     constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
-    extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrix | [RPB][3 * CA] its gradient | basis_mat's gradient, this workgroup's share
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [RPB][3 * CA] decode matrix (float) | [RPB][3 * CA] its gradient | basis_mat's gradient, this workgroup's share (hr_acc_t)
     const int CA = a.ca_total, Z = c.z_channels;
-    float* bacc = lds + 2 * RPB * 3 * CA;
+    hr_acc_t* dMs = reinterpret_cast<hr_acc_t*>(lds + RPB * 3 * CA);
+    hr_acc_t* bacc = dMs + RPB * 3 * CA;
     const int nb = hr_train_basis_rows(c) * a.n_basis_cols;
-    for (int e = threadIdx.x; e < nb; e += 256) bacc[e] = 0.0f;
+    for (int e = threadIdx.x; e < nb; e += 256) bacc[e] = HR_ACC_ZERO;
     const int grp = threadIdx.x / HR_TRAIN_LPS, lane = threadIdx.x % HR_TRAIN_LPS;
     // persistent: the workgroup walks ray blocks blockIdx.x, + gridDim.x, ... and adds its basis_mat gradient to the global one once
     for (int64_t ray0 = (int64_t)blockIdx.x * RPB; ray0 < a.n_rays; ray0 += (int64_t)gridDim.x * RPB) {
@@ -354,14 +361,14 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
                 v = hr_train_decode_coef(c, a, sh, i / CA, i % CA);
             }
             lds[e] = v;
-            lds[RPB * 3 * CA + e] = 0.0f;
+            dMs[e] = HR_ACC_ZERO;
         }
         __syncthreads();
         for (int si = grp; si < RPB * Z; si += GROUPS) {
             const int r = si / Z, k = si - r * Z;
             if (ray0 + r >= a.n_rays) continue;
-            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS, nullptr);
-            else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, lds + (RPB + r) * 3 * CA, lane, HR_TRAIN_LPS);
+            if (a.tape.taps) hr_sample_train_bwd_taps(c, a, ray0 + r, k, lds + r * 3 * CA, dMs + r * 3 * CA, lane, HR_TRAIN_LPS, nullptr);
+            else hr_sample_train_bwd(c, a, ray0 + r, k, lds + r * 3 * CA, dMs + r * 3 * CA, lane, HR_TRAIN_LPS);
         }
         __syncthreads();
         for (int e = threadIdx.x; e < RPB * 3 * CA; e += 256) {
@@ -370,16 +377,17 @@ __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_co
             float sh[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* rr = a.rays + (ray0 + r) * c.ray_dim;
             if (c.shading == HR_SHADING_SH) hr_sh_deg2(rr[3], rr[4], rr[5], sh);
-            hr_train_fold_basis(c, a, sh, i / CA, i % CA, lds[RPB * 3 * CA + e], bacc);
+            hr_train_fold_basis(c, a, sh, i / CA, i % CA, HR_ACC_VALUE(dMs[e]), bacc);
         }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nb; e += 256) {
-        const float v = bacc[e];
-        if (v != 0.0f) HR_ATOMIC_ADD(a.d_basis + e, v);
+        const hr_acc_t v = bacc[e];
+        if (v != HR_ACC_ZERO) HR_ATOMIC_ADD_ACC(a.d_basis + e, v);
     }
 }
 
+#ifndef HR_TRAIN_DET       // the class-specialised, LDS-windowed phase B: float accumulators (the deterministic build takes the generic kernel above)
 // rays per trip: four samples per 16-lane group between the barriers (the per-trip staging of the decode matrices, its barriers and
 // the fold into basis_mat's gradient are then a quarter; measured 1 / 2 / 4 / 8 samples: DoNeRF sample-stage backward 0.84 / 0.80 /
 // 0.78 / 0.77 ms, immersive 1.46 / 1.32 / 1.24 / 1.21, neural_3d 2.56 / 2.32 / 2.19 / 2.14 -- profiles/r03_c_train_experiments.txt)
@@ -700,18 +708,20 @@ static bool hr_lines_opt_in(int pc, size_t lds)
     return hr_lds_opt_in(opt[pc], fn, lds);
 }
 
+#endif
 template <int ZP>
 static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream)
 {
+#if defined(HR_TRAIN_NO_WINDOWS) || defined(HR_TRAIN_DET)      // measurement builds / the deterministic build: the global-atomics kernel for everything
+    (void)cfg; (void)args; (void)stream;
+    return false;
+#else
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
     const int pc = hr_train_plane_class(args, cfg);
     bool any = false, keyed = false;
     for (int j = 0; j < 3; ++j)
         if (args.planes[j].cd4 + args.planes[j].ca4 > 0) { any = true; keyed = keyed || args.planes[j].bw != 1; }
     if (!any) return false;
-#ifdef HR_TRAIN_NO_WINDOWS          // measurement builds: the global-atomics kernel for everything
-    return false;
-#endif
     const size_t base = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols + 4 * RPB);
     const size_t cap = 150 * 1024;
     const int64_t iters = (args.n_rays + RPB - 1) / RPB;
@@ -744,6 +754,7 @@ static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& 
         hr_launch_lines_kernel<ZP, true>(pc, blocks, lds, stream, args, passes[p], p);
     }
     return true;
+#endif
 }
 
 // Tail of phase B (taps path): one thread per sorted sample
@@ -764,7 +775,11 @@ __global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config*
     hr_sample_train_dist_bwd(c, a, s / c.z_channels, (int)(s % c.z_channels));
 }
 
+#ifdef HR_TRAIN_DET
+static void hr_launch_train_impl(const hr_config& cfg, const HrTrainArgs& args_in, hipStream_t stream)
+#else
 void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream_t stream)
+#endif
 {
     if (args_in.n_rays <= 0) return;
     int ZP = 8;
@@ -797,7 +812,7 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
     const int64_t nblocks = (args.n_rays + RPB - 1) / RPB;
     const int64_t resident = 16 * (int64_t)hr_current_device_cus();          // four 256-thread workgroups per CU are resident (128 registers); four rounds of them: the blocks differ in cost
     const unsigned bblocks = (unsigned)(nblocks < resident ? nblocks : resident);
-    const size_t lds = sizeof(float) * (2 * RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
+    const size_t lds = sizeof(float) * (RPB * 3 * args.ca_total) + sizeof(hr_acc_t) * (RPB * 3 * args.ca_total + 27 * args.n_basis_cols);
     if (!done) switch (ZP) {
         case 8: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<8>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
         case 16: hipLaunchKernelGGL(hr_train_gather_bwd_kernel<16>, dim3(bblocks), dim3(256), lds, stream, args.cfg_dev, args); break;
@@ -812,6 +827,17 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
     hipLaunchKernelGGL(hr_train_dist_bwd_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }
 
+#ifdef HR_TRAIN_DET
+}   // namespace hr_det
+// the caller's HrTrainArgs is the default build's (float pointers); the structs differ in pointee types only
+void hr_launch_train_det(const hr_config& cfg, const void* args_flt, size_t args_bytes, hipStream_t stream)
+{
+    hr_det::HrTrainArgs a;
+    if (args_bytes != sizeof(a)) return;
+    memcpy(&a, args_flt, sizeof(a));
+    hr_det::hr_launch_train_impl(cfg, a, stream);
+}
+#else
 // Coarse level of a point_prediction cascade (hr_ray_rows ... in hr_train.h): rows forward per ray, then per sample the
 // point backward and the intersection backward.  Elementwise work, no gather.
 template <int ZP>
@@ -890,3 +916,4 @@ void hr_launch_dense_alpha(const HrMaskArgs& args, hipStream_t stream)
     if (n <= 0) return;
     hipLaunchKernelGGL(hr_dense_alpha_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, args.cfg_dev, args);
 }
+#endif   // !HR_TRAIN_DET

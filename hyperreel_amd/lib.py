@@ -16,7 +16,7 @@ ABI_VERSION = 22
 
 
 HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_PRECISION_ACTIVE, HR_OPT_MLP_OVERFLOW, HR_OPT_MLP_CALIBRATED = 0, 1, 2, 3, 4, 5
-HR_OPT_PLAN_ACTIVE, HR_OPT_PLAN_FAULT, HR_OPT_DUO_CONSUMERS, HR_OPT_DUO_PARTS, HR_OPT_DUO_MLP_WAVES, HR_OPT_DUO_MODE = 6, 7, 8, 9, 10, 11
+HR_OPT_PLAN_ACTIVE, HR_OPT_PLAN_FAULT, HR_OPT_DUO_CONSUMERS, HR_OPT_DUO_MLP_WAVES, HR_OPT_DUO_MODE, HR_OPT_TRAIN_DETERMINISTIC = 6, 7, 8, 9, 10, 11
 HR_E_RANGE = -5
 
 

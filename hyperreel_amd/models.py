@@ -372,7 +372,8 @@ class HipLightfieldModel(nn.Module):
         self._occ_key = None
         self.frame_kernel = self._frame_mode(kwargs.get('frame_kernel', True))
         self.sample_waves = kwargs.get('sample_waves')
-        self.duo = dict(kwargs.get('duo') or {})          # tuning of the co-resident pair: consumers, parts, mlp_waves
+        self.duo = dict(kwargs.get('duo') or {})          # tuning of the co-resident pair: consumers, mlp_waves, mode
+        self.train_deterministic = bool(kwargs.get('train_deterministic', False))
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
             grid = list(kwargs['grid_size'])
@@ -493,6 +494,7 @@ class HipLightfieldModel(nn.Module):
                 # the constants of this iteration and upload again
                 _lib.load().hr_model_destroy(self._native)
                 self._native = None
+                self._render_calls = 0
                 self._native_key = None
                 self.native()
                 return
@@ -585,7 +587,8 @@ class HipLightfieldModel(nn.Module):
         _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_FRAME_KERNEL, int(self.frame_kernel)), 'hr_model_set_option')
         if self.sample_waves is not None:
             _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_SAMPLE_WAVES, int(self.sample_waves)), 'hr_model_set_option')
-        for key, opt in (('consumers', _lib.HR_OPT_DUO_CONSUMERS), ('parts', _lib.HR_OPT_DUO_PARTS), ('mlp_waves', _lib.HR_OPT_DUO_MLP_WAVES), ('mode', _lib.HR_OPT_DUO_MODE)):
+        _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_TRAIN_DETERMINISTIC, int(self.train_deterministic)), 'hr_model_set_option')
+        for key, opt in (('consumers', _lib.HR_OPT_DUO_CONSUMERS), ('mlp_waves', _lib.HR_OPT_DUO_MLP_WAVES), ('mode', _lib.HR_OPT_DUO_MODE)):
             if key in self.duo:
                 _lib.check(L.hr_model_set_option(self._native, opt, int(self.duo[key])), 'hr_model_set_option')
 
@@ -597,12 +600,19 @@ class HipLightfieldModel(nn.Module):
             return 3
         return 2 if (v == 2 and v is not True) else int(bool(v))
 
+    def set_train_deterministic(self, enable=True):
+        """HR_OPT_TRAIN_DETERMINISTIC: the training step's gradient sums as 64-bit fixed point through integer atomics -- two runs of the
+        same step agree bit for bit (the default, fp32 atomics, is faster and reproducible to rounding only)."""
+        self.train_deterministic = bool(enable)
+        if self._native is not None:
+            self._apply_options()
+
     def set_execution(self, frame_kernel=None, sample_waves=None, duo=None):
         """Chooses how render() is laid out on the device (images are bit-identical under every setting):
         frame_kernel False = always the two-kernel path through the HBM workspace, True = the library's choice (the faster plan
         per model family), 2 = the persistent frame kernel wherever the model fits it, 'duo' = the co-resident pair (persistent MLP
-        kernel + persistent sample kernel on two streams); sample_waves 4 | 8 (frame kernel); duo = {'consumers': sample workgroups
-        per CU, 'parts': tickets per 64-ray tile, 'mlp_waves': 4 | 8 | 3}."""
+        kernel + persistent sample kernel on two streams); sample_waves 4 | 8 (frame kernel); duo = {'consumers': sample blocks
+        per CU (measurement knob), 'mlp_waves': 4 | 8 | 3 | 6}."""
         if frame_kernel is not None:
             self.frame_kernel = self._frame_mode(frame_kernel)
         if sample_waves is not None:
@@ -667,6 +677,7 @@ class HipLightfieldModel(nn.Module):
             if self._native is not None:
                 _lib.load().hr_model_destroy(self._native)
                 self._native = None
+                self._render_calls = 0
         except Exception:
             pass
 
@@ -700,11 +711,14 @@ class HipLightfieldModel(nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(rays.device).cuda_stream)
         with torch.cuda.device(rays.device):
             if not want:
-                if frame_time is not None:
-                    _lib.check(L.hr_render_frame(h, C.c_void_p(rays.data_ptr()), B, float(frame_time), C.c_void_p(out['rgb'].data_ptr()), stream),
-                               'hr_render_frame')
-                else:
-                    _lib.check(L.hr_render(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()), stream), 'hr_render')
+                for attempt in (0, 1):
+                    if frame_time is not None:
+                        _lib.check(L.hr_render_frame(h, C.c_void_p(rays.data_ptr()), B, float(frame_time), C.c_void_p(out['rgb'].data_ptr()), stream),
+                                   'hr_render_frame')
+                    else:
+                        _lib.check(L.hr_render(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()), stream), 'hr_render')
+                    if attempt == 1 or not self._overflow_guard(rays):
+                        break
                 return out
             f = hr_fields()
             shapes = {'distances': (B, Z), 'points': (B, Z, 3), 'sigma': (B, Z), 'render_weights': (B, Z),
@@ -717,6 +731,24 @@ class HipLightfieldModel(nn.Module):
             _lib.check(L.hr_render_fields(h, C.c_void_p(rays.data_ptr()), B, C.c_void_p(out['rgb'].data_ptr()),
                                           C.byref(f), stream), 'hr_render_fields')
         return out
+
+    def _overflow_guard(self, rays):
+        """The fp16 split arithmetic ('auto' -> f16x3) was chosen on CALIBRATION rays (hr_model_finalize: synthetic origins in and around
+        the scene box); real cameras may stand further out, and activations beyond the IEEE-half range would render inf / NaN where the
+        reference's fp32 BaseMLP (nlf/nets/mlp.py:159-172) does not.  The kernels raise a sticky bit when that happens; it is read here
+        on the model's first render call, its 16th and every 1024th (one 4-byte read behind a synchronise; never inside a stream
+        capture).  If set: the arithmetic is re-decided on the offending rays -- 'auto' re-packs as bf16x3 (fp32 exponent range), a forced
+        fp16 mode raises HipRangeError -- and the caller renders the batch again.  Returns True when it did so."""
+        n = self._render_calls = getattr(self, '_render_calls', 0) + 1
+        if not (n == 1 or n == 16 or n % 1024 == 0) or torch.cuda.is_current_stream_capturing():
+            return False
+        if self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE) not in (2, 3) or not self.mlp_overflowed():
+            return False
+        import warnings
+        warnings.warn('hyperreel_amd: an MLP activation reached the IEEE-half range on rendered rays (the fp16 split arithmetic had been chosen '
+                      'on calibration rays); re-deciding the arithmetic on these rays and rendering the batch again')
+        self.calibrate(rays)
+        return True
 
     def generate_rays(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None, device=None):
         """get_coords_from_camera (datasets/base.py:485-518) on the device: 3x4 camera-to-world

@@ -26,12 +26,17 @@ from hyperreel_amd import scenes  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden', 'fit')
 CASES = {
-    # case: (model, grid, student seed, teacher seed, rays: (H, W, frame))
-    'donerf_sphere_fit': ('donerf_sphere', [32, 32, 32], 21, 22, (32, 32, 3)),
-    'technicolor_z_plane_fit': ('technicolor_z_plane', [32, 32, 32], 23, 24, (32, 32, 5)),
+    # case: (model, grid, student seed, teacher seed, rays: (H, W, frame), Adam learning rate)
+    # The sphere scene's loss surface has the reference's own steps in it (a sample crossing `dist <= near`, intersect/base.py:194-203,
+    # changes the image by a jump): at lr 2e-4 and seeds 21 / 22 (round 3's fixture) two correct fp32 executions of the reference -- all
+    # threads vs one thread -- ended 0.18 dB / 30 % of the loss apart, which made the fixture a yardstick of nothing.  Round 4 searched
+    # seeds x learning rates with this script's own loop (profiles/r04_fit_fixture_search.txt) for a run the reference reproduces:
+    # seeds 41 / 42 at lr 1e-4 -- 17.6 -> 33.8 dB in 200 steps, reference vs itself 0.017 dB / 0.4 % of the loss.
+    'donerf_sphere_fit': ('donerf_sphere', [32, 32, 32], 41, 42, (32, 32, 3), 1e-4),
+    'technicolor_z_plane_fit': ('technicolor_z_plane', [32, 32, 32], 23, 24, (32, 32, 5), 2e-4),
 }
 N_STEPS = 200
-LR = 2e-4
+LR = 2e-4            # (per case: CASES[...][5])
 
 
 def build(model, grid, dataset, sd):
@@ -77,7 +82,9 @@ def fit(model, grid, ds, student_sd, rays, target):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for case, (model, grid, s_seed, t_seed, (H, W, frame)) in CASES.items():
+    global LR
+    for case, (model, grid, s_seed, t_seed, (H, W, frame), lr) in CASES.items():
+        LR = lr
         cfg, ds = C.model_config(model), C.dataset_scalars(model)
         rays_np = np.ascontiguousarray(scenes.benchmark_rays(model, H, W, frame=frame), np.float32)
         rays = torch.from_numpy(rays_np)

@@ -109,6 +109,10 @@ def _v_donerf_contract_pow2(cfg):             # ... and with its defaults: power
     _isect(cfg).contract = {'type': 'donerf', 'contract_samples': True, 'contract_end_radius': 40.0}
 
 
+def _v_donerf_contract_pow3(cfg):             # ... power 3: ATen's pow kernel takes x * x * x for the inverse contraction, powf(., 1/3) for the points
+    _isect(cfg).contract = {'type': 'donerf', 'contract_samples': True, 'contract_end_radius': 40.0, 'power': 3.0}
+
+
 def _v_color_transform_global_head(cfg):      # transform_color_one fed from the MLP head instead of the per-camera table (tensorf_no_sample.py:242-243)
     out = _pred(cfg).outputs
     spec = out.pop('color_scale_global')
@@ -163,6 +167,7 @@ VARIANTS = [
     ('variant_color_transform_global_head', 'catacaustics_distance', _v_color_transform_global_head),
     ('variant_donerf_contract', 'donerf_sphere', _v_donerf_contract),
     ('variant_donerf_contract_pow2', 'donerf_cylinder', _v_donerf_contract_pow2),
+    ('variant_donerf_contract_pow3', 'donerf_sphere', _v_donerf_contract_pow3),
     ('variant_mask_off_unsorted', 'donerf_sphere', _v_mask_off_unsorted),
     # inside the activation / encoding warm-up windows (EaseValue, activations.py:462-496; WindowedPE, pe.py:166-208)
     ('variant_ease_iter2000', 'donerf_sphere', None, 2000),

@@ -92,3 +92,25 @@ def test_sticky_overflow_bit_reports_rendered_rays_that_leave_the_half_range():
             make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3').model.calibrate(torch.from_numpy(far).cuda())
         fn.model.calibrate(torch.from_numpy(far).cuda())
         assert fn.model.mlp_precision_active() == 'bf16x3'
+
+
+def test_first_render_call_checks_the_bit_and_falls_back_to_bf16x3():
+    """the arithmetic is chosen on synthetic calibration rays; a model whose FIRST real batch leaves the half range must not
+    return an image made from saturated operands -- render() reads the sticky bit on the first call, re-decides on those rays (auto ->
+    bf16x3) and renders the batch again"""
+    from gpu_common import make_render_fn, render_np
+    g = Golden('donerf_sphere_small')
+    far = g.rays.copy()
+    far[:, :3] *= 1e6
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    assert fn.model.mlp_precision_active() == 'f16x3'
+    with pytest.warns(UserWarning, match='IEEE-half range'):
+        img = render_np(fn, far)['rgb']
+    assert fn.model.mlp_precision_active() == 'bf16x3' and not fn.model.mlp_overflowed()
+    ref = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='bf16x3'), far)['rgb']
+    assert np.isfinite(img).all() and np.array_equal(img, ref)
+    # a forced fp16 mode is refused loudly instead
+    from hyperreel_amd.lib import HipRangeError
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3')
+    with pytest.warns(UserWarning), pytest.raises(HipRangeError):
+        render_np(fn, far)

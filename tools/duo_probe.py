@@ -1,8 +1,8 @@
 """The co-resident pair ("duo" plan) against the other execution plans on ONE frame, in one process:
     python tools/duo_probe.py [--model donerf_sphere] [--configs "c=3,p=4,w=4;c=3,p=2,w=3"] [--rounds 3] [--steps 20] [--frame-time]
 Every configuration renders the frame eagerly and through a captured hipGraph, is compared bit for bit with the two-kernel plan's
-image, and is timed in alternation with the library's default plan.  c = sample workgroups per CU, p = tickets per tile,
-w = MLP wavefronts per producer (4 | 8 | 3 = four with the three-slot weight ring).  Measurement aid (GPU box)."""
+image, and is timed in alternation with the library's default plan.  c = sample blocks per CU (0: as many as fit), w = MLP wavefronts per producer (4 | 8 | 3 / 6 = four with a three- / six-slot
+weight ring), m = measurement mode (1: one stream, 2: producer only, 3: consumer only).  Measurement aid (GPU box)."""
 import argparse, json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,7 +70,7 @@ g2, out2 = B.capture(base2.model, rays, frame_time=ft)
 variants.append({'name': 'two_kernels', 'graph': g2, 'out': out2, 'fn': base2, 'ms': [], 'eager_equal': True})
 for spec in args.configs.split(';'):
     kv = dict(x.split('=') for x in spec.split(','))
-    duo = {'consumers': int(kv.get('c', 0)), 'parts': int(kv.get('p', 0)), 'mlp_waves': int(kv.get('w', 0)), 'mode': int(kv.get('m', 0))}
+    duo = {'consumers': int(kv.get('c', 0)), 'mlp_waves': int(kv.get('w', 0)), 'mode': int(kv.get('m', 0))}
     mode = duo.pop('mode')
     fn = make('duo', duo)
     m = fn.model
