@@ -111,14 +111,6 @@ struct hr_model {
     int opt_frame_kernel = 1;              // measured equal-or-faster than the two-kernel path where it applies, at 1/20 of the HBM traffic
     int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
     int n_cus = 0;
-    // the co-resident pair ("duo" plan, hr_kernels.h): a side stream, fork / join events, the whole-launch head workspace
-    hipStream_t duo_stream = nullptr;
-    hipEvent_t duo_fork = nullptr, duo_join = nullptr;
-    unsigned* duo_sync = nullptr;         // [HR_DUO_CTL_WORDS ticket words | one flag per tile]
-    float* duo_head = nullptr;            // HQ layout, duo_cap rays
-    int64_t duo_cap = 0;                  // rays one launch pair can take (multiple of 64)
-    int opt_duo_consumers = 0, opt_duo_mlp_waves = 0;     // 0: the plan's defaults
-    int opt_duo_mode = 0;                 // measurement: 1 = both kernels on ONE stream (producer, then consumer), 2 = producer only, 3 = consumer only (on the flags the last pair left)
 };
 
 namespace {
@@ -1009,120 +1001,6 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
     }
 }
 
-// ---- the co-resident pair ("duo" plan): persistent MLP kernel on `st`, persistent sample kernel on the model's side stream
-static const int64_t HR_DUO_MAX_BYTES = (int64_t)3 << 30;     // head workspace of one launch pair
-
-static bool duo_applies(hr_model* m)
-{
-    if (m->coarse || m->is_coarse || m->cfg.mlp_layers == 0) return false;
-    if (m->active_precision != HR_MLP_BF16X3 && m->active_precision != HR_MLP_F16X3 && m->active_precision != HR_MLP_F16X2) return false;
-    HrMlpArgs ma;
-    fill_mlp_args(m, ma, nullptr, 64);
-    HrSampleArgs sa;
-    fill_sample_args(m, sa, nullptr, 64, nullptr);
-    HrDuoArgs q{};
-    q.n_tiles = 1; q.n_queues = 1; q.producers = 1;
-    if (!hr_launch_duo_consumer(m->kcfg, sa, q, m->opt_duo_consumers, m->n_cus, true, nullptr)) return false;
-    return hr_launch_duo_producer_f16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, true, nullptr);
-}
-
-// Sizes the pair's workspace for calls of n rays (grows only; never while `st` is being captured into a graph).  Returns the rays
-// one launch pair may take, 0 when there is no workspace and none can be made now.
-static int64_t ensure_duo(hr_model* m, int64_t n, hipStream_t st)
-{
-    const int64_t nq = (m->n_out + 3) / 4;
-    const int64_t row_bytes = nq * 16;
-    int64_t want = (n + 63) & ~(int64_t)63;
-    const int64_t max_rays = (HR_DUO_MAX_BYTES / row_bytes) & ~(int64_t)63;
-    if (want > max_rays) want = max_rays;
-    if (m->duo_cap >= want) return m->duo_cap;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return m->duo_cap; }
-    if (cs != hipStreamCaptureStatusNone) return m->duo_cap;       // (a captured call renders with what an earlier call reserved)
-    if (!m->duo_stream) {
-        if (hipStreamCreateWithFlags(&m->duo_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); m->duo_stream = nullptr; return 0; }
-        if (hipEventCreateWithFlags(&m->duo_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->duo_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    }
-    (void)hipStreamSynchronize(st);
-    (void)hipStreamSynchronize(m->duo_stream);
-    free_dev(m->duo_head);
-    free_dev(reinterpret_cast<float*&>(m->duo_sync));
-    m->duo_cap = 0;
-    if (hipMalloc((void**)&m->duo_head, (size_t)(want * row_bytes)) != hipSuccess ||
-        hipMalloc((void**)&m->duo_sync, sizeof(unsigned) * (size_t)(HR_DUO_CTL_WORDS + want / 64)) != hipSuccess) {
-        (void)hipGetLastError();
-        free_dev(m->duo_head);
-        free_dev(reinterpret_cast<float*&>(m->duo_sync));
-        return 0;
-    }
-    m->duo_cap = want;
-    return want;
-}
-
-static bool launch_duo(hr_model* m, const float* rays, int64_t n, float* rgb, hipStream_t st)
-{
-    if (!duo_applies(m)) return false;
-    if (n <= 0) return true;
-    // Not inside a stream capture: a replayed hipGraph runs the two kernel nodes one after the other (measured on ROCm 7.2, with and
-    // without DEBUG_CLR_GRAPH_PACKET_CAPTURE: the consumer starts ~15 us after the producer has ENDED) and in an order it chooses --
-    // the consumer first means 0.3 s of waiting and a faulted frame.  A captured call takes the plans that are one stream's work.
-    if (m->opt_duo_mode == 0) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (cs != hipStreamCaptureStatusNone) return false;
-    }
-    const int64_t cap = ensure_duo(m, n, st);
-    if (cap <= 0) return false;
-    const hr_config& c = m->cfg;
-    for (int64_t r0 = 0; r0 < n; r0 += cap) {
-        const int64_t nn = (n - r0 < cap) ? (n - r0) : cap;
-        HrMlpArgs ma;
-        fill_mlp_args(m, ma, rays + r0 * c.ray_dim, nn);
-        ma.head = m->duo_head;
-        HrSampleArgs sa;
-        fill_sample_args(m, sa, rays + r0 * c.ray_dim, nn, rgb + r0 * 3);
-        sa.head = m->duo_head;
-        HrDuoArgs q;
-        q.ctl = m->duo_sync;
-        q.flags = m->duo_sync + HR_DUO_CTL_WORDS;
-        q.status = m->flags;
-        q.n_tiles = (int)((nn + 63) / 64);
-        q.producers = q.n_tiles < m->n_cus ? q.n_tiles : m->n_cus;
-        q.n_queues = q.producers < 8 ? q.producers : 8;
-        // every polled word is zeroed before every launch pair (a memset node when captured: replayed first)
-        const int mode = m->opt_duo_mode;
-        if (hipMemsetAsync(m->duo_sync, 0, sizeof(unsigned) * (size_t)(HR_DUO_CTL_WORDS + (mode == 3 ? 0 : q.n_tiles)), st) != hipSuccess) return false;
-        if (mode != 0) {                         // measurement modes: no second stream
-            bool ok = true;
-            if (mode != 3) {
-                switch (m->active_precision) {
-                    case HR_MLP_BF16X3: ok = hr_launch_duo_producer_bf16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-                    case HR_MLP_F16X3: ok = hr_launch_duo_producer_f16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-                    default: ok = hr_launch_duo_producer_f16x2(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-                }
-            }
-            HrDuoArgs qc = q;
-            if (mode == 3) qc.producers = 0;     // (no producer in this mode: the gate must not wait for one)
-            if (ok && mode != 2) ok = hr_launch_duo_consumer(m->kcfg, sa, qc, m->opt_duo_consumers, m->n_cus, false, st);
-            if (!ok) return false;
-            continue;
-        }
-        if (hipEventRecord(m->duo_fork, st) != hipSuccess || hipStreamWaitEvent(m->duo_stream, m->duo_fork, 0) != hipSuccess) return false;
-        bool ok;
-        switch (m->active_precision) {          // the producer first: it waits for nothing
-            case HR_MLP_BF16X3: ok = hr_launch_duo_producer_bf16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-            case HR_MLP_F16X3: ok = hr_launch_duo_producer_f16x3(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-            default: ok = hr_launch_duo_producer_f16x2(m->kcfg, m->kcfg_dev, ma, q, m->opt_duo_mlp_waves, m->n_cus, false, st); break;
-        }
-        if (ok) ok = hr_launch_duo_consumer(m->kcfg, sa, q, m->opt_duo_consumers, m->n_cus, false, m->duo_stream);
-        // the join is recorded whatever happened, so that `st` (and a capture) is never left forked
-        if (hipEventRecord(m->duo_join, m->duo_stream) != hipSuccess || hipStreamWaitEvent(st, m->duo_join, 0) != hipSuccess) return false;
-        if (!ok) return false;
-    }
-    return true;
-}
-
 static int check_render(const hr_model* m, const float* rays, int64_t n, const float* rgb)
 {
     if (!m) return fail(HR_E_INVALID, "null model");
@@ -1139,10 +1017,6 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     hipStream_t st = (hipStream_t)stream;
     const hr_config& c = m->cfg;
     const int Z = c.z_channels;
-    if (!fields && m->opt_frame_kernel == 3 && launch_duo(m, rays_dev, n_rays, rgb_dev, st)) {
-        HR_HIP(hipGetLastError());
-        return HR_OK;
-    }
     if (!fields && launch_frame(m, rays_dev, n_rays, rgb_dev, false, st)) {
         HR_HIP(hipGetLastError());
         return HR_OK;
@@ -1264,20 +1138,11 @@ int hr_model_set_option(hr_model* m, int32_t option, int32_t value)
 {
     if (!m) return fail(HR_E_INVALID, "null model");
     if (option == HR_OPT_FRAME_KERNEL) {
-        if (value < 0 || value > 3) return fail(HR_E_INVALID, "HR_OPT_FRAME_KERNEL takes 0, 1, 2 or 3");
+        if (value < 0 || value > 2) return fail(HR_E_INVALID, "HR_OPT_FRAME_KERNEL takes 0, 1 or 2");
         m->opt_frame_kernel = value;
-    } else if (option == HR_OPT_DUO_CONSUMERS) {
-        if (value < 0 || value > 8) return fail(HR_E_INVALID, "HR_OPT_DUO_CONSUMERS takes 0 (the plan's default) .. 8 sample workgroups per CU");
-        m->opt_duo_consumers = value;
-    } else if (option == HR_OPT_DUO_MODE) {
-        if (value < 0 || value > 3) return fail(HR_E_INVALID, "HR_OPT_DUO_MODE takes 0 .. 3");
-        m->opt_duo_mode = value;
     } else if (option == HR_OPT_TRAIN_DETERMINISTIC) {
         if (value != 0 && value != 1) return fail(HR_E_INVALID, "HR_OPT_TRAIN_DETERMINISTIC takes 0 or 1");
         m->opt_train_det = value;
-    } else if (option == HR_OPT_DUO_MLP_WAVES) {
-        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 8) return fail(HR_E_INVALID, "HR_OPT_DUO_MLP_WAVES takes 0 (the plan's default), 4, 8, or 3 (four wavefronts, three-slot weight ring)");
-        m->opt_duo_mlp_waves = value;
     } else if (option == HR_OPT_SAMPLE_WAVES) {
         if (value != 0 && value != 4 && value != 8) return fail(HR_E_INVALID, "HR_OPT_SAMPLE_WAVES takes 0 (the plan's default), 4 or 8");
         m->opt_sample_waves = value;
@@ -1292,20 +1157,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (!m || !value) return fail(HR_E_INVALID, "null argument");
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
-    else if (option == HR_OPT_DUO_CONSUMERS) *value = m->opt_duo_consumers;
-    else if (option == HR_OPT_DUO_MLP_WAVES) *value = m->opt_duo_mlp_waves;
-    else if (option == HR_OPT_DUO_MODE) *value = m->opt_duo_mode;
     else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
-    else if (option == HR_OPT_PLAN_FAULT) {
-        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
-        unsigned f = 0;
-        HR_HIP(hipMemcpy(&f, m->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
-        *value = (int32_t)((f >> 1) & 1u);
-    } else if (option == HR_OPT_PLAN_ACTIVE) {
-        if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
-        if (m->opt_frame_kernel == 3 && duo_applies(m)) *value = 2;
-        else *value = launch_frame(m, nullptr, 64, nullptr, true, nullptr) ? 1 : 0;
-    }
     else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         if (option == HR_OPT_MLP_PRECISION_ACTIVE) *value = m->active_precision;
@@ -1777,19 +1629,6 @@ int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsig
     return HR_OK;
 }
 
-int hr_debug_duo_times(hr_model* m, unsigned long long* out8)
-{
-    if (!m || !out8) return fail(HR_E_INVALID, "null argument");
-    for (int i = 0; i < 8; ++i) out8[i] = 0ull;
-    if (!m->duo_sync) return HR_OK;
-    HR_HIP(hipDeviceSynchronize());
-    unsigned long long t[8];
-    HR_HIP(hipMemcpy(t, m->duo_sync + 272, sizeof(t), hipMemcpyDeviceToHost));
-    out8[0] = t[0] ? ~t[0] : 0ull; out8[1] = t[1]; out8[2] = t[2] ? ~t[2] : 0ull; out8[3] = t[3];
-    for (int i = 4; i < 8; ++i) out8[i] = t[i];
-    return HR_OK;
-}
-
 int64_t hr_model_device_bytes(const hr_model* m)
 {
     if (!m) return 0;
@@ -1825,11 +1664,6 @@ void hr_model_destroy(hr_model* m)
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); free_dev(m->frame_line[j]); }
     free_dev(m->tape);
     if (m->grad_fx) (void)hipFree(m->grad_fx);
-    if (m->duo_stream) { (void)hipStreamSynchronize(m->duo_stream); (void)hipStreamDestroy(m->duo_stream); }
-    if (m->duo_fork) (void)hipEventDestroy(m->duo_fork);
-    if (m->duo_join) (void)hipEventDestroy(m->duo_join);
-    free_dev(m->duo_head);
-    free_dev(reinterpret_cast<float*&>(m->duo_sync));
     hr_model_destroy(m->coarse);
     delete m;
 }

@@ -4,8 +4,6 @@
 #define HR_SPLIT_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define HR_FUSED_KERNEL hr_frame_f16x3_kernel
 #define HR_FUSED_LAUNCH hr_launch_frame_f16x3
-#define HR_DUO_KERNEL hr_duo_mlp_f16x3_kernel
-#define HR_DUO_LAUNCH hr_launch_duo_producer_f16x3
 #define HR_TUNING_SET hr_tuning_set_f16x3
 #define HR_TUNING_PHASES hr_tuning_phases_f16x3
 #include "fused_impl.inc"

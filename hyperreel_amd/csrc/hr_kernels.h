@@ -133,37 +133,6 @@ bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSa
 bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
                             hipStream_t stream);
 
-// ---------------------------------------------------------------- the co-resident pair ("duo" plan: fused_impl.inc + sampleq_kernel.hip)
-// Two kernels on two streams of ONE device, resident on the same CUs at the same time, each with its OWN register allocation: the
-// producer (a persistent 4-wavefront MLP workgroup per CU, matrix cores; 168-203 VGPRs) writes each 64-ray tile of the raw head to a
-// whole-launch workspace write-through and raises the tile's flag; the consumer (the stand-alone sample kernel's grid, 77 VGPRs,
-// three or four of its blocks per CU beside the producer, vector ALU / texture path) is dispatched in order by the hardware, each
-// block waiting for the flag of the tile its rays belong to.  Nothing ever waits for a consumer, so the pair completes under ANY
-// dispatch order or placement in which the producer eventually runs; a consumer that sees no flag for HR_DUO_TIMEOUT_TICKS gives up and
-// raises bit 1 of the model's status word instead of hanging.  Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility":
-// payload and flag are sc1 (write-through) stores, every writing wavefront drains vmcnt before the flag; the consumer polls the flag
-// relaxed at agent scope (one lane, sleeping) and reads the payload with sc1 loads (served past its own L1).
-#define HR_DUO_TIMEOUT_TICKS 30000000ull     // s_memrealtime ticks (100 MHz): 0.3 s
-#define HR_DUO_CTL_WORDS 512                 // control words of a launch pair, zeroed with the flags before every pair:
-                                             //   [256 + 32 x] "the pair is over" word of queue x (own 128-byte line each; a consumer gave up)
-                                             //   [264] producer workgroups that have started (the consumer grid's gate waits for all of them)
-                                             //   [272 .. 287] eight 64-bit measurement words (hr_debug_duo_times)
-struct HrDuoArgs {
-    unsigned* flags;        // [n_tiles]: 0 -> 1 when the tile's head is complete in the workspace; zeroed before every launch pair
-    unsigned* ctl;          // [HR_DUO_CTL_WORDS]
-    unsigned* status;       // the model's sticky status word: bit 1 = a consumer gave up waiting for a tile
-    int n_tiles;            // 64-ray tiles of the launch pair
-    int n_queues;           // queues = XCDs the producer grid spans: min(8, producer workgroups)
-    int producers;          // producer workgroups; workgroup b serves queue b % 8 and makes its tiles idx, idx + wx, ... (idx = b / 8)
-};
-// queue x owns the contiguous tile range [n_tiles * x / n_queues, n_tiles * (x + 1) / n_queues)
-__host__ __device__ inline int hr_duo_tile_lo(int n_tiles, int n_queues, int x) { return (int)(((int64_t)n_tiles * x) / n_queues); }
-bool hr_launch_duo_producer_bf16x3(const hr_config& cfg, const hr_config* cfg_dev, const HrMlpArgs& ma, const HrDuoArgs& q, int mlp_waves, int n_cus, bool probe, hipStream_t stream);
-bool hr_launch_duo_producer_f16x3(const hr_config& cfg, const hr_config* cfg_dev, const HrMlpArgs& ma, const HrDuoArgs& q, int mlp_waves, int n_cus, bool probe, hipStream_t stream);
-bool hr_launch_duo_producer_f16x2(const hr_config& cfg, const hr_config* cfg_dev, const HrMlpArgs& ma, const HrDuoArgs& q, int mlp_waves, int n_cus, bool probe, hipStream_t stream);
-// consumers_per_cu: measurement knob -- an LDS request that admits exactly that many sample blocks per CU beside the producer (0: as many as fit)
-bool hr_launch_duo_consumer(const hr_config& cfg, const HrSampleArgs& sa, const HrDuoArgs& q, int consumers_per_cu, int n_cus, bool probe, hipStream_t stream);
-
 // activation range of the MLP on a set of rays (range_kernel.hip): act_max[0] = max |input feature|, act_max[l + 1] = max |pre-activation|
 // of hidden Linear l; w / b: the uploaded reference-layout tensors (out, in) / (out)
 struct HrRangeArgs {

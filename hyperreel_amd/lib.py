@@ -16,7 +16,7 @@ ABI_VERSION = 22
 
 
 HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_PRECISION_ACTIVE, HR_OPT_MLP_OVERFLOW, HR_OPT_MLP_CALIBRATED = 0, 1, 2, 3, 4, 5
-HR_OPT_PLAN_ACTIVE, HR_OPT_PLAN_FAULT, HR_OPT_DUO_CONSUMERS, HR_OPT_DUO_MLP_WAVES, HR_OPT_DUO_MODE, HR_OPT_TRAIN_DETERMINISTIC = 6, 7, 8, 9, 10, 11
+HR_OPT_TRAIN_DETERMINISTIC = 6
 HR_E_RANGE = -5
 
 
@@ -68,7 +68,6 @@ SYMBOLS = [
     ('hr_stage_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('hr_stage_samples', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_debug_trace_mlp', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    ('hr_debug_duo_times', C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ('hr_model_device_bytes', C.c_int64, [C.c_void_p]),
     ('hr_model_destroy', None, [C.c_void_p]),
 ]

