@@ -589,18 +589,13 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
         const int rd = m->coarse ? c.casc_row_dim : c.ray_dim;
         e = hipMalloc((void**)&synth, sizeof(float) * n * rd);
         if (e == hipSuccess) {
-            // where rays start.  Cascade rows (first columns: points): the model's box.  Rays: half of them inside the box, half in a box
-            // three times as large about the same centre -- cameras usually stand OUTSIDE the scene box, and ray parameterisations
-            // such as the Pluecker moment o x d grow with |o| (a caller who knows the real cameras passes rays: hr_model_calibrate)
-            float lo3[3], hi3[3];
-            for (int i = 0; i < 3; ++i) {
-                const float mid = 0.5f * (c.aabb[i] + c.aabb[3 + i]), half = 0.5f * (c.aabb[3 + i] - c.aabb[i]);
-                lo3[i] = mid - 3.0f * half;
-                hi3[i] = mid + 3.0f * half;
-            }
-            hr_launch_synthetic_rays(synth, n / 2, rd, c.aabb, c.aabb + 3, 0x5eedu, st);
-            if (m->coarse) hr_launch_synthetic_rays(synth + (size_t)(n / 2) * rd, n - n / 2, rd, c.aabb, c.aabb + 3, 0x5eeeu, st);
-            else hr_launch_synthetic_rays(synth + (size_t)(n / 2) * rd, n - n / 2, rd, lo3, hi3, 0x5eeeu, st);
+            // where rays start: the model's own box, or (cascade rows, whose first columns are points) the same box.  Real cameras may stand
+            // outside it, and a parameterisation such as the Pluecker moment o x d grows with |o|: a caller who has the real rays passes
+            // them (hr_model_calibrate), and the host checks the kernels' sticky overflow bit on the first rendered batches and
+            // falls back to bf16x3 (models.py, _overflow_guard).  (Origins in a box three times as large were tried for this default: with
+            // uniformly random directions the two-plane families then show activations of 1.8e4 that no camera of theirs produces,
+            // and AUTO would give up f16x3 -- and its zero flipped rays, DESIGN 3a -- on every one of them.)
+            hr_launch_synthetic_rays(synth, n, rd, c.aabb, c.aabb + 3, 0x5eedu, st);
             rays_dev = synth;
         }
     }
