@@ -425,5 +425,7 @@ def test_deterministic_gradients_equal_the_default_ones_to_rounding(case):
     assert set(d0) == set(f) and len(d0) >= 15
     for n in d0:
         assert np.array_equal(d0[n], d1[n]), n
+        if d0[n].size == 0:                       # (plane pairs without appearance components carry empty tensors)
+            continue
         scale = max(float(np.abs(f[n]).max()), 1e-30)
         assert float(np.abs(d0[n] - f[n]).max()) <= 1e-5 * scale, (n, float(np.abs(d0[n] - f[n]).max()), scale)
