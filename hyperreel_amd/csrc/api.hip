@@ -95,6 +95,9 @@ struct hr_model {
     hr_config* ucfg_dev = nullptr;
     float* grad_a[3] = {};
     float* grad_b[3] = {};
+    void* wsplit_t[HR_MAX_LAYERS] = {};  // training forward (hr_mlp_train_forward): bf16 split tiles of the CURRENT parameter values, re-packed on the device every step
+    float* bias_t[HR_MAX_LAYERS] = {};
+    int n_tiles_t[HR_MAX_LAYERS] = {};
     long long* grad_fx = nullptr;        // deterministic training (HR_OPT_TRAIN_DETERMINISTIC): ONE 64-bit fixed-point buffer for every accumulator of a step
     size_t grad_fx_elems = 0;
     int opt_train_det = 0;
@@ -1373,6 +1376,66 @@ int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float*
     return HR_OK;
 }
 
+int hr_mlp_train_forward(hr_model* m, const float* const* weights_dev, const float* const* biases_dev, const float* rays_dev, int64_t n_rays,
+                         float* const* acts_dev, const int64_t* act_ld, const int32_t* act_off, float* head_dev, void* stream)
+{
+    int rc = check_train(m, rays_dev, n_rays);
+    if (rc != HR_OK) return rc;
+    if (m->coarse || m->is_coarse) return fail(HR_E_INVALID, "hr_mlp_train_forward: point_prediction cascades run their MLPs layer by layer (hr_linear_forward)");
+    const hr_config& c = m->cfg;
+    const int L = c.mlp_layers;
+    if (L < 2 || c.mlp_hidden != 256) return fail(HR_E_INVALID, "hr_mlp_train_forward needs hidden width 256 and at least two layers");
+    if (!weights_dev || !biases_dev || !acts_dev || !act_ld || !act_off || (n_rays > 0 && !head_dev)) return fail(HR_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    // ---- the current parameter values -> bf16 hi / lo tiles, on the device (what pack_mlp does on the host at finalize)
+    const int P_user = c.preds_per_z, P_live = m->p_live;
+    const int k0p = (c.mlp_in + 15) & ~15;
+    const int n_out = samples_per_row(c) * P_live;
+    for (int l = 0; l < L; ++l) {
+        if (!weights_dev[l] || !biases_dev[l]) return fail(HR_E_INVALID, "hr_mlp_train_forward: layer %d has no weights", l);
+        HrPackDesc d = {};
+        d.w = weights_dev[l]; d.b = biases_dev[l];
+        d.last = (l == L - 1); d.first = (l == 0); d.skip = (c.mlp_skip_mask >> l) & 1;
+        d.N_user = layer_out(c, l); d.Kt = layer_in(c, l);
+        d.N = d.last ? n_out : d.N_user;
+        d.nt = (d.N + 31) / 32;
+        d.Kp = d.first ? k0p : (d.skip ? k0p + 256 : 256);
+        d.mlp_in = c.mlp_in; d.k0p = k0p; d.P_user = P_user; d.P_live = P_live;
+        for (int i = 0, j = 0; i < P_user && i < 64; ++i)
+            if (m->col_map.col[i] >= 0) d.live_cols[j++] = i;
+        if (!m->wsplit_t[l] || m->n_tiles_t[l] != d.nt) {
+            if (m->wsplit_t[l]) (void)hipFree(m->wsplit_t[l]);
+            free_dev(m->bias_t[l]);
+            m->wsplit_t[l] = nullptr;
+            HR_HIP(hipMalloc(&m->wsplit_t[l], sizeof(uint16_t) * (size_t)(d.Kp / 16) * d.nt * 2 * 64 * 8));
+            HR_HIP(hipMalloc((void**)&m->bias_t[l], sizeof(float) * (size_t)d.nt * 32));
+            m->n_tiles_t[l] = d.nt;
+        }
+        d.wsplit = m->wsplit_t[l]; d.bias = m->bias_t[l];
+        hr_launch_pack_split_bf16(d, st);
+    }
+    HrMlpTaps taps = {};
+    for (int l = 0; l + 1 < L; ++l) { taps.act[l] = acts_dev[l]; taps.ld[l] = act_ld[l]; taps.off[l] = act_off[l]; }
+    const int nq = (n_out + 3) / 4;
+    for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
+        const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
+        HrMlpArgs a = {};
+        a.rays = rays_dev + r0 * c.ray_dim;
+        a.n_rays = n;
+        a.head = m->head;
+        for (int l = 0; l < L; ++l) { a.wsplit[l] = m->wsplit_t[l]; a.bias[l] = m->bias_t[l]; a.winv[l] = 1.0f; a.n_tiles[l] = m->n_tiles_t[l]; }
+        a.n_out = n_out; a.nq = nq; a.k0p = k0p;
+        a.trace = nullptr; a.flags = nullptr;
+        HrMlpTaps tc = taps;
+        for (int l = 0; l + 1 < L; ++l)
+            if (tc.act[l]) tc.act[l] += r0 * tc.ld[l];
+        hr_launch_mlp_train_bf16x3(m->kcfg, a, tc, st);
+        hr_launch_head_export(m->head, head_dev + r0 * (int64_t)c.z_channels * P_user, n, c.z_channels, P_user, P_live, nq, 1, m->col_map, st);
+    }
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays, const float* head, int64_t n, int white_bg)
 {
     a = HrTrainArgs();
@@ -1498,6 +1561,7 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         if (need > m->grad_fx_elems) {
             HR_HIP(hipStreamSynchronize(st));
             if (m->grad_fx) (void)hipFree(m->grad_fx);
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) { if (m->wsplit_t[l]) (void)hipFree(m->wsplit_t[l]); free_dev(m->bias_t[l]); }
             m->grad_fx = nullptr; m->grad_fx_elems = 0;
             HR_HIP(hipMalloc((void**)&m->grad_fx, sizeof(long long) * need));
             m->grad_fx_elems = need;

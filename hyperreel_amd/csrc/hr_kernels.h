@@ -117,6 +117,29 @@ struct HrSampleArgs {
     int dbg_mode;           // measurement builds only (-DHR_TUNING, HR_SAMPLE_DBG): 1 = skip the feature gather
 };
 
+// training forward (mlp_split_impl.inc, HR_SPLIT_TRAIN_KERNEL): where the output of hidden Linear l (after its LeakyReLU) goes besides LDS --
+// act[l] + ray * ld[l] + off[l] + feature, fp32 (NULL: not kept)
+struct HrMlpTaps {
+    float* act[HR_MAX_LAYERS];
+    int64_t ld[HR_MAX_LAYERS];
+    int off[HR_MAX_LAYERS];
+};
+void hr_launch_mlp_train_bf16x3(const hr_config& cfg, const HrMlpArgs& args, const HrMlpTaps& taps, hipStream_t stream);
+// one layer's reference-layout weights (N_user, Kt) / bias (N_user) in device memory -> the split kernels' bf16 hi / lo tiles and padded
+// bias, on the device (what pack_mlp does on the host at finalize; the training step re-packs every step)
+struct HrPackDesc {
+    const float* w;
+    const float* b;
+    void* wsplit;
+    float* bias;
+    int N_user, Kt;         // the torch matrix
+    int N, nt, Kp;          // rows the kernel computes, their 32-row tiles, padded K
+    int first, skip, last;
+    int mlp_in, k0p;
+    int P_user, P_live;
+    int live_cols[64];      // last layer: live column c' of a sample -> the user's column
+};
+void hr_launch_pack_split_bf16(const HrPackDesc& d, hipStream_t stream);
 void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 // split-precision form: wsplit[L][(((kt * n_tiles[L] + nt) * 2 + part) * 64 + lane)] = 8 bf16 of
 //   W[n = 32*nt + (lane & 31)][k = 16*kt + 8*(lane >> 5) + 0..7], part 0 = hi (bf16(w)), 1 = lo (bf16(w - hi))

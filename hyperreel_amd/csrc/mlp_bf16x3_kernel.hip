@@ -4,4 +4,6 @@
 #define HR_SPLIT_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define HR_SPLIT_KERNEL hr_mlp_bf16x3_kernel
 #define HR_SPLIT_LAUNCH hr_launch_mlp_bf16x3
+#define HR_SPLIT_TRAIN_KERNEL hr_mlp_train_bf16x3_kernel      // + the training step's fused forward (bf16 halves: the fp32 exponent range, whatever the weights become)
+#define HR_SPLIT_TRAIN_LAUNCH hr_launch_mlp_train_bf16x3
 #include "mlp_split_impl.inc"

@@ -357,3 +357,47 @@ void hr_launch_fixed_to_float(const long long* src, float* dst, int64_t n, hipSt
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(hr_fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
 }
+
+
+// ---------------------------------------------------------------- device-side weight packing for the training step's fused MLP forward
+// Same layout and roundings as pack_mlp (api.hip) for the bf16 split: wsplit[(((kt * nt + t) * 2 + part) * 64 + lane) * 8 + j] =
+// W[n = 32 t + (lane & 31)][k = 16 kt + 8 (lane >> 5) + j], part 0 = bf16(w), part 1 = bf16(w - hi); K order: layer 0 the input features
+// padded to k0p, skip layers [input padded to k0p | hidden]; last layer: kernel row n = k * P_live + c' is the user's row
+// k * P_user + live_cols[c'] (BaseMLP's weights, nlf/nets/mlp.py:127-172, as torch stores them: (out, in)).
+__global__ __launch_bounds__(256) void hr_pack_split_bf16_kernel(const HrPackDesc d)
+{
+    const int64_t total = (int64_t)(d.Kp / 16) * d.nt * 64 * 8;
+    uint16_t* out = reinterpret_cast<uint16_t*>(d.wsplit);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t tt = i >> 9;
+        const int t = (int)(tt % d.nt), kt = (int)(tt / d.nt);
+        const int n = 32 * t + (lane & 31), kk = 16 * kt + 8 * (lane >> 5) + j;
+        int col = -1;
+        if (d.first) { if (kk < d.mlp_in) col = kk; }
+        else if (d.skip) { if (kk < d.k0p) { if (kk < d.mlp_in) col = kk; } else col = d.mlp_in + (kk - d.k0p); }
+        else col = kk;
+        float v = 0.0f;
+        if (n < d.N && col >= 0 && col < d.Kt) {
+            const int row = d.last ? (n / d.P_live) * d.P_user + d.live_cols[n % d.P_live] : n;
+            v = d.w[(int64_t)row * d.Kt + col];
+        }
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int64_t base = (((tt * 2) * 64 + lane) * 8) + j;
+        out[base] = __builtin_bit_cast(uint16_t, hi);
+        out[base + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < d.nt * 32; i += 256)
+            d.bias[i] = i < d.N ? d.b[d.last ? (i / d.P_live) * d.P_user + d.live_cols[i % d.P_live] : i] : 0.0f;
+}
+
+void hr_launch_pack_split_bf16(const HrPackDesc& d, hipStream_t stream)
+{
+    const int64_t total = (int64_t)(d.Kp / 16) * d.nt * 64 * 8;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(hr_pack_split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d);
+}

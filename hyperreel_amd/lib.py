@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 
@@ -60,6 +60,8 @@ SYMBOLS = [
     ('hr_pack_display', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ('hr_plane_reg_forward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ('hr_plane_reg_backward', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('hr_mlp_train_forward', C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     ('hr_linear_workspace', C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     ('hr_linear_forward', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                     C.c_int64, C.c_void_p]),

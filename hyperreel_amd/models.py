@@ -800,7 +800,13 @@ class HipLightfieldModel(nn.Module):
         if lvl0.mlp_layers == 0:                                # ZeroMLP, nlf/nets/mlp.py:14-33
             head = torch.zeros((rays.shape[0], lvl0.z_channels * lvl0.preds_per_z), dtype=torch.float32, device=rays.device)
         else:
-            head = T.mlp_forward(pred.net, T.ray_features(h, rays, lvl0.mlp_in), lvl0.mlp_skip_mask)
+            feats = T.ray_features(h, rays, lvl0.mlp_in)
+            if self._coarse_hc is None and lvl0.mlp_hidden == 256 and lvl0.mlp_layers >= 2 and not self.train_deterministic:
+                # one launch for the six layers (hr_mlp_train_forward: bf16 split arithmetic, head within 7e-6 of max |head|); the
+                # deterministic mode keeps the layer-by-layer GEMMs, whose forward carries 24 mantissa bits (HipLinear)
+                head = T.mlp_forward_fused(h, rays, feats, pred.net, lvl0.mlp_skip_mask, lvl0.z_channels * lvl0.preds_per_z)
+            else:
+                head = T.mlp_forward(pred.net, feats, lvl0.mlp_skip_mask)
         if self._coarse_hc is not None:                         # point_prediction cascade (point.py:137-203)
             rows = T.CoarseRows.apply(h, rays, head, lvl0.z_channels, hc.casc_row_dim)
             point = self.embedding_model.embeddings[types.index('point_prediction')]

@@ -194,6 +194,98 @@ class HipLinear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class HipMLP(torch.autograd.Function):
+    """BaseMLP.forward (nlf/nets/mlp.py:159-172) of the ray MLP as ONE launch (hr_mlp_train_forward: the render path's six-layer MFMA
+    kernel on the current parameter values, which also leaves every hidden layer's output in HBM), and its backward layer by layer on
+    the matrix cores (hr_linear_backward, as HipLinear).  Inputs: the model handle, rays, the MLP's input features (for layer 0's
+    weight gradient), the skip mask, then weight_0, bias_0, weight_1, ... as the reference names them."""
+
+    @staticmethod
+    def forward(ctx, handle, rays, feats, skip_mask, n_out, *params):
+        L = _lib.load()
+        dev = rays.device
+        nl = len(params) // 2
+        ws = [p.detach().contiguous().float() for p in params[0::2]]
+        bs = [p.detach().contiguous().float() for p in params[1::2]]
+        n, fin = rays.shape[0], feats.shape[1]
+        hidden = ws[0].shape[0]
+        # x[l]: the input of layer l.  x[0] = feats; x[l] = the output of layer l - 1, behind a copy of feats where layer l is a skip layer
+        xs = [feats]
+        acts, lds, offs = [], [], []
+        for l in range(1, nl):
+            skip = (skip_mask >> l) & 1
+            # a skip layer's input row is [feats | hidden]; two pad columns in FRONT of it keep the hidden part (what the kernels read
+            # and write in 16-byte pieces) on a 16-byte boundary
+            lead = (fin + ((-fin) % 4)) if skip else 0
+            buf = torch.empty((n, lead + hidden), dtype=torch.float32, device=dev)
+            x = buf[:, lead - fin:] if skip else buf
+            if skip:
+                x[:, :fin] = feats
+            xs.append(x)
+            acts.append(buf); lds.append(lead + hidden); offs.append(lead)
+        head = torch.empty((n, int(n_out)), dtype=torch.float32, device=dev)
+        PV = C.c_void_p * nl
+        wv, bv = PV(*[w.data_ptr() for w in ws]), PV(*[b.data_ptr() for b in bs])
+        av = PV(*([a.data_ptr() for a in acts] + [0]))
+        ldv = (C.c_int64 * nl)(*(lds + [0]))
+        offv = (C.c_int32 * nl)(*(offs + [0]))
+        with torch.cuda.device(dev):
+            _lib.check(L.hr_mlp_train_forward(handle, wv, bv, _ptr(rays), n, av, ldv, offv, _ptr(head), _stream(dev)), 'hr_mlp_train_forward')
+        ctx.skip_mask, ctx.nl, ctx.fin, ctx.hidden = int(skip_mask), nl, fin, hidden
+        ctx.save_for_backward(*xs, *ws)
+        return head
+
+    @staticmethod
+    def backward(ctx, dhead):
+        L = _lib.load()
+        nl, fin, hidden = ctx.nl, ctx.fin, ctx.hidden
+        xs, ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        dev = dhead.device
+        dy = dhead.contiguous().float()
+        dy_ptr, ld_dy = dy.data_ptr(), dy.shape[1]
+        grads = [None] * (2 * nl)
+        rows = xs[0].shape[0]
+        keep = []
+        with torch.cuda.device(dev):
+            for l in range(nl - 1, -1, -1):
+                x, w = xs[l], ws[l]
+                fout, fin_l = w.shape[0], w.shape[1]
+                last = (l == nl - 1)
+                # y of layer l (the LeakyReLU mask) = the hidden part of x[l + 1]
+                if last:
+                    y_ptr, ldy = 0, fout
+                else:
+                    nxt = xs[l + 1]
+                    y_ptr, ldy = nxt.data_ptr() + 4 * (nxt.shape[1] - hidden), nxt.stride(0)
+                dx = None
+                if l > 0:                               # same row shape as x[l]: the hidden columns of dx stay 16-byte aligned
+                    lead = x.stride(0) - hidden
+                    dxb = torch.empty((rows, lead + hidden), dtype=torch.float32, device=dev)
+                    dx = dxb[:, lead + hidden - fin_l:]
+                dw = torch.empty_like(w)
+                db = torch.empty((fout,), dtype=torch.float32, device=dev)
+                wsb = torch.empty((max(int(L.hr_linear_workspace(rows, fin_l, fout)) // 4, 1),), dtype=torch.float32, device=dev)
+                _lib.check(L.hr_linear_backward(_ptr(x), x.stride(0), _ptr(w), C.c_void_p(y_ptr), ldy, C.c_void_p(dy_ptr), ld_dy, rows, fin_l, fout,
+                                                -1.0 if last else 0.01, _ptr(dx) if dx is not None else C.c_void_p(0),
+                                                dx.stride(0) if dx is not None else fin_l, _ptr(dw), _ptr(db), _ptr(wsb), _stream(dev)),
+                           'hr_linear_backward')
+                grads[2 * l], grads[2 * l + 1] = dw, db
+                keep.append((dx, wsb))
+                if dx is not None:                      # upstream of layer l - 1: the hidden columns of dx (a skip layer's first fin columns belong to the input)
+                    dy_ptr, ld_dy = dx.data_ptr() + 4 * (fin_l - hidden), dx.stride(0)
+        return (None, None, None, None, None, *grads)
+
+
+def mlp_forward_fused(handle, rays, feats, net, skip_mask, n_out):
+    """mlp_forward below through HipMLP: one forward launch.  The caller checks that the model qualifies (hidden width 256, no cascade)."""
+    n = len(net.layers)
+    params = []
+    for i, layer in enumerate(net.layers):
+        lin = layer[0] if i < n - 1 else layer
+        params += [lin.weight, lin.bias]
+    return HipMLP.apply(handle, rays, feats, int(skip_mask), int(n_out), *params)
+
+
 def mlp_forward(net, x, skip_mask):
     """BaseMLP.forward (nlf/nets/mlp.py:159-172) on the reference-named parameters: Linear + LeakyReLU(0.01), the
     input concatenated in front of the activations at the skip layers, no activation after the last Linear."""

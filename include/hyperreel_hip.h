@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 22
+#define HR_ABI_VERSION 23
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -417,6 +417,17 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
  *              db (out) = column sums of dy'.  The batch dimension of dw / db is reduced in a fixed order (no atomics).
  *              workspace_dev: hr_linear_workspace(rows, in, out) bytes. */
 size_t hr_linear_workspace(int64_t rows, int32_t in, int32_t out);
+/* The ray MLP's FORWARD of a training step in ONE launch (BaseMLP.forward, nlf/nets/mlp.py:159-172, as INRSystem.training_step runs it,
+ * nlf/__init__.py:658-690): weights_dev[l] / biases_dev[l] are the CURRENT values of the reference's parameters (torch layout (out, in) /
+ * (out), device memory) -- the library splits them into bf16 hi / lo tiles on the device first (three v_mfma_f32_32x32x16_bf16 products
+ * per fp32 GEMM, fp32 accumulation: head within 7e-6 of max |head| of the fp32 chain; bf16 halves keep the fp32 exponent range
+ * whatever the weights become).  rays_dev (n, ray_dim) -> head_dev (n, Z * P) in the caller's column order (columns no stage reads: 0),
+ * and the output of hidden Linear l after its LeakyReLU -> acts_dev[l] + ray * act_ld[l] + act_off[l] + feature, fp32 (l < layers - 1;
+ * NULL: not kept): what hr_linear_backward needs as `x` of layer l + 1 and `y` of layer l (a skip layer's input starts at column mlp_in
+ * of a wider row).  Hidden width 256, no cascades; the activation / encoding schedules are those of the last hr_model_update_config. */
+int hr_mlp_train_forward(hr_model* m, const float* const* weights_dev, const float* const* biases_dev, const float* rays_dev, int64_t n_rays,
+                         float* const* acts_dev, const int64_t* act_ld, const int32_t* act_off, float* head_dev, void* stream);
+
 int hr_linear_forward(const float* x_dev, int64_t ldx, int64_t rows, int32_t in, const float* w_dev, const float* b_dev, int32_t out,
                       float leaky_slope, float* y_dev, int64_t ldy, void* stream);
 int hr_linear_backward(const float* x_dev, int64_t ldx, const float* w_dev, const float* y_dev, int64_t ldy, const float* dy_dev, int64_t ld_dy,

@@ -429,3 +429,41 @@ def test_deterministic_gradients_equal_the_default_ones_to_rounding(case):
             continue
         scale = max(float(np.abs(f[n]).max()), 1e-30)
         assert float(np.abs(d0[n] - f[n]).max()) <= 1e-5 * scale, (n, float(np.abs(d0[n] - f[n]).max()), scale)
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small'])
+def test_fused_mlp_forward_matches_the_layer_by_layer_one(case):
+    """hr_mlp_train_forward (one launch: the render path's six-layer MFMA kernel on the current parameter values, bf16 split, every
+    hidden layer's output kept for the backward) against the layer-by-layer HipLinear path (24-bit forward GEMMs): head within 2e-5
+    of max |head|, every MLP gradient within 1e-3 of its largest entry (BaseMLP.forward, nlf/nets/mlp.py:159-172)"""
+    from gpu_common import make_render_fn
+    from hyperreel_amd import train as T
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    fn.train()
+    m = fn.model
+    rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([g.rays] * 3, 0), np.float32)).cuda()
+    h = m.native()
+    hc = m._hc
+    pred = m.embedding_model.embeddings[0]
+    feats = T.ray_features(h, rays, hc.mlp_in)
+    G = torch.from_numpy(np.random.default_rng(5).standard_normal((rays.shape[0], hc.z_channels * hc.preds_per_z)).astype(np.float32)).cuda()
+    params = [p for p in pred.net.parameters()]
+
+    def run(fused):
+        for p in params:
+            p.grad = None
+        head = T.mlp_forward_fused(h, rays, feats, pred.net, hc.mlp_skip_mask, hc.z_channels * hc.preds_per_z) if fused else \
+            T.mlp_forward(pred.net, feats, hc.mlp_skip_mask)
+        (head * G).sum().backward()
+        torch.cuda.synchronize()
+        return head.detach().cpu().numpy(), [p.grad.detach().cpu().numpy().copy() for p in params]
+    h0, g0 = run(False)
+    h1, g1 = run(True)
+    live = np.abs(h1).max(0) > 0                       # columns no stage reads are not computed by the fused kernel (exported as 0)
+    assert live.sum() >= 0.5 * live.size
+    assert np.abs(h1[:, live] - h0[:, live]).max() <= 2e-5 * np.abs(h0).max()
+    # (the backward is the same layer-by-layer code in both: dW = dy^T x, dx = dy W -- only the activations it reads differ, by ~1e-5)
+    for a, b in zip(g0, g1):
+        scale = max(float(np.abs(a).max()), 1e-30)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3 * scale, (a.shape, float(np.abs(a - b).max()), scale)
