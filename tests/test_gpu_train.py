@@ -431,11 +431,15 @@ def test_deterministic_gradients_equal_the_default_ones_to_rounding(case):
         assert float(np.abs(d0[n] - f[n]).max()) <= 1e-5 * scale, (n, float(np.abs(d0[n] - f[n]).max()), scale)
 
 
-@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small'])
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small'])
 def test_fused_mlp_forward_matches_the_layer_by_layer_one(case):
-    """hr_mlp_train_forward (one launch: the render path's six-layer MFMA kernel on the current parameter values, bf16 split, every
-    hidden layer's output kept for the backward) against the layer-by-layer HipLinear path (24-bit forward GEMMs): head within 2e-5
-    of max |head|, every MLP gradient within 1e-3 of its largest entry (BaseMLP.forward, nlf/nets/mlp.py:159-172)"""
+    """hr_mlp_train_forward (opt-in `train_fused_mlp`: one launch, the render path's six-layer MFMA kernel on the current parameter
+    values -- split into bf16 halves on the device --, every hidden layer's output kept for the backward) against the layer-by-layer
+    HipLinear path (24-bit forward GEMMs; BaseMLP.forward, nlf/nets/mlp.py:159-172): head within 2e-5 of max |head|, every kept
+    activation within 3e-5 of its layer's largest.  The GRADIENTS agree to 1e-3 of a tensor's largest entry when no pre-activation
+    changed sign between the two forwards, and to a few per cent otherwise: an activation within 7e-6 of zero takes the other branch
+    of the LeakyReLU (one such entry moves a bias gradient summed over a few hundred rays by ~1 / sqrt(rays)) -- which is why the
+    fused forward is not the default (the reference-autograd goldens hold the default path to 1e-3)."""
     from gpu_common import make_render_fn
     from hyperreel_amd import train as T
     g = Golden(case)
@@ -449,12 +453,17 @@ def test_fused_mlp_forward_matches_the_layer_by_layer_one(case):
     feats = T.ray_features(h, rays, hc.mlp_in)
     G = torch.from_numpy(np.random.default_rng(5).standard_normal((rays.shape[0], hc.z_channels * hc.preds_per_z)).astype(np.float32)).cuda()
     params = [p for p in pred.net.parameters()]
+    kept = {}
 
     def run(fused):
         for p in params:
             p.grad = None
         head = T.mlp_forward_fused(h, rays, feats, pred.net, hc.mlp_skip_mask, hc.z_channels * hc.preds_per_z) if fused else \
             T.mlp_forward(pred.net, feats, hc.mlp_skip_mask)
+        # the hidden activations the backward will read: saved tensors of the graph (fused: HipMLP's x[1..]; layered: each HipLinear's y)
+        node = head.grad_fn
+        if fused:
+            kept[fused] = [t[:, -256:].detach().clone() for t in node.saved_tensors[1:len(params) // 2]]
         (head * G).sum().backward()
         torch.cuda.synchronize()
         return head.detach().cpu().numpy(), [p.grad.detach().cpu().numpy().copy() for p in params]
@@ -463,7 +472,19 @@ def test_fused_mlp_forward_matches_the_layer_by_layer_one(case):
     live = np.abs(h1).max(0) > 0                       # columns no stage reads are not computed by the fused kernel (exported as 0)
     assert live.sum() >= 0.5 * live.size
     assert np.abs(h1[:, live] - h0[:, live]).max() <= 2e-5 * np.abs(h0).max()
-    # (the backward is the same layer-by-layer code in both: dW = dy^T x, dx = dy W -- only the activations it reads differ, by ~1e-5)
+    # the kept activations against the layer-by-layer ones, and the entries whose sign differs
+    x = feats
+    flips = 0
+    n = len(pred.net.layers)
+    with torch.no_grad():
+        for i, layer in enumerate(pred.net.layers[:-1]):
+            if (hc.mlp_skip_mask >> i) & 1:
+                x = torch.cat([feats, x], -1)
+            x = T.HipLinear.apply(x, layer[0].weight, layer[0].bias, 0.01)
+            a = kept[True][i]
+            assert float((a - x).abs().max()) <= 3e-5 * float(x.abs().max()), i
+            flips += int(((a > 0) != (x > 0)).sum())
+    tol = 1e-3 if flips == 0 else 1e-1
     for a, b in zip(g0, g1):
         scale = max(float(np.abs(a).max()), 1e-30)
-        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3 * scale, (a.shape, float(np.abs(a - b).max()), scale)
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * scale, (a.shape, float(np.abs(a - b).max()), scale, flips)
