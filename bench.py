@@ -18,7 +18,7 @@ The JSON line also carries
   roofline        the dominant kernel of the step, its launches timed live with HIP events on the launch stream, against the
                   MI355X peak that bounds it (MI355X_MICROARCH.md: 2500 TFLOP/s dense bf16/fp16 MFMA);
   roofline_other  the other kernel: vector-ALU issue (wave-instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles);
-                  the instruction count per launch comes from the committed PMC pass (profiles/r03_counters.json);
+                  the instruction count per launch comes from the committed PMC pass (the committed PMC pass);
   frame_kernel    the same frame through the single persistent frame kernel (head tile handed over in LDS);
   value_fp32_exact  the same frame with the exact fp32-MFMA MLP;
   value_f16x2     the same frame with the opt-in two-product MLP arithmetic, and its own parity against the oracle;
@@ -61,6 +61,27 @@ def algorithmic_bytes_per_ray(cfg, video, texel_bytes=4):
         na = [a if d > 0 else 0 for a, d in zip(na, nd)]
     G = (sum(nd) + sum(na)) * T * texel_bytes          # 'fp16 grids: halve the G terms' 
     return 4 * (8 if video else 6) + 12 + Z * G
+
+
+def load_counters(suffix, matches):
+    """The newest committed PMC counter file profiles/r0N_counters<suffix>.json whose workload matches -> (dict, 'fresh' | 'stale' |
+    'none').  'fresh': collected from THIS tree's kernels (the file's csrc_hash equals hyperreel_amd.build.csrc_hash()); 'stale':
+    another tree's -- the caller prints that and does not quote the numbers."""
+    import glob
+    from hyperreel_amd.build import csrc_hash
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r0?_counters{suffix}.json')), reverse=True)
+    state = 'none'
+    for f in files:
+        try:
+            tr = json.load(open(f))
+            if not matches(tr['workload']):
+                continue
+        except (OSError, KeyError, ValueError):
+            continue
+        if tr.get('csrc_hash') == csrc_hash():
+            return tr, 'fresh', os.path.relpath(f, ROOT)
+        state = 'stale'
+    return None, state, None
 
 
 def mlp_flops_per_ray(cfg):
@@ -372,6 +393,10 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rays / (dt / args.steps) / 1e6
+    # the fp16 split arithmetic was chosen on calibration rays: the kernels' sticky overflow bit must be clear on the rays that were timed
+    # (render() checks it on the first batches and falls back to bf16x3, models.py _overflow_guard; a replayed graph cannot)
+    if model.mlp_overflowed():
+        raise SystemExit('bench: an MLP activation left the IEEE-half range on the benchmark rays (HR_OPT_MLP_OVERFLOW): the figure would be invalid')
     prec_name = model.mlp_precision_active()      # 'auto' resolved by the library's activation-range calibration (hr_model_finalize)
     result = {
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
@@ -438,34 +463,30 @@ def main():
                  'algorithmic_gather_GBs': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
                  'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays (L2 / Infinity-Cache resident: not an HBM figure)',
                  'note': 'the sample stage is bound by vector-ALU issue, not by bytes: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, '
-                         'profiles/r03_counters.json) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue '
+                         'the committed PMC pass) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue '
                          'rate for plain fp32 instructions; the stage\'s mix of DPP, packed and transcendental instructions issues slower: '
                          'profiles/r03_valu_ilp_ubench.txt)'}
         # counters measured separately with rocprofv3 --pmc (never inside a timed run) and committed under profiles/;
         # attached only when the workload matches the profiled one
-        try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r03_counters.json')))
-            w = tr['workload']
-            if (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
-                    and w['mlp_precision'] == prec_name and w['grid_dtype'] == args.grid_dtype):
-                for r in (r_mlp, r_smp):
-                    k = tr.get(r['kernel'])
-                    if not k:
-                        continue
-                    r['traffic'] = k.get('traffic_bytes')
-                    r['traffic_unit'] = 'HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r03_counters.json)'
-                    if 'limiter' in k:
-                        r['limiter'] = k['limiter']
-                    if 'mfma_busy_frac' in k:
-                        r['mfma_busy_frac'] = k['mfma_busy_frac']
-                k = tr.get('hr_sample_kernel')
-                if k and 'valu_insts' in k:
-                    ginst = k['valu_insts'] / (smp_ms[0] / nl * 1e-3) / 1e9
-                    r_smp['achieved'] = round(ginst, 1)
-                    r_smp['frac'] = round(ginst / VALU_PEAK_GINST, 4)
-                    r_smp['valu_insts_per_sample_slot'] = k.get('valu_insts_per_wave')
-        except (OSError, KeyError, ValueError):
-            pass
+        tr, state, src = load_counters('', lambda w: (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
+                                                      and w['mlp_precision'] == prec_name and w['grid_dtype'] == args.grid_dtype))
+        result['counters'] = {'two_kernels': state}
+        if tr:
+            for r in (r_mlp, r_smp):
+                k = tr.get(r['kernel'])
+                if not k:
+                    continue
+                r['traffic'] = k.get('traffic_bytes')
+                r['traffic_unit'] = f'HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, {src})'
+                for key in ('limiter', 'mfma_busy_frac', 'lds_conflict_frac', 'l2_hit_rate'):
+                    if key in k:
+                        r[key] = k[key]
+            k = tr.get('hr_sample_kernel')
+            if k and 'valu_insts' in k:
+                ginst = k['valu_insts'] / (smp_ms[0] / nl * 1e-3) / 1e9
+                r_smp['achieved'] = round(ginst, 1)
+                r_smp['frac'] = round(ginst / VALU_PEAK_GINST, 4)
+                r_smp['valu_insts_per_sample_slot'] = k.get('valu_insts_per_wave')
         result['stage_ms'] = {'mlp': round(mlp_ms[0], 4), 'samples': round(smp_ms[0], 4)}
         if model.frame_kernel_active() and not strong:
             # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
@@ -484,19 +505,17 @@ def main():
                             '2.44 GHz with zero operands (profiles/r02_e_mfma_pipe_ubench.txt).  See valu_busy_frac / mfma_busy_frac',
                     'sustained_mfma_tflops': 1850.0,
                     'frac_of_sustained_issued': round(n_prod * flops / (fr_ms[0] * 1e-3) / 1e12 / 1850.0, 4)}
-            try:
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r03_counters_frame_kernel.json')))
-                w = tr['workload']
-                if (w['model'] == args.model and w['rays_per_launch'] == B and w['grid'] == grid and w['mlp_precision'] == prec_name
-                        and w['grid_dtype'] == args.grid_dtype and fk in tr):
-                    k = tr[fk]
-                    r_fr['traffic'] = k.get('traffic_bytes')
-                    r_fr['traffic_unit'] = 'HBM-side bytes per launch = per frame (FETCH_SIZE + WRITE_SIZE, profiles/r03_counters_frame_kernel.json)'
-                    for key in ('valu_busy_frac', 'mfma_busy_frac', 'ta_busy_frac', 'limiter'):
-                        if key in k:
-                            r_fr[key] = k[key]
-            except (OSError, KeyError, ValueError):
-                pass
+            r_fr['frac_of_step'] = round(flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)       # the same FLOPs over the timed step (graph replay), not the event-timed launch
+            tr, state, src = load_counters('_frame_kernel', lambda w: (w['model'] == args.model and w['rays_per_launch'] == B and w['grid'] == grid
+                                                                      and w['mlp_precision'] == prec_name and w['grid_dtype'] == args.grid_dtype))
+            result['counters']['frame_kernel'] = state
+            if tr and fk in tr:
+                k = tr[fk]
+                r_fr['traffic'] = k.get('traffic_bytes')
+                r_fr['traffic_unit'] = f'HBM-side bytes per launch = per frame (FETCH_SIZE + WRITE_SIZE, {src})'
+                for key in ('valu_busy_frac', 'mfma_busy_frac', 'ta_busy_frac', 'lds_conflict_frac', 'limiter'):
+                    if key in k:
+                        r_fr[key] = k[key]
             result['roofline'] = r_fr
             result['roofline_other'] = {'what': 'the two kernels of the other execution plan (two_kernel_path), timed through hr_stage_*', 'mlp': r_mlp, 'samples': r_smp}
         else:

@@ -31,6 +31,22 @@ if os.environ.get('HR_FAST_MATH', '0') == '1':       # measurements only: all th
     FLAGS.append('-DHR_FAST_MATH')
 
 
+def csrc_hash():
+    """sha256 over the names and bytes of everything the library is built from (csrc/, the public header, the flags): the identity of
+    the kernels.  tools/make_counters.py stamps it into the PMC counter files and bench.py attaches counters to its line only when it
+    equals the running tree's -- counters of another tree are reported as "stale", not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC)) + [os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
+    for f in files:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(os.path.basename(f).encode() + b'\0')
+            h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

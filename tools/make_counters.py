@@ -2,6 +2,7 @@
 python tools/make_counters.py <tag> <out.json> <model> <mlp_precision> <grid_dtype> <rays_per_launch> <gx> <gy> <gz>"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 tag, out, model, prec, gdt, rpl = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6])
 grid = [int(v) for v in sys.argv[7:10]]
 vals = {}
@@ -21,7 +22,8 @@ res = {'_about': 'per-launch PMC counters of the render kernels (tools/pmc.sh: s
                  'profiles/r03_*_pmc_pass*.txt).  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KB, and FETCH_SIZE under-counts '
                  'wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated; Infinity-Cache hits are included in '
                  'these fabric-side counters.  SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE cycles.',
-       'workload': {'model': model, 'rays_per_launch': rpl, 'grid': grid, 'mlp_precision': prec, 'grid_dtype': gdt}}
+       'workload': {'model': model, 'rays_per_launch': rpl, 'grid': grid, 'mlp_precision': prec, 'grid_dtype': gdt},
+       'csrc_hash': __import__('hyperreel_amd.build', fromlist=['csrc_hash']).csrc_hash()}
 for k, v in vals.items():
     if not k.startswith(('hr_mlp', 'hr_sample', 'hr_frame')):
         continue

@@ -122,12 +122,29 @@ def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_
 
     ms_mlp_hip = timed(mlp_hip, args.steps)
     ms_mlp_blas = timed(mlp_blas, args.steps) if blas else float('nan')
+    # the opt-in forms of the step: the MLP's forward as one launch (train_fused_mlp), and the deterministic mode (64-bit fixed-point sums)
+    from hyperreel_amd.train import mlp_forward_fused
+
+    def mlp_fused():
+        for p in params:
+            p.grad = None
+        mlp_forward_fused(h, rays, feats, pred.net, hc.mlp_skip_mask, hc.z_channels * hc.preds_per_z).backward(d_head)
+
+    ms_mlp_fused = timed(mlp_fused, args.steps) if (hc.mlp_hidden == 256 and not model._coarse_hc) else float('nan')
+    model.train_fused_mlp = True
+    ms_step_fused = timed(step, args.steps)
+    model.train_fused_mlp = False
+    model.set_train_deterministic(True)
+    ms_step_det = timed(step, args.steps)
+    model.set_train_deterministic(False)
     out = {'workload': f'{args.model}: training step, batch {args.batch} rays x {hc.z_channels} samples, grid {grid[0]}x{grid[1]}x{grid[2]}',
            'hip_ms_per_step': round(ms_step, 3), 'hip_ms_forward_backward': round(ms_fwd_bwd, 3),
            'hip_ms_sample_stage_forward': round(ms_stage_fwd, 3),
            'hip_ms_sample_stage_backward': round(ms_stage_both - ms_stage_fwd, 3),
            'hip_ms_mlp_forward_backward': round(ms_mlp_hip, 3), 'rocblas_ms_mlp_forward_backward': round(ms_mlp_blas, 3),
-           'hip_krays_per_s': round(args.batch / ms_step, 1)}
+           'hip_krays_per_s': round(args.batch / ms_step, 1),
+           'opt_in': {'fused_mlp_forward_ms_per_step': round(ms_step_fused, 3), 'fused_mlp_forward_backward_ms': round(ms_mlp_fused, 3),
+                      'deterministic_ms_per_step': round(ms_step_det, 3)}}
 
     if args.torch_gpu:
         from torch_port import TorchPort
