@@ -1438,6 +1438,7 @@ int hr_mlp_train_forward(hr_model* m, const float* const* weights_dev, const flo
 
 static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays, const float* head, int64_t n, int white_bg)
 {
+    a.f_dist = a.f_points = a.f_weights = nullptr;
     a = HrTrainArgs();
     a.cfg_dev = m->ucfg_dev;
     a.rays = rays;
@@ -1455,8 +1456,25 @@ static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays
     }
 }
 
+static int train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                         int32_t white_bg, float* rgb_dev, const hr_fields* fields, void* stream);
+
 int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
                      int32_t white_bg, float* rgb_dev, void* stream)
+{
+    return train_forward(m, params, rays_dev, head_dev, n_rays, white_bg, rgb_dev, nullptr, stream);
+}
+
+int hr_train_forward_fields(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                            int32_t white_bg, float* rgb_dev, const hr_fields* fields, void* stream)
+{
+    if (fields && (fields->sigma_dev || fields->head_dev)) return fail(HR_E_INVALID, "hr_train_forward_fields serves distances, points and weights");
+    if (fields && m && m->cfg.z_channels > 64) return fail(HR_E_INVALID, "hr_train_forward_fields: rays of more than 64 samples take the one-thread-per-ray walk, which keeps no fields");
+    return train_forward(m, params, rays_dev, head_dev, n_rays, white_bg, rgb_dev, fields, stream);
+}
+
+static int train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                         int32_t white_bg, float* rgb_dev, const hr_fields* fields, void* stream)
 {
     int rc = check_train(m, rays_dev, n_rays);
     if (rc != HR_OK) return rc;
@@ -1494,6 +1512,7 @@ int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* r
     HrTrainArgs a;
     fill_train_args(m, a, rays_dev, head_dev, n_rays, white_bg);
     a.rgb = rgb_dev;
+    if (fields) { a.f_dist = fields->distances_dev; a.f_points = fields->points_dev; a.f_weights = fields->weights_dev; }
     hr_launch_train(m->cfg, a, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -120,6 +120,11 @@ struct HrTrainArgs {
     const float* color_table;   // (color_table_views, 12) per-camera [3x3 | shift] (ColorTransformEmbedding) or NULL
     hr_acc_t* d_color_table;    // accumulated
     HrTrainTape tape;
+    // optional per-sample outputs of the forward, by sorted rank like hr_fields of the render path (NULL: not wanted): what a
+    // field-consuming regulariser of the training loop reads (nlf/__init__.py:658-690) without a second, inference pass
+    float* f_dist;              // (n, Z) final (contracted) distances
+    float* f_points;            // (n, Z, 3)
+    float* f_weights;           // (n, Z) render weights
 };
 
 // d/dx of hr_apply_act

@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
     float T = __shfl_up(prod, 1, 64);
     if (k == 0) T = 1.0f;
     const float wgt = lane_ok ? alpha * T : 0.0f;
+    if (lane_ok) {                                 // optional diagnostics / regulariser inputs, same definitions as the render path's hr_fields
+        const int64_t s = ray * Z + k;
+        if (a.f_dist) a.f_dist[s] = dist_c;
+        if (a.f_points) { a.f_points[3 * s] = p[0]; a.f_points[3 * s + 1] = p[1]; a.f_points[3 * s + 2] = p[2]; }
+        if (a.f_weights) a.f_weights[s] = wgt;
+    }
     const bool app = lane_ok && (wgt > c.weight_thresh);
     const float pre[3] = {pre0, pre1, pre2};
     float raw[3] = {0.f, 0.f, 0.f}, sc[3] = {1.f, 1.f, 1.f}, rr[3] = {0.f, 0.f, 0.f};

@@ -53,6 +53,8 @@ SYMBOLS = [
     ('hr_train_rows_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('hr_train_forward', C.c_int, [C.c_void_p, C.POINTER(hr_train_tensors), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
+    ('hr_train_forward_fields', C.c_int, [C.c_void_p, C.POINTER(hr_train_tensors), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                          C.POINTER(hr_fields), C.c_void_p]),
     ('hr_train_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                     C.POINTER(hr_train_tensors), C.c_void_p]),
     ('hr_dense_alpha', C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),

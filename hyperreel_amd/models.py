@@ -779,11 +779,12 @@ class HipLightfieldModel(nn.Module):
                                                    C.c_void_p(torch.cuda.current_stream(rgb.device).cuda_stream)), 'hr_pack_display')
         return out
 
-    def forward_train(self, rays, white_bg=None):
+    def forward_train(self, rays, white_bg=None, want_fields=False):
         """One differentiable forward of the training step (nlf/__init__.py:634-709 calls `self(coords)` in train mode):
         rgb (B, 3) WITHOUT the eval-mode clamp, with autograd history to the MLP, the planes / lines and basis_mat.
         white_bg: this step's background; default = the reference's draw `white_bg or rand() < 0.5` unless black_bg
-        (tensorf_no_sample.py:236).  The activation schedules are the converged ones (see set_iter)."""
+        (tensorf_no_sample.py:236).  The activation schedules are the converged ones (see set_iter).
+        want_fields: also return {'distances', 'points', 'render_weights', 'head'} of THIS forward (detached; hr_train_forward_fields)."""
         from . import train as T
         box = self.color_model.net.aabb
         if self._native is None or self._native_grid != self.grid_size or self._native_box != (box.data_ptr(), box._version):
@@ -818,7 +819,14 @@ class HipLightfieldModel(nn.Module):
         extra = ()
         if hc.color_table_views > 0:                            # ColorTransformEmbedding's table (point.py:558-602)
             extra = (self.embedding_model.embeddings[types.index('color_transform')].color_embedding,)
-        return T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm), *extra)
+        if want_fields:
+            T.SampleStage.want_fields = hc.z_channels
+        rgb = T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm), *extra)
+        if want_fields:
+            f, T.SampleStage.fields_out = T.SampleStage.fields_out, None
+            f['head'] = head.detach()
+            return rgb, f
+        return rgb
 
     def forward(self, rays, render_kwargs=None):
         """LightfieldModel.forward (models.py:135-138).  In train mode with autograd enabled this is the
@@ -829,6 +837,23 @@ class HipLightfieldModel(nn.Module):
             return {'rgb': self.forward_train(rays)}
         if not fields:
             return {'rgb': self.render(rays)['rgb']}
+        if self.training and torch.is_grad_enabled() and self._hc.z_channels <= 64:
+            # INRSystem.training_step passes the regularizers' field list on the main forward (nlf/__init__.py:658-690): the colour
+            # stays differentiable (training arithmetic: no eval-mode clamp, the per-step background draw) and the requested fields are
+            # the per-sample values of the SAME forward pass (hr_train_forward_fields), detached -- no second, inference pass and no
+            # re-upload of the weights.  A regulariser that needs d(field)/d(parameters) is outside the training path (SURVEY 8f-4
+            # covers the colour loss and the plane regularisers).
+            rgb, r = self.forward_train(rays, want_fields=True)
+            r['rgb'] = rgb.detach()
+            out = {k: v.detach() for k, v in self._forward_fields(rays, render_kwargs, r).items()}
+            if not getattr(self, '_warned_detached_fields', False):
+                import warnings
+                self._warned_detached_fields = True
+                warnings.warn('HipLightfieldModel.forward in train mode: the fields ' + ', '.join(sorted(k for k in out if k != 'rgb')) +
+                              ' are DETACHED values of the training forward -- a regulariser that needs their gradient contributes none '
+                              '(differentiable: rgb, and the plane regularisers of hyperreel_amd.train)', RuntimeWarning, stacklevel=2)
+            out['rgb'] = rgb
+            return out
         out = self._forward_fields(rays, render_kwargs)
         if self.training and torch.is_grad_enabled():
             # INRSystem.training_step passes the regularizers' field list on the main forward (nlf/__init__.py:634-709):
@@ -870,7 +895,9 @@ class HipLightfieldModel(nn.Module):
     def embed(self, rays, render_kwargs=None):
         """LightfieldModel.embed (models.py:131-133): the flattened fields handed to the
         colour net (extract_fields lists of the YAMLs).  Diagnostics path."""
-        r = self.render(rays, want=('distances', 'points', 'head'))
+        return self._embed_from(rays, self.render(rays, want=('distances', 'points', 'head')))
+
+    def _embed_from(self, rays, r):
         rays = self._check_rays(rays)
         B, Z = rays.shape[0], self._hc.z_channels
         x = {'points': r['points'].reshape(B, -1), 'distances': r['distances'],
@@ -886,14 +913,16 @@ class HipLightfieldModel(nn.Module):
             x['times'] = t.expand(B, Z).contiguous()
         return x
 
-    def _forward_fields(self, rays, render_kwargs):
-        """render_kwargs `fields` / `no_over_fields` (tensorf_no_sample.py:254-278)."""
+    def _forward_fields(self, rays, render_kwargs, r=None):
+        """render_kwargs `fields` / `no_over_fields` (tensorf_no_sample.py:254-278).  r: per-sample values already at hand (the training
+        forward's own); default: one pass of the inference kernels."""
         fields = list(render_kwargs.get('fields', []))
         no_over = list(render_kwargs.get('no_over_fields', []))
         if render_kwargs.get('pred_weights_fields'):
             raise NotImplementedError('pred_weights_fields')
-        r = self.render(rays, want=('distances', 'points', 'render_weights', 'head'))
-        x = self.embed(rays)
+        if r is None:
+            r = self.render(rays, want=('distances', 'points', 'render_weights', 'head'))
+        x = self._embed_from(rays, r)
         B, Z = r['render_weights'].shape
         out = {'rgb': r['rgb']}
         w = r['render_weights']

@@ -46,6 +46,8 @@ class SampleStage(torch.autograd.Function):
     app a[0..2], app b[0..2] (a = plane | plane_space, b = line | plane_time), then -- only for models with a per-camera
     colour table (ColorTransformEmbedding, read with dataset.val_all) -- its `color_embedding`."""
 
+    fields_out = None      # set by forward() when `want_fields` was given: {'distances', 'points', 'render_weights'} of that call, detached
+
     @staticmethod
     def forward(ctx, handle, rays, head, white_bg, basis, *tensors):
         grids, table = tensors[:12], (tensors[12] if len(tensors) > 12 else None)
@@ -58,13 +60,30 @@ class SampleStage(torch.autograd.Function):
         groups = [vals[0:3], vals[3:6], vals[6:9], vals[9:12]]
         params = _tensors_struct(groups, basis.detach().contiguous(), None if table is None else table.detach().contiguous())
         rgb = torch.empty((rays.shape[0], 3), dtype=torch.float32, device=dev)
+        want = SampleStage.want_fields
+        SampleStage.want_fields = None
         with torch.cuda.device(dev):
-            _lib.check(L.hr_train_forward(handle, C.byref(params), _ptr(rays), _ptr(head), rays.shape[0], int(bool(white_bg)), _ptr(rgb),
-                                          _stream(dev)), 'hr_train_forward')
+            if want:
+                # the forward's own per-sample values (hr_train_forward_fields): what a field-consuming regulariser reads, without a
+                # second pass through the inference kernels
+                from .plan import hr_fields
+                B, Z = rays.shape[0], int(want)
+                f = hr_fields()
+                out = {'distances': torch.zeros((B, Z), dtype=torch.float32, device=dev), 'points': torch.zeros((B, Z, 3), dtype=torch.float32, device=dev),
+                       'render_weights': torch.zeros((B, Z), dtype=torch.float32, device=dev)}
+                f.distances_dev, f.points_dev, f.weights_dev = out['distances'].data_ptr(), out['points'].data_ptr(), out['render_weights'].data_ptr()
+                _lib.check(L.hr_train_forward_fields(handle, C.byref(params), _ptr(rays), _ptr(head), B, int(bool(white_bg)), _ptr(rgb), C.byref(f),
+                                                     _stream(dev)), 'hr_train_forward_fields')
+                SampleStage.fields_out = out
+            else:
+                _lib.check(L.hr_train_forward(handle, C.byref(params), _ptr(rays), _ptr(head), rays.shape[0], int(bool(white_bg)), _ptr(rgb),
+                                              _stream(dev)), 'hr_train_forward')
         ctx.handle, ctx.white_bg = handle, int(bool(white_bg))
         ctx.has_table = table is not None
         ctx.save_for_backward(rays, head, basis, *tensors)
         return rgb
+
+    want_fields = None     # set to z_channels right before apply() to make that call produce fields_out (single-threaded host code)
 
     @staticmethod
     def backward(ctx, d_rgb):

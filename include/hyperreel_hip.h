@@ -397,6 +397,12 @@ int hr_train_features(hr_model* m, const float* rays_dev, int64_t n_rays, float*
  * (`white_bg or (training and rand() < 0.5)`, tensorf_no_sample.py:236). */
 int hr_train_forward(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
                      int32_t white_bg, float* rgb_dev, void* stream);
+/* hr_train_forward that also writes per-sample values of ITS OWN forward -- fields->distances_dev (n, Z), points_dev (n, Z, 3),
+ * weights_dev (n, Z), by sorted rank, the definitions of hr_render_fields; NULL members are skipped, sigma_dev / head_dev must be NULL --
+ * so that a training step whose regularisers read such fields (INRSystem.training_step passes their names on the main forward,
+ * nlf/__init__.py:658-690) needs no second, inference pass over re-uploaded weights.  Up to 64 samples per ray. */
+int hr_train_forward_fields(hr_model* m, const hr_train_tensors* params, const float* rays_dev, const float* head_dev, int64_t n_rays,
+                            int32_t white_bg, float* rgb_dev, const hr_fields* fields, void* stream);
 
 /* Given d_rgb_dev (n, 3) writes d_head_dev (n, z_channels * preds_per_z) and every non-NULL tensor of `grads` (overwritten,
  * not accumulated), for the parameter values of the last hr_train_forward / hr_model_finalize. */

@@ -488,3 +488,53 @@ def test_fused_mlp_forward_matches_the_layer_by_layer_one(case):
     for a, b in zip(g0, g1):
         scale = max(float(np.abs(a).max()), 1e-30)
         assert a.shape == b.shape and np.abs(a - b).max() <= tol * scale, (a.shape, float(np.abs(a - b).max()), scale, flips)
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'technicolor_z_plane_small'])
+def test_train_mode_fields_come_from_the_training_forward(case):
+    """INRSystem.training_step passes the regularizers' field list on its main forward (nlf/__init__.py:658-690).  In train mode the
+    colour stays differentiable and the fields are the per-sample values of the SAME pass (hr_train_forward_fields): equal to what the
+    inference kernels report (<= 2e-5; the training MLP's forward is the 24-bit one, the inference MLP f16x3), detached, and without a
+    second pass: a step that asks for fields costs at most 1.25 x a step that does not (round 3: a full weight re-upload + inference
+    pass on every such step)."""
+    import time
+    import warnings
+    from gpu_common import make_render_fn
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([g.rays] * 16, 0), np.float32)).cuda()
+    fn.eval()
+    with torch.no_grad():
+        ref = fn(rays, fields=['render_weights', 'distances', 'points'])
+        ref = {k: v.clone() for k, v in ref.items()}
+    fn.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = fn(rays, fields=['render_weights', 'distances', 'points'])
+    assert out['rgb'].requires_grad and not out['render_weights'].requires_grad
+    for k in ('render_weights', 'distances', 'points'):
+        assert out[k].shape == ref[k].shape
+        assert float((out[k] - ref[k]).abs().max()) <= 2e-5 * max(1.0, float(ref[k].abs().max())), k
+    out['rgb'].sum().backward()                      # the colour path carries gradients as usual
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in fn.parameters())
+
+    def ms(f, reps=20):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def step(fields):
+        for p in fn.parameters():
+            p.grad = None
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            o = fn(rays, fields=fields) if fields else fn(rays)
+        o['rgb'].sum().backward()
+    plain = min(ms(lambda: step(None)) for _ in range(2))
+    with_fields = min(ms(lambda: step(['render_weights'])) for _ in range(2))
+    assert with_fields <= 1.25 * plain + 0.05, (with_fields, plain)
