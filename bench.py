@@ -161,7 +161,7 @@ def family_figures(names=('technicolor_z_plane', 'neural_3d_z_plane', 'immersive
                      'ms_per_frame_hr_render': round(d0 / 20 * 1e3, 4),
                      'samples_per_ray': Z, 'grid': grid, 'mlp_gemm': f.model.mlp_precision_active(),
                      'execution': 'persistent frame kernel (head tile in LDS)' if f.model.frame_kernel_active() else
-                                  'two kernels per 131 072-ray chunk (MLP -> HBM workspace -> sample stage)',
+                                  'two kernels per workspace chunk (MLP -> HBM workspace -> sample stage)',
                      'parity_rays': int(parity_rays), 'parity_vs_oracle_linf': float(err.max()), 'parity_rays_over_1e-4': int((err > 1e-4).sum())}
         del f, g, g0, rgb, rays
         torch.cuda.empty_cache()
@@ -407,7 +407,7 @@ def main():
                                f'= {args.height * args.width} rays, {Z} samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
                    'rays_per_gpu': rays_per_gpu, 'parallelism': parallelism, 'frame_ms': round(ms_per_step, 4),
                    'execution': 'persistent frame kernel (head tile in LDS)' if model.frame_kernel_active() else
-                                'two kernels per 131 072-ray chunk (MLP -> HBM workspace -> sample stage)'},
+                                'two kernels per workspace chunk (MLP -> HBM workspace -> sample stage)'},
     }
 
     # ---- per-kernel timing + roofline (rank 0): the two kernels of the default path through hr_stage_*

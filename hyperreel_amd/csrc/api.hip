@@ -780,10 +780,13 @@ int hr_model_finalize(hr_model* m)
     HR_HIP(hipGetLastError());
     m->finalized = true;
     if (m->chunk == 0) {
-        // 131072 rays per launch measured best among 16k..640k (DoNeRF); wide heads (z_channels up to 256, cascades)
-        // are held to a 512 MiB workspace
+        // 131072 rays per launch measured best among 16k..640k (DoNeRF: a 185 MB head).  The head of a chunk should still be in the
+        // 256 MB Infinity Cache when the sample kernel reads it: wide heads (Neural-3D: 64 samples x 15 columns = 3840 bytes per ray) get
+        // fewer rays per launch -- measured on the 800x800 frames (profiles/r04_z_chunk_sweep.txt): neural_3d 4.44 ms at 131 072 rays
+        // (503 MB), 4.18 at 65 536 (252 MB), 4.24 at 49 152; the 1920-byte heads (technicolor, immersive: 252 MB at 131 072) are best there
         const int64_t nq = ((int64_t)m->n_out + 3) / 4;
-        int64_t rays = (512ll << 20) / (nq * 16 * rows_per_ray(m->cfg));
+        int64_t rays = (256ll << 20) / (nq * 16 * rows_per_ray(m->cfg));
+        if (rays >= 16384) rays &= ~(int64_t)16383;
         rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
         return hr_model_reserve(m, rays);
     }

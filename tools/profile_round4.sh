@@ -17,7 +17,7 @@ for m in technicolor_z_plane immersive_sphere; do     # the 32-ray-tile frame ke
 done
 # neural_3d (BASELINE configs[3], the slowest family, 64 samples per ray): its default plan is the two kernels
 bash tools/pmc.sh ${T}_neural3d --model neural_3d_z_plane > /dev/null 2>&1
-python tools/make_counters.py ${T}_neural3d gpurun_out/r04_counters_neural_3d_z_plane.json neural_3d_z_plane f16x3 fp32 131072 823 617 514 >> gpurun_out/r04_${T}_counters_summary.txt
+python tools/make_counters.py ${T}_neural3d gpurun_out/r04_counters_neural_3d_z_plane.json neural_3d_z_plane f16x3 fp32 65536 823 617 514 >> gpurun_out/r04_${T}_counters_summary.txt
 for i in 1 2 3 4 5; do for c in two frame neural3d technicolor_z_plane immersive_sphere; do [ -f gpurun_out/pmc_${T}_${c}_$i.txt ] && cp gpurun_out/pmc_${T}_${c}_$i.txt gpurun_out/r04_${T}_${c}_pmc_pass$i.txt; done; done
 cp gpurun_out/r04_counters.json profiles/r04_counters.json      # so that this run's bench line quotes them
 cp gpurun_out/r04_counters_frame_kernel.json profiles/r04_counters_frame_kernel.json
