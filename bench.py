@@ -22,6 +22,7 @@ The JSON line also carries
   frame_kernel    the same frame through the single persistent frame kernel (head tile handed over in LDS);
   value_fp32_exact  the same frame with the exact fp32-MFMA MLP;
   value_f16x2     the same frame with the opt-in two-product MLP arithmetic, and its own parity against the oracle;
+  value_f16f8     the same frame with the opt-in f16 + fp8 MLP arithmetic (one f16 product + one fp8 K=64 MFMA per 32 k), ditto;
   pytorch_gpu_baseline  the reference's algorithm as stock PyTorch-ROCm ops on this GPU (north star: ">= 10x");
   cpu_baseline    the CPU port of the reference's algorithm (oracle/torch_port.py) on a bounded sample of the same frame,
                   with its calibration against the reference itself (profiles/r02_cpu_calibration.json).
@@ -267,7 +268,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
-    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16x2', 'fp32'],
+    ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16f8', 'f16x2', 'fp32'],
                     help="arithmetic of the MLP GEMMs: auto = 3-product fp16 split on MFMA (fp32-grade), or exact fp32 MFMA")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
@@ -442,9 +443,9 @@ def main():
         flops = mlp_flops_per_ray(cfg) * B
         byts = algorithmic_bytes_per_ray(cfg, video, texel_bytes) * B
         split = prec_name != 'fp32'
-        mlp_kernel = {'bf16x3': 'hr_mlp_bf16x3_kernel', 'f16x3': 'hr_mlp_f16x3_kernel', 'f16x2': 'hr_mlp_f16x2_kernel', 'fp32': 'hr_mlp_kernel'}[prec_name]
+        mlp_kernel = {'bf16x3': 'hr_mlp_bf16x3_kernel', 'f16x3': 'hr_mlp_f16x3_kernel', 'f16x2': 'hr_mlp_f16x2_kernel', 'f16f8': 'hr_mlp_f16f8_kernel', 'fp32': 'hr_mlp_kernel'}[prec_name]
         peak = MFMA_16BIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        n_prod = {'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'fp32': 1}[prec_name]
+        n_prod = {'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'f16f8': 2, 'fp32': 1}[prec_name]       # (f16f8: one f16 product + one fp8 K=64 instruction per 32 k = two f16 products' pipe time)
         r_mlp = {'kernel': mlp_kernel, 'bound': 'mfma',
                  'achieved': round(flops / (mlp_ms[0] * 1e-3) / 1e12, 3),
                  'peak': peak, 'unit': 'TFLOP/s', 'frac': round(flops / (mlp_ms[0] * 1e-3) / 1e12 / peak, 4),
@@ -492,7 +493,7 @@ def main():
             # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
             # the frame's arithmetic) and quote the VALU issue fraction -- what actually limits it -- next to it
             fr_ms = time_stage(lambda: model.render(rays, out=rgb_tmp), reps)
-            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel'}[prec_name]
+            fk = {'bf16x3': 'hr_frame_bf16x3_kernel', 'f16x3': 'hr_frame_f16x3_kernel', 'f16x2': 'hr_frame_f16x2_kernel', 'f16f8': 'hr_frame_f16f8_kernel'}[prec_name]
             r_fr = {'kernel': fk, 'bound': 'mfma', 'achieved': round(flops / (fr_ms[0] * 1e-3) / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(flops / (fr_ms[0] * 1e-3) / 1e12 / peak, 4), 'traffic': None, 'launches_per_step': 1,
                     'avg_launch_ms': round(fr_ms[0], 4), 'algorithmic_per_launch': f'{mlp_flops_per_ray(cfg)} FLOP/ray x {B} rays',
@@ -557,6 +558,21 @@ def main():
                                      'what': 'same frame, MLP GEMMs as two fp16 MFMA products (activations split, weights rounded once to half): opt-in mlp_precision="f16x2"',
                                      'linf_vs_value_path': float((fast_rgb - rgb).abs().max())}
             del fast
+            # the f16 + fp8 mode: the leading product as an f16 MFMA, the two correction products as ONE fp8 (e4m3, block-scaled) K=64 MFMA per
+            # 32 k -- the matrix-pipe time of f16x2 at 1/16 of its head error; both execution plans, the faster one reported
+            best = None
+            for plan in ((False, True) if use_frame else (False,)):
+                f8 = make('f16f8', plan)
+                v, ms = quick(f8)
+                if best is None or ms < best[1]:
+                    best = (v, ms, f8.model.render(rays)['rgb'].clone(), bool(f8.model.frame_kernel_active()))
+                del f8
+            f8_rgb = best[2]
+            result['value_f16f8'] = {'value': round(best[0], 3), 'unit': 'Mrays/s', 'ms_per_step': round(best[1], 4),
+                                     'what': 'same frame, MLP GEMMs as one f16 MFMA product + one fp8 e4m3 K=64 MFMA for both correction products '
+                                             '(v_mfma_scale_f32_32x32x64_f8f6f4): opt-in mlp_precision="f16f8"',
+                                     'execution': 'frame kernel' if best[3] else 'two kernels per workspace chunk',
+                                     'linf_vs_value_path': float((f8_rgb - rgb).abs().max())}
         if args.grid_dtype == 'fp32':
             # float16 texel STORAGE (the viewer's setting, BASELINE configs[4]): a different (rounded) scene, so not the headline;
             # its parity is held against the reference algorithm on the rounded grids in tests/test_gpu_parity.py
@@ -593,6 +609,10 @@ def main():
             e2 = np.abs(fast_rgb[torch.from_numpy(idx).cuda()].cpu().numpy() - ref_rgb).max(-1)
             result['value_f16x2']['parity_vs_oracle_linf'] = float(e2.max())
             result['value_f16x2']['parity_rays_over_1e-4'] = int((e2 > 1e-4).sum())
+        if 'value_f16f8' in result:
+            e3 = np.abs(f8_rgb[torch.from_numpy(idx).cuda()].cpu().numpy() - ref_rgb).max(-1)
+            result['value_f16f8']['parity_vs_oracle_linf'] = float(e3.max())
+            result['value_f16f8']['parity_rays_over_1e-4'] = int((e3 > 1e-4).sum())
 
     if strong:
         result['host_us_per_frame'] = round(host_us, 1)
@@ -600,10 +620,12 @@ def main():
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else \
         ('hipGraph replay of this rank\'s captured render + all-gather enqueued from Python on the side stream' if strong else 'hipGraph replay of one captured frame')
     result['dtype'] = {'bf16x3': 'f32 storage/accumulate; GEMM operands bf16x3 split', 'f16x3': 'f32 storage/accumulate; GEMM operands f16x3 split',
-                       'f16x2': 'f32 storage/accumulate; GEMM operands f16x2 (weights rounded to half)', 'fp32': 'f32'}[prec_name]
+                       'f16x2': 'f32 storage/accumulate; GEMM operands f16x2 (weights rounded to half)',
+                       'f16f8': 'f32 storage/accumulate; GEMM operands f16 (leading product) + fp8 e4m3 (correction products)', 'fp32': 'f32'}[prec_name]
     result['mlp_gemm'] = {'bf16x3': 'bf16x3 split on MFMA, fp32 accumulate (raw head within 7e-6 of the fp32 chain)',
                           'f16x3': 'f16x3 split on MFMA: 11+11-bit halves, weights pre-scaled by an exact power of two, fp32 accumulate (raw head within 1e-6 of the fp32 chain)',
                           'f16x2': 'f16x2 on MFMA: activations split in two halfs, weights rounded once to half, fp32 accumulate',
+                          'f16f8': 'f16 + fp8 on MFMA: x_hi*w_hi as f16, x*w_lo + x_lo*w_hi as one block-scaled fp8 K=64 product, fp32 accumulate (raw head within 2e-5 of the fp32 chain)',
                           'fp32': 'fp32 MFMA'}[prec_name]
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same algorithm as stock
     #      PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda'; the reference itself cannot travel to the GPU

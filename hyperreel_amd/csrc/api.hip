@@ -63,6 +63,7 @@ struct hr_model {
     void* wsplit[HR_MAX_LAYERS] = {};
     float* bias[HR_MAX_LAYERS] = {};
     float winv[HR_MAX_LAYERS] = {};       // 2^-s of the packed split weights (HrMlpArgs::winv)
+    int xexp[HR_MAX_LAYERS] = {};         // f16 + fp8 split: exponent of the fp8 images of hidden Linear l's output (HrMlpArgs::xexp), from act_max
     int n_tiles[HR_MAX_LAYERS] = {};
     int k0p = 0;
     int n_out = 0;
@@ -200,7 +201,7 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_AUTO) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16F8) return fail(HR_E_INVALID, "unknown mlp_precision");
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_AUTO && c.mlp_hidden != 256)      // (AUTO resolves to fp32 there)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -305,6 +306,29 @@ float f16_to_float(uint16_t u)
     return (float)h;
 }
 
+// OCP e4m3 (what v_mfma_scale_f32_32x32x64_f8f6f4 reads with cbsz / blgp = 0): 1-4-3, bias 7, no infinities, 0x7f = NaN, largest 448;
+// round-to-nearest-even, subnormals down to 2^-9.  The packed weights stay below 2^8 by construction, so nothing saturates here.
+uint8_t e4m3_rne(float f)
+{
+    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+    float a = fabsf(f);
+    if (!(a == a)) return 0x7f;
+    if (a > 448.0f) a = 448.0f;
+    if (a < ldexpf(1.0f, -10)) return sign;                    // below half the smallest subnormal (a tie at 2^-10 goes to even = 0)
+    int e = 0;
+    (void)frexpf(a, &e);                                       // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;                                            // a = 1.xxx * 2^ex
+    if (ex < -6) ex = -6;                                      // subnormal range: fixed quantum 2^-9
+    const float q = ldexpf(1.0f, ex - 3);                      // spacing
+    const float r = nearbyintf(a / q);                         // ties to even (default rounding mode)
+    float v = r * q;
+    if (v > 448.0f) v = 448.0f;
+    if (v < ldexpf(1.0f, -6)) return (uint8_t)(sign | (int)(v / ldexpf(1.0f, -9)));
+    (void)frexpf(v, &e);
+    const int E = e - 1 + 7;
+    const int M = (int)(v / ldexpf(1.0f, e - 1 - 3)) - 8;
+    return (uint8_t)(sign | (E << 3) | M);
+}
 float bf16_to_float(uint16_t h)
 {
     uint32_t u = (uint32_t)h << 16;
@@ -456,8 +480,31 @@ int hr_model_upload(hr_model* m, const char* name, const void* ptr, size_t bytes
 
 // The MLP's weights re-laid out for the active arithmetic (m->active_precision).  Called by hr_model_finalize and again by
 // hr_model_calibrate when the calibration changes that choice.
+// f16 + fp8 split: how far above the calibration's largest activation of a layer the fp8 image of that layer's output still is finite
+// (e4m3 keeps 4 significant bits over the 15 octaves below that; the correction products it feeds are 2^-11 of the result)
+static const float HR_F8_HEADROOM = 16.0f;
+
+// fp8 image of hidden Linear l's output (f16 + fp8 split only): e4m3(x * 2^-Ea) with the calibration's largest |pre-activation| of that layer
+// (act_max[l + 1]) times HR_F8_HEADROOM at or below 448 -- beyond 448 * 2^Ea the image saturates and the kernels say so (HR_OPT_MLP_F8_SATURATED).  Depends on the
+// calibration only, not on the packed weights: hr_model_calibrate refreshes it without re-packing.
+static void f8_exponents(hr_model* m)
+{
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+        m->xexp[l] = 0;
+        if (m->active_precision != HR_MLP_F16F8 || l + 1 >= m->cfg.mlp_layers) continue;
+        const float mx = m->act_max[l + 1] * HR_F8_HEADROOM;
+        int e = 0;
+        if (mx > 0.0f && std::isfinite(mx)) {
+            (void)frexpf(mx / 448.0f, &e);              // mx / 448 = f * 2^e, f in [0.5, 1): mx <= 448 * 2^e
+            e = e < -30 ? -30 : (e > 30 ? 30 : e);
+        }
+        m->xexp[l] = e;
+    }
+}
+
 static int pack_mlp(hr_model* m)
 {
+    f8_exponents(m);
     const hr_config& c = m->cfg;
     char name[64];
     m->mlp_bytes = 0;
@@ -477,7 +524,8 @@ static int pack_mlp(hr_model* m)
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
         const bool split = (m->active_precision != HR_MLP_FP32);
-        const bool half = (m->active_precision == HR_MLP_F16X3 || m->active_precision == HR_MLP_F16X2);
+        const bool f8lo = (m->active_precision == HR_MLP_F16F8);
+        const bool half = (m->active_precision == HR_MLP_F16X3 || m->active_precision == HR_MLP_F16X2 || f8lo);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -546,6 +594,23 @@ static int pack_mlp(hr_model* m)
                             pk[base] = hi;
                             pk[base + 64 * 8] = lo;
                         }
+            if (f8lo) {
+                // f16 + fp8 split (mlp_split_core.inc, hr_accumulate_f8): over the HIDDEN k-steps (those past the input segment of the first / skip
+                // layer, which keeps three f16 products) the "lo" tile of a k-step pair's even step becomes 16 bytes per lane of
+                // e4m3((w' - half(w')) * 2^6) and the odd step's 16 bytes of e4m3(w' * 2^-6), both for the pair's k = 32 kp + 16 (lane >> 5) + 0..15
+                const int kseg = first ? Kp / 16 : (skip ? m->k0p / 16 : 0);
+                uint8_t* bytes = reinterpret_cast<uint8_t*>(pk.data());
+                for (int kt = kseg; kt < Kp / 16; ++kt)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 16; ++j) {
+                                const int kk = 16 * (kseg + 2 * ((kt - kseg) / 2)) + 16 * (lane >> 5) + j;
+                                const float v = wk(32 * t + (lane & 31), kk) * wmul;
+                                const bool odd = (kt - kseg) & 1;
+                                const float q = odd ? ldexpf(v, -6) : ldexpf(v - f16_to_float(f16_rne(v)), 6);
+                                bytes[(((((size_t)kt * nt + t) * 2 + 1) * 64 + lane) * 8) * 2 + j] = e4m3_rne(q);
+                            }
+            }
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
             HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             m->mlp_bytes += (int64_t)pk.size() * sizeof(uint16_t);
@@ -643,7 +708,7 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     if (!fits)
         return fail(HR_E_RANGE, "mlp_precision %s was requested, but the MLP's activations reach %.4g on the calibration rays (limit %.4g = "
                     "65504 / 8): IEEE-half operands would overflow.  Use HR_MLP_AUTO (falls back to bf16x3) or HR_MLP_BF16X3",
-                    want == HR_MLP_F16X3 ? "f16x3" : "f16x2", (double)mx, (double)HR_F16_CALIBRATION_LIMIT);
+                    want == HR_MLP_F16X3 ? "f16x3" : (want == HR_MLP_F16X2 ? "f16x2" : "f16f8"), (double)mx, (double)HR_F16_CALIBRATION_LIMIT);
     m->active_precision = want;
     return HR_OK;
 }
@@ -811,6 +876,7 @@ int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float
         return rc;
     }
     HR_HIP(hipMemset(m->flags, 0, sizeof(unsigned)));
+    f8_exponents(m);
     if (m->active_precision != before) {
         m->packed_bytes -= m->mlp_bytes;
         rc = pack_mlp(m);
@@ -881,6 +947,7 @@ static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a
     if (m->active_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (m->active_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else if (m->active_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
+    else if (m->active_precision == HR_MLP_F16F8) hr_launch_mlp_f16f8(c, a, st);
     else hr_launch_mlp(c, a, st);
 }
 
@@ -894,6 +961,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
         a.wsplit[l] = m->wsplit[l];
         a.bias[l] = m->bias[l];
         a.winv[l] = m->winv[l];
+        a.xexp[l] = m->xexp[l];
         a.n_tiles[l] = m->n_tiles[l];
     }
     a.n_out = m->n_out;
@@ -998,6 +1066,7 @@ static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, 
         case HR_MLP_BF16X3: return hr_launch_frame_bf16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
         case HR_MLP_F16X3: return hr_launch_frame_f16x3(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
         case HR_MLP_F16X2: return hr_launch_frame_f16x2(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
+        case HR_MLP_F16F8: return hr_launch_frame_f16f8(m->kcfg, ma, sa, m->opt_sample_waves, m->opt_frame_kernel, m->n_cus, probe, st);
         default: return false;          // the exact-fp32 MLP (v_mfma_f32_16x16x4_f32) keeps its own kernel
     }
 }
@@ -1159,7 +1228,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
     else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
-    else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW) {
+    else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW || option == HR_OPT_MLP_F8_SATURATED) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         if (option == HR_OPT_MLP_PRECISION_ACTIVE) *value = m->active_precision;
         else if (option == HR_OPT_MLP_CALIBRATED) *value = m->calibrated;
@@ -1171,7 +1240,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
                 HR_HIP(hipMemcpy(&g, m->coarse->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
                 f |= g;
             }
-            *value = (int32_t)(f & 1u);
+            *value = (int32_t)(option == HR_OPT_MLP_OVERFLOW ? (f & 1u) : ((f >> 1) & 1u));
         }
     } else if (option == HR_OPT_FRAME_KERNEL_ACTIVE) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");

@@ -72,13 +72,16 @@ struct HrMlpArgs {
     const float* bias[HR_MAX_LAYERS];
     float winv[HR_MAX_LAYERS];   // split kernels: the packed weights of layer L are W * 2^s (fp16 modes: keeps the low halves out of
                                  //   the subnormal range); the epilogue multiplies the accumulator by winv = 2^-s (exact).  1 for bf16
+    int xexp[HR_MAX_LAYERS];     // f16 + fp8 split (mlp_f16f8_kernel.hip): the fp8 images of hidden Linear L's output are e4m3(x * 2^-xexp[L]) and
+                                 //   e4m3((x - half(x)) * 2^(11 - xexp[L])); from the activation-range calibration, 0 in the other modes
     int n_tiles[HR_MAX_LAYERS];  // output tiles of layer L: 16 columns (fp32) or 32 features (bf16x3)
     int n_out;                   // Z * P
     int nq;                      // ceil(n_out / 4)
     int k0p;                     // mlp_in padded to a multiple of 16
     unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
     unsigned* flags;             // sticky status word of the model: bit 0 = an fp16-split kernel saw an input feature or hidden activation
-                                 //   at or beyond the IEEE-half range (HR_OPT_MLP_OVERFLOW)
+                                 //   at or beyond the IEEE-half range (HR_OPT_MLP_OVERFLOW); bit 1 = the f16 + fp8 split saturated an fp8 image
+                                 //   of a hidden activation (HR_OPT_MLP_F8_SATURATED)
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -146,6 +149,7 @@ void hr_launch_mlp(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stre
 void hr_launch_mlp_bf16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);
 void hr_launch_mlp_f16x3(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // same layouts, fp16 halves
 void hr_launch_mlp_f16x2(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16, weights unsplit
+void hr_launch_mlp_f16f8(const hr_config& cfg, const HrMlpArgs& args, hipStream_t stream);   // fp16 leading product, the two correction products as one fp8 K=64 MFMA
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream);
 // fused frame kernel (fused_impl.inc): MLP + sample stage of all rays in one persistent launch, head tile in LDS.
 // Returns false when the model does not fit it (nothing launched); probe: only answer.
@@ -154,6 +158,8 @@ bool hr_launch_frame_bf16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrS
 bool hr_launch_frame_f16x3(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
                             hipStream_t stream);
 bool hr_launch_frame_f16x2(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
+                            hipStream_t stream);
+bool hr_launch_frame_f16f8(const hr_config& cfg, const HrMlpArgs& ma, const HrSampleArgs& sa, int sample_waves, int frame_mode, int n_cus, bool probe,
                             hipStream_t stream);
 
 // activation range of the MLP on a set of rays (range_kernel.hip): act_max[0] = max |input feature|, act_max[l + 1] = max |pre-activation|

@@ -8,4 +8,5 @@
 #define HR_SPLIT_KERNEL hr_mlp_f16x2_kernel
 #define HR_SPLIT_LAUNCH hr_launch_mlp_f16x2
 #define HR_SPLIT_PRODUCTS 2
+#define HR_W_LOAD_AUX 0            // weights through buffer loads (mlp_split_core.inc, hr_load_w)
 #include "mlp_split_impl.inc"

@@ -362,7 +362,7 @@ class HipLightfieldModel(nn.Module):
         self.cfg = cfg
         system = kwargs.get('system')
         self.dataset = kwargs['dataset'] if 'dataset' in kwargs else dataset_scalars_from_system(system)
-        # arithmetic of the MLP GEMMs: 'auto' (= 'f16x3' where its fp16 range is proven at finalize, else 'bf16x3') | 'f16x3' | 'bf16x3' | 'f16x2' | 'fp32' (plan.compile_config)
+        # arithmetic of the MLP GEMMs: 'auto' (= 'f16x3' where its fp16 range is proven at finalize, else 'bf16x3') | 'f16x3' | 'bf16x3' | 'f16f8' | 'f16x2' | 'fp32' (plan.compile_config)
         self.mlp_precision = kwargs.get('mlp_precision', 'auto')
         self.grid_dtype = kwargs.get('grid_dtype', 'fp32')     # 'fp16': half-precision texels (viewer path)
         # execution plan of render() (hr_model_set_option): frame kernel on/off, its sample wavefronts (None: library default)
@@ -628,11 +628,16 @@ class HipLightfieldModel(nn.Module):
 
     def mlp_precision_active(self):
         """The arithmetic the MLP kernels run ('auto' resolved by the library's activation-range calibration)."""
-        return {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2'}[self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)]
+        return {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2', 5: 'f16f8'}[self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)]
 
     def mlp_overflowed(self):
         """True when an fp16-split kernel saw an activation at the IEEE-half range on a rendered ray (sticky; synchronises)."""
         return bool(self._get_option(_lib.HR_OPT_MLP_OVERFLOW))
+
+    def mlp_f8_saturated(self):
+        """mlp_precision 'f16f8': True when a hidden activation of a rendered ray was beyond the range of its fp8 image (sticky; synchronises).
+        Nothing overflowed -- that ray's correction products were computed from saturated images; `calibrate(rays)` moves the exponents."""
+        return bool(self._get_option(_lib.HR_OPT_MLP_F8_SATURATED))
 
     def calibrate(self, rays):
         """Re-decides the MLP arithmetic on the caller's rays (hr_model_calibrate); returns the per-layer activation maxima."""
@@ -724,13 +729,34 @@ class HipLightfieldModel(nn.Module):
         n = self._render_calls = getattr(self, '_render_calls', 0) + 1
         if not (n == 1 or n == 16 or n % 1024 == 0) or torch.cuda.is_current_stream_capturing():
             return False
-        if self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE) not in (2, 3) or not self.mlp_overflowed():
+        active = self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)
+        if active not in (2, 3, 5):                                      # f16x3, f16x2, f16f8
             return False
         import warnings
-        warnings.warn('hyperreel_amd: an MLP activation reached the IEEE-half range on rendered rays (the fp16 split arithmetic had been chosen '
-                      'on calibration rays); re-deciding the arithmetic on these rays and rendering the batch again')
-        self.calibrate(rays)
-        return True
+        if self.mlp_overflowed():
+            warnings.warn('hyperreel_amd: an MLP activation reached the IEEE-half range on rendered rays (the fp16 split arithmetic had been chosen '
+                          'on calibration rays); re-deciding the arithmetic on these rays and rendering the batch again')
+            self.calibrate(rays)
+            return True
+        if active == 5 and self.mlp_f8_saturated():
+            # f16f8: the fp8 images of a layer's output are scaled from the calibration's largest activation of that layer.  Beyond 16x that they
+            # saturate (finite, less accurate).  Where the model can be calibrated on the caller's rays, do so and render again; a cascade's
+            # point MLP sees internal rows (hr_model_calibrate refuses it): say so once and carry on
+            if getattr(self, '_f8_cannot_calibrate', False):
+                return False
+            try:
+                self.calibrate(rays)
+            except RuntimeError as e:
+                if 'cascades' not in str(e):
+                    raise
+                self._f8_cannot_calibrate = True
+                warnings.warn('hyperreel_amd: mlp_precision f16f8 saturated the fp8 image of an activation on rendered rays and this model (a cascade) '
+                              'cannot be re-calibrated on them: those rays carry less accurate correction products (mlp_precision f16x3 has none)')
+                return False
+            warnings.warn('hyperreel_amd: mlp_precision f16f8 saturated the fp8 image of an activation on rendered rays; moved the exponents to these '
+                          'rays and rendering the batch again')
+            return True
+        return False
 
     def generate_rays(self, pose, K, width, height, time=None, cam_id=0.0, pixel_range=None, device=None):
         """get_coords_from_camera (datasets/base.py:485-518) on the device: 3x4 camera-to-world

@@ -314,7 +314,7 @@ class _Affine:
 
 
 # --------------------------------------------------------------------------- the compiler
-MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3, 'auto': 4}
+MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3, 'auto': 4, 'f16f8': 5}
 
 
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
@@ -749,7 +749,7 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     # (HR_E_RANGE).  'fp32' is the exact fp32 MFMA; other hidden widths only have that.
     if mlp_precision == 'auto' or hc.mlp_layers == 0:
         mlp_precision = 'auto' if hc.mlp_hidden == 256 else 'fp32'
-    if mlp_precision in ('bf16x3', 'f16x3', 'f16x2') and hc.mlp_hidden != 256:
+    if mlp_precision in ('bf16x3', 'f16x3', 'f16x2', 'f16f8') and hc.mlp_hidden != 256:
         raise NotImplementedError(f'{mlp_precision} MLP needs hidden_channels == 256')
     hc.mlp_precision = MLP_PRECISION[mlp_precision]
     if grid_dtype not in GRID_DTYPE:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 23
+#define HR_ABI_VERSION 24
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -105,7 +105,12 @@ enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
         * rays; hr_model_calibrate: the caller's rays) keeps every input feature and hidden activation below 65504 / 8, bf16x3
         * otherwise (fp32 when mlp_hidden != 256).  The same test makes a FORCED f16x3 / f16x2 fail with HR_E_RANGE instead of
         * rendering infinities (the reference's BaseMLP is fp32, nlf/nets/mlp.py:127-172: any finite activation is legal there) */
-       HR_MLP_AUTO = 4 };
+       HR_MLP_AUTO = 4,
+       /* fp16 halves like F16X3, but only the leading product x_hi*w_hi is an f16 MFMA: the two correction products (2^-11 of it) are ONE
+        * fp8 (OCP e4m3) K=64 MFMA per 32 k with power-of-two block scales -- two thirds of F16X3's matrix-pipe time at ~2^-16 relative
+        * per product (F16X3 2^-22, F16X2 2^-12).  Same range rule as F16X3, plus a per-layer exponent for the fp8 images taken from the
+        * calibration (16x headroom); an activation beyond either range sets HR_OPT_MLP_OVERFLOW.  gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4). */
+       HR_MLP_F16F8 = 5 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
@@ -301,9 +306,12 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * Read-only: HR_OPT_FRAME_KERNEL_ACTIVE whether hr_render currently takes the frame kernel; HR_OPT_MLP_PRECISION_ACTIVE the HR_MLP_*
  * arithmetic the MLP kernels run (HR_MLP_AUTO resolved); HR_OPT_MLP_CALIBRATED 0 / 1 (finalize's synthetic rays) / 2 (hr_model_calibrate);
  * HR_OPT_MLP_OVERFLOW the sticky bit the fp16-split kernels set when an input feature or hidden activation of a RENDERED ray reached
- * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate). */
+ * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate); HR_OPT_MLP_F8_SATURATED the
+ * sticky bit HR_MLP_F16F8's kernels set when a hidden activation of a rendered ray was beyond the range of its fp8 image (16x the calibration's
+ * largest activation of that layer): the image saturates, the ray's correction products lose accuracy (towards HR_MLP_F16X2's), nothing
+ * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit. */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
-       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6 };
+       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6, HR_OPT_MLP_F8_SATURATED = 7 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

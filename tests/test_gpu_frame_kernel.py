@@ -69,7 +69,7 @@ def test_keyframe_families_take_the_32_ray_tile_frame_kernel(case):
 
 
 @pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
-@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2', 'f16f8'])
 @pytest.mark.parametrize('case', KEYFRAME)
 def test_keyframe_frame_kernel_equals_two_kernel_path_bit_for_bit(case, precision, grid_dtype):
     g, fn = _fns(case, precision, grid_dtype)
@@ -102,7 +102,7 @@ def test_keyframe_frame_kernel_full_frame_every_word_and_repeats(model):
 
 
 @pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
-@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2'])
+@pytest.mark.parametrize('precision', ['bf16x3', 'f16x3', 'f16x2', 'f16f8'])
 @pytest.mark.parametrize('waves', [4, 8])
 @pytest.mark.parametrize('case', FUSABLE)
 def test_frame_kernel_equals_two_kernel_path_bit_for_bit(case, waves, precision, grid_dtype):

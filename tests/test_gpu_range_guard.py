@@ -58,7 +58,7 @@ def test_large_activations_fall_back_to_bf16x3_and_still_match_the_reference():
     assert linf(got, exact) <= 5e-5
 
 
-@pytest.mark.parametrize('forced', ['f16x3', 'f16x2'])
+@pytest.mark.parametrize('forced', ['f16x3', 'f16x2', 'f16f8'])
 def test_forced_fp16_arithmetic_is_refused_by_name_when_it_would_overflow(forced):
     from gpu_common import make_render_fn
     from hyperreel_amd.lib import HipRangeError

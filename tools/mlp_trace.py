@@ -8,10 +8,10 @@ from hyperreel_amd.render import build_render_fn
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
 sd = scenes.make_state_dict(cfg, ds, [64, 64, 64], seed=7)
-fn = build_render_fn(cfg, dataset=ds, grid_size=[64, 64, 64])
+fn = build_render_fn(cfg, dataset=ds, grid_size=[64, 64, 64], mlp_precision=os.environ.get('HR_PREC', 'auto'), frame_kernel=False)
 fn.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
 rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800)[:n]).cuda()
-fn.model.reserve(n); h = fn.model.native(); L = lib.load()
+fn.model.reserve(max(n, 4096)); h = fn.model.native(); L = lib.load()
 tile = 128 if os.environ.get('HR_MLP_TILE') == '128' else 64
 nwg = (n + tile - 1) // tile
 tr = torch.zeros((nwg * 4, 64), dtype=torch.int64, device='cuda')
