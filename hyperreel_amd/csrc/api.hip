@@ -1395,6 +1395,41 @@ int hr_plane_reg_backward(const float* plane_dev, int32_t channels, int32_t h, i
     return HR_OK;
 }
 
+int hr_adam_step(float* const* param_dev, const float* const* grad_dev, float* const* exp_avg_dev, float* const* exp_avg_sq_dev, const int64_t* n,
+                 const double* hp, int32_t n_tensors, void* stream)
+{
+    if (n_tensors < 0 || (n_tensors > 0 && (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !n || !hp))) return fail(HR_E_INVALID, "null argument");
+    HrAdamBatch b;
+    b.count = 0;
+    b.first_block[0] = 0;
+    auto flush = [&]() {
+        hr_launch_adam(b, (hipStream_t)stream);
+        b.count = 0;
+        b.first_block[0] = 0;
+    };
+    for (int i = 0; i < n_tensors; ++i) {
+        if (n[i] < 0) return fail(HR_E_INVALID, "hr_adam_step: tensor %d has a negative size", i);
+        if (n[i] == 0) continue;
+        if (!param_dev[i] || !grad_dev[i] || !exp_avg_dev[i] || !exp_avg_sq_dev[i]) return fail(HR_E_INVALID, "hr_adam_step: tensor %d has a null buffer", i);
+        const double lr = hp[6 * i], b1 = hp[6 * i + 1], b2 = hp[6 * i + 2], eps = hp[6 * i + 3], wd = hp[6 * i + 4], step = hp[6 * i + 5];
+        if (!(step >= 1.0) || !(b1 >= 0.0 && b1 < 1.0) || !(b2 >= 0.0 && b2 < 1.0)) return fail(HR_E_INVALID, "hr_adam_step: tensor %d: step >= 1 and betas in [0, 1) required", i);
+        const int64_t blocks = (n[i] + 4095) / 4096;
+        if (blocks > 0x3fffffff) return fail(HR_E_INVALID, "hr_adam_step: tensor %d is too large", i);
+        if (b.count == HR_ADAM_MAX_TENSORS || (int64_t)b.first_block[b.count] + blocks > 0x7fffffff) flush();
+        const int k = b.count++;
+        b.p[k] = param_dev[i]; b.g[k] = grad_dev[i]; b.m[k] = exp_avg_dev[i]; b.v[k] = exp_avg_sq_dev[i]; b.n[k] = n[i];
+        // bias corrections in double on the host (torch: python floats)
+        const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+        b.step_size[k] = (float)(lr / bc1);
+        b.inv_sqrt_bc2[k] = (float)(1.0 / sqrt(bc2));
+        b.omb1[k] = (float)(1.0 - b1); b.beta2[k] = (float)b2; b.omb2[k] = (float)(1.0 - b2); b.eps[k] = (float)eps; b.weight_decay[k] = (float)wd;
+        b.first_block[k + 1] = b.first_block[k] + (int)blocks;
+    }
+    if (b.count > 0) flush();
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 // ---------------------------------------------------------------- training path
 static int check_train(hr_model* m, const float* rays, int64_t n)
 {

@@ -192,6 +192,23 @@ void hr_launch_upsample_plane(const float* src, int C, int H, int W, float* dst,
 void hr_launch_pack_display(const float* rgb, int h, int w, int transpose, int flip, int rgba8, void* out, hipStream_t stream);
 void hr_launch_plane_reg_forward(const float* p, int C, int H, int W, float* sums, hipStream_t stream);
 void hr_launch_plane_reg_backward(const float* p, int C, int H, int W, const float* coef, float* grad, hipStream_t stream);
+// optimizer step of the training loop (utils/__init__.py:49-76 get_optimizer -> torch.optim.Adam(betas=(0.9, 0.99), eps=1e-8)): every parameter
+// tensor of a step in ONE launch.  A block owns 4096 consecutive elements of one tensor; first_block[] is the prefix sum of the tensors' block counts
+constexpr int HR_ADAM_MAX_TENSORS = 40;
+struct HrAdamBatch {
+    float* p[HR_ADAM_MAX_TENSORS];
+    const float* g[HR_ADAM_MAX_TENSORS];
+    float* m[HR_ADAM_MAX_TENSORS];
+    float* v[HR_ADAM_MAX_TENSORS];
+    int64_t n[HR_ADAM_MAX_TENSORS];
+    float step_size[HR_ADAM_MAX_TENSORS];      // lr / (1 - beta1^t)
+    float inv_sqrt_bc2[HR_ADAM_MAX_TENSORS];   // 1 / sqrt(1 - beta2^t)
+    float omb1[HR_ADAM_MAX_TENSORS], beta2[HR_ADAM_MAX_TENSORS], omb2[HR_ADAM_MAX_TENSORS];     // 1 - beta1, beta2, 1 - beta2 (the differences formed in double)
+    float eps[HR_ADAM_MAX_TENSORS], weight_decay[HR_ADAM_MAX_TENSORS];
+    int first_block[HR_ADAM_MAX_TENSORS + 1];
+    int count;
+};
+void hr_launch_adam(const HrAdamBatch& b, hipStream_t stream);
 // the training step's re-layouts in ONE launch per direction (reference (C, H, W) tensors <-> packed channel-last texels): up to 12 jobs
 struct HrLayoutJob { const float* src; float* dst; int C, H, W, tex, c_off; };
 struct HrLayoutBatch { HrLayoutJob job[12]; int n; };

@@ -424,7 +424,14 @@ class HipLightfieldModel(nn.Module):
 
     @property
     def grid_size(self):
-        return [int(v) for v in self.color_model.net.gridSize.tolist()]
+        # gridSize is a buffer and lives on the device with the model: read it back only when it changed (forward_train asks every step --
+        # a device-to-host copy there stalls the host behind the queue and cannot be captured into a graph)
+        gs = self.color_model.net.gridSize
+        key = (gs.data_ptr(), gs._version, gs.device)
+        cached = getattr(self, '_grid_size_host', None)
+        if cached is None or cached[0] != key:
+            cached = self._grid_size_host = (key, [int(v) for v in gs.tolist()])
+        return list(cached[1])
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts reference checkpoints: strips a leading `render_fn.model.` / `model.`,

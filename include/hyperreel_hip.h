@@ -472,6 +472,16 @@ int hr_pack_display(const float* rgb_dev, int32_t h, int32_t w, int32_t transpos
 int hr_plane_reg_forward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, float* sums_dev, void* stream);
 int hr_plane_reg_backward(const float* plane_dev, int32_t channels, int32_t h, int32_t w, const float* coef_dev, float* grad_dev, void* stream);
 
+/* The optimizer of the training loop (utils/__init__.py:49-76: torch.optim.Adam(params, lr, eps=1e-8, weight_decay, betas=(0.9, 0.99)); stepped by
+ * Lightning after INRSystem.training_step, nlf/__init__.py:634-709): one Adam step over any number of parameter tensors in ONE pass over memory
+ * (28 bytes per parameter).  Tensor i is n[i] contiguous floats at param_dev[i] with its gradient, first and second moment (torch's state names
+ * exp_avg / exp_avg_sq) in grad_dev[i], exp_avg_dev[i], exp_avg_sq_dev[i]; the pointer arrays and hp are HOST memory.  hp holds six doubles per
+ * tensor: lr, beta1, beta2, eps, weight_decay, step (the 1-based step count this call performs -- bias corrections are 1 - beta^step; doubles
+ * because torch derives 1 - beta and the corrections from Python floats).  The arithmetic is torch/optim/adam.py's single-tensor form
+ * (amsgrad / maximize off), evaluated in fp32. */
+int hr_adam_step(float* const* param_dev, const float* const* grad_dev, float* const* exp_avg_dev, float* const* exp_avg_sq_dev, const int64_t* n,
+                 const double* hp, int32_t n_tensors, void* stream);
+
 /* The two stages of hr_render on their own, for profiling: the sample-prediction MLP
  * (rays -> raw head in the workspace) and the per-sample stage (head -> rgb).  n_rays
  * must not exceed the reserved chunk size. */

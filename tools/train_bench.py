@@ -63,7 +63,8 @@ def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_
     rays = torch.from_numpy(np.ascontiguousarray(rays_np[idx])).cuda()
     target = torch.rand((args.batch, 3), device='cuda')
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3)
+    from hyperreel_amd.optim import HipAdam
+    opt = HipAdam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8)              # the reference's Adam (utils/__init__.py:61-66) as one launch
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -72,6 +73,9 @@ def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_
         opt.step()
 
     ms_step = timed(step, args.steps)
+    opt_hip, opt = opt, torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8)      # the same step with torch's own (foreach) Adam
+    ms_step_torch_adam = timed(step, args.steps)
+    opt = opt_hip
 
     def fwd_bwd():
         for p in params:
@@ -143,6 +147,7 @@ def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_
            'hip_ms_sample_stage_backward': round(ms_stage_both - ms_stage_fwd, 3),
            'hip_ms_mlp_forward_backward': round(ms_mlp_hip, 3), 'rocblas_ms_mlp_forward_backward': round(ms_mlp_blas, 3),
            'hip_krays_per_s': round(args.batch / ms_step, 1),
+           'torch_optim_adam_ms_per_step': round(ms_step_torch_adam, 3),
            'opt_in': {'fused_mlp_forward_ms_per_step': round(ms_step_fused, 3), 'fused_mlp_forward_backward_ms': round(ms_mlp_fused, 3),
                       'deterministic_ms_per_step': round(ms_step_det, 3)}}
 
