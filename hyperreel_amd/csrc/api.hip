@@ -596,19 +596,18 @@ static int pack_mlp(hr_model* m)
                         }
             if (f8lo) {
                 // f16 + fp8 split (mlp_split_core.inc, hr_accumulate_f8): over the HIDDEN k-steps (those past the input segment of the first / skip
-                // layer, which keeps three f16 products) the "lo" tile of a k-step pair's even step becomes 16 bytes per lane of
-                // e4m3((w' - half(w')) * 2^6) and the odd step's 16 bytes of e4m3(w' * 2^-6), both for the pair's k = 32 kp + 16 (lane >> 5) + 0..15
+                // layer, which keeps three f16 products) the 16 bytes of a lane's "lo" half become the fp8 images of the SAME 8 weights its f16 half
+                // holds: e4m3((w' - half(w')) * 2^6) x 8, then e4m3(w' * 2^-6) x 8
                 const int kseg = first ? Kp / 16 : (skip ? m->k0p / 16 : 0);
                 uint8_t* bytes = reinterpret_cast<uint8_t*>(pk.data());
                 for (int kt = kseg; kt < Kp / 16; ++kt)
                     for (int t = 0; t < nt; ++t)
                         for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 16; ++j) {
-                                const int kk = 16 * (kseg + 2 * ((kt - kseg) / 2)) + 16 * (lane >> 5) + j;
-                                const float v = wk(32 * t + (lane & 31), kk) * wmul;
-                                const bool odd = (kt - kseg) & 1;
-                                const float q = odd ? ldexpf(v, -6) : ldexpf(v - f16_to_float(f16_rne(v)), 6);
-                                bytes[(((((size_t)kt * nt + t) * 2 + 1) * 64 + lane) * 8) * 2 + j] = e4m3_rne(q);
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = wk(32 * t + (lane & 31), 16 * kt + 8 * (lane >> 5) + j) * wmul;
+                                const size_t at = (((((size_t)kt * nt + t) * 2 + 1) * 64 + lane) * 8) * 2;
+                                bytes[at + j] = e4m3_rne(ldexpf(v - f16_to_float(f16_rne(v)), 6));
+                                bytes[at + 8 + j] = e4m3_rne(ldexpf(v, -6));
                             }
             }
             HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
