@@ -72,7 +72,7 @@ def train_step_figures(model_name='donerf_sphere', batch=16384, steps=30, torch_
         loss.backward()
         opt.step()
 
-    ms_step = timed(step, args.steps)
+    ms_step = timed(step, args.steps, warm=6, rounds=3)         # (the first figure of the process: allocator and optimizer state settle in the warm-up)
     opt_hip, opt = opt, torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8)      # the same step with torch's own (foreach) Adam
     ms_step_torch_adam = timed(step, args.steps)
     opt = opt_hip
