@@ -219,7 +219,7 @@ def viewer_figures(sizes=((512, 512), (800, 800)), model_name='immersive_sphere'
     """BASELINE configs[4] (Google Immersive, viewer path): one displayed frame = camera -> rays on the device
     (hr_generate_rays; datasets/base.py:485-518) -> render -> the viewer's transpose / flip / 8-bit pack (hr_pack_display;
     utils/gui_utils.py:174-205), captured as ONE hipGraph and replayed; float16 texels, and next to the default f16x3 MLP the
-    two-product f16x2 speed mode.  ms per displayed frame."""
+    opt-in f16f8 and f16x2 arithmetics.  ms per displayed frame."""
     from hyperreel_amd.render import build_render_fn
     cfg, ds = C.model_config(model_name), C.dataset_scalars(model_name)
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
@@ -227,7 +227,7 @@ def viewer_figures(sizes=((512, 512), (800, 800)), model_name='immersive_sphere'
     out = {'model': model_name, 'grid': grid, 'grid_dtype': 'fp16',
            'what': 'pose -> hr_generate_rays -> hr_render -> hr_pack_display (RGBA8, transposed + flipped like NeRFGUI.test_step), one hipGraph replay per frame'}
     pose = scenes.look_at_pose((0.3, 0.0, 0.0), (1.0, 0.1, 0.05))
-    for prec in ('auto', 'f16x2'):
+    for prec in ('auto', 'f16f8', 'f16x2'):
         f = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision=prec, grid_dtype='fp16')
         f.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         m = f.model

@@ -1398,6 +1398,7 @@ int hr_adam_step(float* const* param_dev, const float* const* grad_dev, float* c
                  const double* hp, int32_t n_tensors, void* stream)
 {
     if (n_tensors < 0 || (n_tensors > 0 && (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !n || !hp))) return fail(HR_E_INVALID, "null argument");
+    if (n_tensors == 0) return HR_OK;
     HrAdamBatch b;
     b.count = 0;
     b.first_block[0] = 0;
@@ -1686,7 +1687,6 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         if (need > m->grad_fx_elems) {
             HR_HIP(hipStreamSynchronize(st));
             if (m->grad_fx) (void)hipFree(m->grad_fx);
-    for (int l = 0; l < HR_MAX_LAYERS; ++l) { if (m->wsplit_t[l]) (void)hipFree(m->wsplit_t[l]); free_dev(m->bias_t[l]); }
             m->grad_fx = nullptr; m->grad_fx_elems = 0;
             HR_HIP(hipMalloc((void**)&m->grad_fx, sizeof(long long) * need));
             m->grad_fx_elems = need;
@@ -1848,6 +1848,11 @@ void hr_model_destroy(hr_model* m)
     for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); free_dev(m->frame_line[j]); }
     free_dev(m->tape);
     if (m->grad_fx) (void)hipFree(m->grad_fx);
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {          // the training forward's per-step weight tiles (hr_mlp_train_forward)
+        if (m->wsplit_t[l]) (void)hipFree(m->wsplit_t[l]);
+        m->wsplit_t[l] = nullptr;
+        free_dev(m->bias_t[l]);
+    }
     hr_model_destroy(m->coarse);
     delete m;
 }

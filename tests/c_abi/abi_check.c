@@ -49,6 +49,14 @@ int main(void)
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
         if (hr_model_calibrate(NULL, &x, 1, NULL, NULL) != HR_E_INVALID) return 24;
         if (hr_allgather_tiles(NULL, &x, &x, 3, NULL) != HR_E_INVALID) return 25;
+        {   /* hr_adam_step: NULL arrays refused; a negative size and a step count of 0 refused before anything is launched; zero tensors is a no-op */
+            float* pp[1] = {&x}; const float* gp[1] = {&x}; int64_t nn[1] = {-1}; double hp[6] = {1e-3, 0.9, 0.99, 1e-8, 0.0, 1.0};
+            if (hr_adam_step(NULL, NULL, NULL, NULL, NULL, NULL, 1, NULL) != HR_E_INVALID) return 28;
+            if (hr_adam_step(pp, gp, pp, pp, nn, hp, 1, NULL) != HR_E_INVALID) return 29;
+            nn[0] = 4; hp[5] = 0.0;
+            if (hr_adam_step(pp, gp, pp, pp, nn, hp, 1, NULL) != HR_E_INVALID) return 30;
+            if (hr_adam_step(NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) != HR_OK) return 31;
+        }
         { int64_t f = -1, c = -1; if (hr_shard_range(10, 1, 4, &f, &c) != HR_OK || f != 3 || c != 3) return 26; if (hr_shard_range(10, 4, 4, &f, &c) != HR_E_INVALID) return 27; }
     }
     return 0;

@@ -538,3 +538,34 @@ def test_train_mode_fields_come_from_the_training_forward(case):
     plain = min(ms(lambda: step(None)) for _ in range(2))
     with_fields = min(ms(lambda: step(['render_weights'])) for _ in range(2))
     assert with_fields <= 1.25 * plain + 0.05, (with_fields, plain)
+
+
+def test_fused_forward_survives_the_deterministic_mode_allocating_its_scratch():
+    """the one-launch forward keeps per-step weight tiles on the handle; the deterministic backward (re)allocates its fixed-point scratch on
+    first use.  Neither may touch the other's buffers: fused step, deterministic step, fused step again -- first and third forward equal
+    word for word (a mis-placed free released the tiles inside the scratch reallocation until round 4)"""
+    from gpu_common import make_render_fn
+    g = Golden('donerf_sphere_small')
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    fn.train()
+    m = fn.model
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays, np.float32)).cuda()
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def step(fused, det):
+        m.train_fused_mlp = fused
+        m.set_train_deterministic(det)
+        for p in params:
+            p.grad = None
+        out = m.forward_train(rays, white_bg=False)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone()
+
+    a = step(True, False)
+    step(False, True)
+    junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(8)]       # whatever was freed gets reused by now
+    b = step(True, False)
+    del junk
+    assert torch.isfinite(b).all() and torch.equal(a, b)
+    m.train_fused_mlp = False
