@@ -94,8 +94,10 @@ struct hr_model {
     float* rows = nullptr;   // input rows of the point MLP for one chunk: (chunk * casc_in_z, casc_row_dim)
     // training path (hr_train_*): the caller's configuration on the device and packed gradient accumulators
     hr_config* ucfg_dev = nullptr;
-    float* grad_a[3] = {};
+    float* grad_a[3] = {};               // training: packed texel-gradient accumulators of the plane pairs -- slices of grad_pool
     float* grad_b[3] = {};
+    float* grad_pool = nullptr;          // ONE allocation (cleared by one memset per step)
+    size_t grad_pool_bytes = 0;
     void* wsplit_t[HR_MAX_LAYERS] = {};  // training forward (hr_mlp_train_forward): bf16 split tiles of the CURRENT parameter values, re-packed on the device every step
     float* bias_t[HR_MAX_LAYERS] = {};
     int n_tiles_t[HR_MAX_LAYERS] = {};
@@ -1633,15 +1635,26 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
     if (!grads) return fail(HR_E_INVALID, "null grads");
     if (n_rays > 0 && (!head_dev || !d_rgb_dev || !d_head_dev)) return fail(HR_E_INVALID, "null head / d_rgb / d_head buffer");
     hipStream_t st = (hipStream_t)stream;
-    for (int j = 0; j < 3; ++j) {     // packed accumulators, allocated once, cleared per step on the stream
-        const HrGridPlane& g = m->planes[j];
-        if (g.tex == 0) continue;
-        const size_t a_bytes = sizeof(float) * (size_t)g.aw * g.ah * g.tex, b_bytes = sizeof(float) * (size_t)g.bw * g.bh * g.tex;
-        if (!m->grad_a[j]) HR_HIP(hipMalloc((void**)&m->grad_a[j], a_bytes));
-        if (!m->grad_b[j]) HR_HIP(hipMalloc((void**)&m->grad_b[j], b_bytes));
-        HR_HIP(hipMemsetAsync(m->grad_a[j], 0, a_bytes, st));
-        HR_HIP(hipMemsetAsync(m->grad_b[j], 0, b_bytes, st));
+    if (!m->grad_pool) {              // packed accumulators: one allocation, made on the first step
+        size_t off_a[3] = {}, off_b[3] = {}, total = 0;
+        for (int j = 0; j < 3; ++j) {
+            const HrGridPlane& g = m->planes[j];
+            if (g.tex == 0) continue;
+            off_a[j] = total; total += (sizeof(float) * (size_t)g.aw * g.ah * g.tex + 255) & ~(size_t)255;
+            off_b[j] = total; total += (sizeof(float) * (size_t)g.bw * g.bh * g.tex + 255) & ~(size_t)255;
+        }
+        if (total > 0) {
+            HR_HIP(hipMalloc((void**)&m->grad_pool, total));
+            m->grad_pool_bytes = total;
+            for (int j = 0; j < 3; ++j) {
+                if (m->planes[j].tex == 0) continue;
+                m->grad_a[j] = reinterpret_cast<float*>(reinterpret_cast<char*>(m->grad_pool) + off_a[j]);
+                m->grad_b[j] = reinterpret_cast<float*>(reinterpret_cast<char*>(m->grad_pool) + off_b[j]);
+            }
+        }
     }
+    // cleared per step on the stream, in one go (the deterministic mode overwrites them from its fixed-point sums instead)
+    if (m->grad_pool && !m->opt_train_det) HR_HIP(hipMemsetAsync(m->grad_pool, 0, m->grad_pool_bytes, st));
     const size_t basis_bytes = m->raw["basis_mat.weight"].bytes;
     // basis_mat's gradient needs no re-layout: accumulate in the caller's buffer (or a scratch nobody reads)
     float* d_basis = grads->basis;
@@ -1845,7 +1858,8 @@ void hr_model_destroy(hr_model* m)
     free_dev(reinterpret_cast<float*&>(m->occ_cells));
     if (m->kcfg_dev) (void)hipFree(m->kcfg_dev);
     if (m->ucfg_dev) (void)hipFree(m->ucfg_dev);
-    for (int j = 0; j < 3; ++j) { free_dev(m->grad_a[j]); free_dev(m->grad_b[j]); free_dev(m->frame_line[j]); }
+    free_dev(m->grad_pool);
+    for (int j = 0; j < 3; ++j) { m->grad_a[j] = m->grad_b[j] = nullptr; free_dev(m->frame_line[j]); }
     free_dev(m->tape);
     if (m->grad_fx) (void)hipFree(m->grad_fx);
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {          // the training forward's per-step weight tiles (hr_mlp_train_forward)

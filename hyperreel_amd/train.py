@@ -83,6 +83,7 @@ class SampleStage(torch.autograd.Function):
         ctx.save_for_backward(rays, head, basis, *tensors)
         return rgb
 
+    poison_outputs = False # tests: gradient buffers start as NaN instead of uninitialised memory
     want_fields = None     # set to z_channels right before apply() to make that call produce fields_out (single-threaded host code)
 
     @staticmethod
@@ -93,9 +94,14 @@ class SampleStage(torch.autograd.Function):
         dev = rays.device
         d_rgb = d_rgb.contiguous().float()
         d_head = torch.empty_like(head)
-        g_grids = [torch.zeros_like(g, memory_format=torch.contiguous_format) for g in grids]
-        g_basis = torch.zeros_like(basis, memory_format=torch.contiguous_format)
-        g_table = None if table is None else torch.zeros_like(table, memory_format=torch.contiguous_format)
+        # hr_train_backward writes every element of every gradient tensor (the re-layout of the packed texel gradients covers the whole
+        # (C, H, W) tensors; basis_mat's and the colour table's accumulators are cleared by the library on the stream): no zero fill here --
+        # thirteen fills of 48 MB per step otherwise.  `poison_outputs` (tests) fills them with NaN instead, which must not survive.
+        fresh = (lambda t: torch.full_like(t, float('nan'), memory_format=torch.contiguous_format)) if SampleStage.poison_outputs else \
+            (lambda t: torch.empty_like(t, memory_format=torch.contiguous_format))
+        g_grids = [fresh(g) for g in grids]
+        g_basis = fresh(basis)
+        g_table = None if table is None else fresh(table)
         gt = _tensors_struct([g_grids[0:3], g_grids[3:6], g_grids[6:9], g_grids[9:12]], g_basis, g_table)
         if g_basis.numel() == 0:
             raise RuntimeError('basis_mat has no columns')

@@ -569,3 +569,39 @@ def test_fused_forward_survives_the_deterministic_mode_allocating_its_scratch():
     del junk
     assert torch.isfinite(b).all() and torch.equal(a, b)
     m.train_fused_mlp = False
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'neural_3d_z_plane_small', 'immersive_sphere_small',
+                                  'sweep/bom_sphere', 'sweep/technicolor_cascaded', 'sweep/donerf_voxel', 'sweep/shiny_z_plane_feedback'])
+def test_backward_writes_every_gradient_element(case):
+    """SampleStage.backward hands hr_train_backward UNINITIALISED gradient tensors (no zero fill per step): with the buffers poisoned
+    instead, no NaN may survive and the gradients must equal the ordinary run's in the deterministic mode (bit for bit)"""
+    from gpu_common import make_render_fn
+    from hyperreel_amd import train as T
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    fn.train()
+    m = fn.model
+    try:
+        m.set_train_deterministic(True)
+        m.forward_train(torch.from_numpy(np.ascontiguousarray(g.rays[:8], np.float32)).cuda(), white_bg=False)
+    except (NotImplementedError, RuntimeError) as e:
+        pytest.skip(f'training path not offered for this model: {e}')
+    rays = torch.from_numpy(np.ascontiguousarray(g.rays, np.float32)).cuda()
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def grads(poison):
+        T.SampleStage.poison_outputs = poison
+        try:
+            for p in params:
+                p.grad = None
+            m.forward_train(rays, white_bg=False).square().mean().backward()
+            return [None if p.grad is None else p.grad.detach().clone() for p in params]
+        finally:
+            T.SampleStage.poison_outputs = False
+
+    a, b = grads(False), grads(True)
+    for ga, gb in zip(a, b):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert torch.isfinite(gb).all() and torch.equal(ga, gb)
