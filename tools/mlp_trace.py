@@ -5,6 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from hyperreel_amd import config as C, scenes, lib
 from hyperreel_amd.render import build_render_fn
+if os.environ.get('HR_LIB'):
+    lib.LIB_PATH = os.path.abspath(os.environ['HR_LIB'])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
 sd = scenes.make_state_dict(cfg, ds, [64, 64, 64], seed=7)
@@ -22,7 +24,7 @@ t = tr.cpu().numpy().astype(np.int64)
 ns = int((t[0] != 0).sum())
 t = t[:, :ns]
 d = np.diff(t, axis=1)
-names = ['prologue'] + sum([[f'L{l} gemm', f'L{l} barrier', f'L{l} epilogue+bar'] for l in range(5)], [])
+names = ['prologue'] + sum([[f'L{l} gemm', f'L{l} barrier'] + ([f'L{l} epilogue (own)', f'L{l} wait at barrier'] if os.environ.get('HR_FINE') else [f'L{l} epilogue+bar']) for l in range(5)], [])
 names += ['last p0 gemm', 'last p0 store', 'last p1 gemm', 'last p1 store']
 print(f'{nwg} workgroups of {tile} rays; stamps per wave {ns}; cycles (s_memtime, 100 MHz?) mean/median over waves')
 tot = (t[:, -1] - t[:, 0])
