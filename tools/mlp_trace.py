@@ -24,7 +24,7 @@ t = tr.cpu().numpy().astype(np.int64)
 ns = int((t[0] != 0).sum())
 t = t[:, :ns]
 d = np.diff(t, axis=1)
-names = ['prologue'] + sum([[f'L{l} gemm', f'L{l} barrier'] + ([f'L{l} epilogue (own)', f'L{l} wait at barrier'] if os.environ.get('HR_FINE') else [f'L{l} epilogue+bar']) for l in range(5)], [])
+names = ['prologue'] + sum([[f'L{l} gemm', f'L{l} barrier'] + ([f'L{l} first bias loads', f'L{l} epilogue (own, rest)', f'L{l} wait at barrier'] if os.environ.get('HR_FINE') else [f'L{l} epilogue+bar']) for l in range(5)], [])
 names += ['last p0 gemm', 'last p0 store', 'last p1 gemm', 'last p1 store']
 print(f'{nwg} workgroups of {tile} rays; stamps per wave {ns}; cycles (s_memtime, 100 MHz?) mean/median over waves')
 tot = (t[:, -1] - t[:, 0])
