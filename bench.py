@@ -191,6 +191,48 @@ def timed_frames(step, steps, warmup, multi, dist):
     return dt
 
 
+def prewarm(step, seconds, multi, dist):
+    """Replays `step` for about `seconds` of device time before anything is counted.  A fresh lease idles at 390 MHz and the power
+    manager takes ~15 frames (30-40 ms) to reach the steady clock (profiles/r05_headline_diag_*.json: 2.35 -> 1.98 ms per frame over the
+    first 15 replays of a process, again after 0.5 s of idling); 5 warm-up steps end inside that ramp.  Multi-rank: every rank runs the
+    SAME number of steps (the step holds a collective)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    per = max((time.perf_counter() - t0) / 8, 1e-5)
+    n = int(min(max(seconds / per, 8), 4000))
+    if multi:
+        t = torch.tensor([n], dtype=torch.int64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = int(t.item())
+    for i in range(n):
+        step()
+        if i % 32 == 31:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return n + 8
+
+
+def step_series(steps_by_name, n):
+    """One HIP event pair around EVERY step, the plans interleaved (A, B, A, B, ...) in one window: {name: {min, p50, p90, max, mean}} in ms.
+    Events are recorded on the stream the graphs replay on (torch's current stream)."""
+    ev = {k: [] for k in steps_by_name}
+    for _ in range(n):
+        for k, st in steps_by_name.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); st(); b.record()
+            ev[k].append((a, b))
+    torch.cuda.synchronize()
+    out = {}
+    for k, pairs in ev.items():
+        x = np.sort(np.asarray([a.elapsed_time(b) for a, b in pairs]))
+        out[k] = {'min': round(float(x[0]), 4), 'p50': round(float(np.percentile(x, 50)), 4), 'p90': round(float(np.percentile(x, 90)), 4),
+                  'max': round(float(x[-1]), 4), 'mean': round(float(x.mean()), 4), 'n': int(len(x))}
+    return out
+
+
 def capture(model, rays, frame_time=None):
     """One frame = hr_render's kernel launches, captured once into a hipGraph and replayed per step (the library neither
     allocates nor synchronises inside hr_render), so a slow host thread cannot starve the GPU between launches.
@@ -266,6 +308,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0, help='rays per internal workspace chunk (0 = library default)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--cpu-sample', type=int, default=640000, help='rays of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--prewarm', type=float, default=0.5, help='seconds of uncounted replays before the first warm-up step (clock ramp of an idle GPU; 0 = none)')
+    ap.add_argument('--windows', type=int, default=3, help='consecutive timed windows of exactly --steps steps each; value = their median')
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16f8', 'f16x2', 'fp32'],
@@ -274,8 +318,8 @@ def main():
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
     ap.add_argument('--lib', default='', help='measurement builds only (tools/build_variant.py): load this library instead of the in-tree one')
-    ap.add_argument('--frame-kernel', action='store_true', help='(default where the model fits) the persistent frame kernel, head tile in LDS')
-    ap.add_argument('--no-frame-kernel', action='store_true', help='two-kernel path through the HBM workspace instead')
+    ap.add_argument('--frame-kernel', action='store_true', help='opt-in plan: the persistent frame kernel, head tile in LDS')
+    ap.add_argument('--no-frame-kernel', action='store_true', help='(default) two-kernel path through the HBM workspace')
     ap.add_argument('--frame-mode', type=int, default=1, choices=[1, 2], help='HR_OPT_FRAME_KERNEL: 1 = the frame kernel where it is the faster plan (static nets), 2 = wherever the model fits it (keyframe families on 32-ray tiles)')
     ap.add_argument('--sample-waves', type=int, default=0, choices=[0, 4, 8], help='sample wavefronts per workgroup of the frame kernel (0 = library default)')
     args = ap.parse_args()
@@ -319,12 +363,20 @@ def main():
         f.model.native()
         return f
 
-    use_frame = False if args.no_frame_kernel else (2 if args.frame_mode == 2 else True)
+    def headline(step):
+        """value's window: uncounted pre-warm by time, then --windows consecutive windows of W warm-up + EXACTLY K timed steps (barrier +
+        synchronize on both sides, max over ranks); the median window is the figure, all of them are printed."""
+        n_pre = prewarm(step, args.prewarm, multi, dist) if args.prewarm > 0 else 0
+        wins = [timed_frames(step, args.steps, args.warmup, multi, dist) for _ in range(max(1, args.windows))]
+        return sorted(wins)[(len(wins) - 1) // 2], wins, n_pre
+
+    use_frame = (2 if args.frame_mode == 2 else True) if (args.frame_kernel and not args.no_frame_kernel) else False
     fn = make(args.mlp_precision, use_frame)
     model = fn.model
     strong = args.scaling == 'strong' and multi
     Z = cfg['embedding']['embeddings']['ray_prediction_0']['z_channels']
 
+    graph = None
     if not strong:
         # tile of this rank: the same camera, panned by the tile index (weak scaling)
         rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
@@ -335,7 +387,6 @@ def main():
         rays = torch.from_numpy(rays_np).cuda()
         B = rays.shape[0]
         gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if multi else None
-        graph = None
         if not args.no_graph:
             graph, rgb_static = capture(model, rays)
 
@@ -349,7 +400,7 @@ def main():
                 dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))
             return out
 
-        dt = timed_frames(step, args.steps, args.warmup, multi, dist)
+        dt, windows, n_pre = headline(step)
         rgb = step()
         torch.cuda.synchronize()
         total_rays = B * world
@@ -376,7 +427,7 @@ def main():
         else:       # one hipGraph per tile buffer: a step is a graph launch + the all-gather enqueue
             step = pipe.capture(lambda tile: model.render(rays, out=tile))
 
-        dt = timed_frames(step, args.steps, args.warmup, multi, dist)
+        dt, windows, n_pre = headline(step)
         # host time per frame: how long the CPU needs to enqueue a step (no synchronisation inside the loop) -- the floor a rank's
         # frame time cannot go below however little of the frame it renders
         torch.cuda.synchronize()
@@ -394,6 +445,8 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rays / (dt / args.steps) / 1e6
+    # every step of one more window with its own event pair: a stall (clock dip, a neighbour's SMI poll) shows as max >> p50 in the line itself
+    series = step_series({'value_path': step}, max(args.steps, 20))
     # the fp16 split arithmetic was chosen on calibration rays: the kernels' sticky overflow bit must be clear on the rays that were timed
     # (render() checks it on the first batches and falls back to bf16x3, models.py _overflow_guard; a replayed graph cannot)
     if model.mlp_overflowed():
@@ -404,6 +457,9 @@ def main():
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32 storage / accumulate; MLP GEMM operands: see mlp_gemm', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
+        'windows_ms_per_step': [round(w / args.steps * 1e3, 4) for w in windows],
+        'value_rule': f'median of {len(windows)} consecutive windows of exactly {args.steps} steps (each after {args.warmup} warm-up steps), wall clock, max over ranks',
+        'step_ms': series,
         'config': {'workload': f'BASELINE configs[1]: DoNeRF static ({args.model}), {args.height}x{args.width} frame '
                                f'= {args.height * args.width} rays, {Z} samples/ray, grid {grid[0]}x{grid[1]}x{grid[2]}, single forward render',
                    'rays_per_gpu': rays_per_gpu, 'parallelism': parallelism, 'frame_ms': round(ms_per_step, 4),
@@ -535,6 +591,11 @@ def main():
         if other.model.frame_kernel_active() != model.frame_kernel_active():
             v, ms = quick(other)
             same = bool(torch.equal(other.model.render(rays)['rgb'], rgb))
+            if graph is not None:       # the two plans in ONE window, interleaved replay by replay, an event pair around each
+                g_other, _ = capture(other.model, rays)
+                ab = step_series({'value_path': graph.replay, 'other_plan': g_other.replay}, 100)
+                result['step_ms_interleaved'] = {'value_path': ab['value_path'], 'frame_kernel' if other.model.frame_kernel_active() else 'two_kernel_path': ab['other_plan']}
+                del g_other
             result['frame_kernel' if other.model.frame_kernel_active() else 'two_kernel_path'] = {
                 'value': round(v, 3), 'unit': 'Mrays/s', 'ms_per_step': round(ms, 4), 'bit_identical_to_value_path': same,
                 'what': 'ONE persistent kernel per frame: MLP wavefronts hand the 64-ray head tile to sample wavefronts of the same workgroup '
@@ -619,6 +680,7 @@ def main():
     result['grid_dtype'] = args.grid_dtype
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else \
         ('hipGraph replay of this rank\'s captured render + all-gather enqueued from Python on the side stream' if strong else 'hipGraph replay of one captured frame')
+    result['config']['launch'] += f'; {n_pre} uncounted pre-warm steps (~{args.prewarm} s: the idle GPU\'s clock ramp) before the first warm-up step'
     result['dtype'] = {'bf16x3': 'f32 storage/accumulate; GEMM operands bf16x3 split', 'f16x3': 'f32 storage/accumulate; GEMM operands f16x3 split',
                        'f16x2': 'f32 storage/accumulate; GEMM operands f16x2 (weights rounded to half)',
                        'f16f8': 'f32 storage/accumulate; GEMM operands f16 (leading product) + fp8 e4m3 (correction products)', 'fp32': 'f32'}[prec_name]

@@ -114,7 +114,8 @@ struct hr_model {
     // execution plan of hr_render (hr_model_set_option)
     int frame_row = -1;                  // hr_render_frame: >= 0 while a call renders from frame_line[] (-1: general path)
     float* frame_line[3] = {nullptr, nullptr, nullptr};   // the frame's blended keyframe rows, one line per time plane (float32 texels)
-    int opt_frame_kernel = 1;              // measured equal-or-faster than the two-kernel path where it applies, at 1/20 of the HBM traffic
+    int opt_frame_kernel = 0;              // two kernels per chunk: level with the frame kernel since K1 took buffer loads (1.96 vs 1.99 ms per DoNeRF frame, interleaved
+                                           // events, profiles/r05_headline_diag_*.json) and with the tighter tail (hardware block dispatch instead of a static tile deal)
     int opt_sample_waves = HR_DEFAULT_SAMPLE_WAVES;
     int n_cus = 0;
 };

@@ -370,7 +370,7 @@ class HipLightfieldModel(nn.Module):
         # gathered nor composited -- the reference's own test at tensorf_no_sample.py:171-177, which it ships disabled
         self.use_occupancy = bool(kwargs.get('use_occupancy', False))
         self._occ_key = None
-        self.frame_kernel = self._frame_mode(kwargs.get('frame_kernel', True))
+        self.frame_kernel = self._frame_mode(kwargs.get('frame_kernel', False))
         self.sample_waves = kwargs.get('sample_waves')
         self.train_deterministic = bool(kwargs.get('train_deterministic', False))
         self.train_fused_mlp = bool(kwargs.get('train_fused_mlp', False))
@@ -598,7 +598,7 @@ class HipLightfieldModel(nn.Module):
 
     @staticmethod
     def _frame_mode(v):
-        """HR_OPT_FRAME_KERNEL: False / 0 = two kernels, True / 1 = the frame kernel where it fits and is the faster plan (default),
+        """HR_OPT_FRAME_KERNEL: False / 0 = two kernels (default), True / 1 = the frame kernel for the static nets it fits on 64-ray tiles,
         2 = wherever it fits"""
         return 2 if (v == 2 and v is not True) else int(bool(v))
 
@@ -611,8 +611,8 @@ class HipLightfieldModel(nn.Module):
 
     def set_execution(self, frame_kernel=None, sample_waves=None):
         """Chooses how render() is laid out on the device (images are bit-identical under every setting):
-        frame_kernel False = always the two-kernel path through the HBM workspace, True = the persistent frame kernel where
-        it is the faster plan, 2 = wherever the model fits it; sample_waves 4 | 8."""
+        frame_kernel False = the two-kernel path through the HBM workspace (default), True = the persistent frame kernel for the static
+        nets (64-ray tiles), 2 = wherever the model fits it; sample_waves 4 | 8."""
         if frame_kernel is not None:
             self.frame_kernel = self._frame_mode(frame_kernel)
         if sample_waves is not None:

@@ -79,7 +79,7 @@ def render_chunked(rays, render_fn, render_kwargs, chunk):
 
 
 def build_render_fn(model_cfg, dataset=None, system=None, grid_size=None, net_chunk=32768, device='cuda',
-                    mlp_precision='auto', grid_dtype='fp32', frame_kernel=True, sample_waves=None, use_occupancy=False, train_deterministic=False, train_fused_mlp=False):
+                    mlp_precision='auto', grid_dtype='fp32', frame_kernel=False, sample_waves=None, use_occupancy=False, train_deterministic=False, train_fused_mlp=False):
     """What INRSystem.__init__ does for the render path (nlf/__init__.py:350-364):
     model_dict[cfg.type](cfg, system=...) -> render_fn_dict[cfg.render.type](model, None, cfg.render, net_chunk=...)."""
     kwargs = {'system': system, 'mlp_precision': mlp_precision, 'grid_dtype': grid_dtype, 'frame_kernel': frame_kernel,

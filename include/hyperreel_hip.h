@@ -285,7 +285,10 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
 
 /* Execution plan of hr_render.  The arithmetic is the same under every setting (bit-identical images); the options choose
  * how it is laid out on the device.
- *   HR_OPT_FRAME_KERNEL   1 (default): models whose head tile fits the CU's LDS are rendered by ONE persistent kernel in which
+ *   HR_OPT_FRAME_KERNEL   0 (default): two kernels per chunk of rays -- the MLP writes the head to an HBM workspace, the sample kernel
+ *                         reads it back.  Level in time with the frame kernel (round 5, interleaved per-frame events: 1.96 vs 1.99 ms
+ *                         on the DoNeRF frame) and with the tighter tail: the hardware dispatches its blocks, nothing is dealt statically.
+ *                         1: models whose head tile fits the CU's LDS are rendered by ONE persistent kernel in which
  *                         MLP wavefronts hand the (B, Z*P) head that the reference materialises between RayPredictionEmbedding and
  *                         Intersect (nlf/embedding/ray.py:332-337 -> nlf/intersect/base.py:142-259) to sample wavefronts of the
  *                         same workgroup through LDS -- no workspace traffic (static nets, 64-ray tiles).  Models that do not
@@ -294,8 +297,6 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         2: additionally the keyframe families (480-column heads, 960 at 64 samples per ray;
  *                         nlf/nets/tensorf_dynamic.py:645-839) on 32-ray tiles, two head buffers where they fit: same images, no
  *                         head workspace traffic, measured as fast as or slower than two kernels (hence not part of 1).
- *                         0: always two kernels per chunk of rays -- the MLP writes the head to an HBM workspace, the sample
- *                         kernel reads it back.
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default, 8).
  *   HR_OPT_TRAIN_DETERMINISTIC  1: hr_train_backward accumulates every gradient that many samples add to -- texel gradients, basis_mat's,
  *                         the colour table's -- as 64-bit fixed point (2^-40 units) with integer atomics instead of fp32 atomics: the

@@ -25,7 +25,13 @@ from unittest.mock import MagicMock
 import torch
 import yaml
 
-REF = "/root/reference"
+import contextlib
+import os
+
+# HR_REF_ROOT: where the reference tree lies (the authoring container: /root/reference; a GPU lease: a copy shipped for ONE timing run,
+# oracle/refgen/time_reference_gpu.py).  HR_REF_DEVICE=cuda: no cuda -> cpu rewrite -- the reference runs on the device it asks for.
+REF = os.environ.get('HR_REF_ROOT', "/root/reference")
+ON_CUDA = os.environ.get('HR_REF_DEVICE', 'cpu') == 'cuda'
 
 
 class AttrDict(dict):
@@ -96,6 +102,8 @@ def install():
         if name not in sys.modules or name.startswith(('pytorch3d', 'kornia', 'cv2', 'torchvision',
                                                          'skimage', 'plyfile', 'lpips')):
             sys.modules[name] = MagicMock()
+    if ON_CUDA:
+        return
     # .cuda() no-ops
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
@@ -127,7 +135,7 @@ def _module_to(self, *args, **kwargs):
 
 
 def cpu_mode():
-    return _CpuMode()
+    return contextlib.nullcontext() if ON_CUDA else _CpuMode()
 
 
 def load_model_cfg(name, overrides=None, iters_per_epoch=4000):

@@ -27,3 +27,35 @@ def render_np(fn, rays, want=()):
     out = fn.model.render(r, want=want)
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+# ---- the poison kernel (tests/c_abi/poison.hip): test infrastructure, built in-tree by __graft_entry__.build() so that it travels
+POISON_SRC = __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'c_abi', 'poison.hip')
+POISON_LIB = __import__('os').path.join(__import__('os').path.dirname(POISON_SRC), '_build', 'libhr_poison.so')
+
+
+def build_poison(force=False):
+    """hipcc --offload-arch=gfx950 tests/c_abi/poison.hip -> tests/c_abi/_build/libhr_poison.so (cross-compiles without a GPU)."""
+    import os
+    import subprocess
+    from hyperreel_amd.build import hipcc
+    if not force and os.path.exists(POISON_LIB) and os.path.getmtime(POISON_LIB) >= os.path.getmtime(POISON_SRC):
+        return POISON_LIB
+    os.makedirs(os.path.dirname(POISON_LIB), exist_ok=True)
+    subprocess.run([hipcc(), '--offload-arch=gfx950', '-O2', '-shared', '-fPIC', POISON_SRC, '-o', POISON_LIB], check=True)
+    return POISON_LIB
+
+
+class Poison:
+    """poison(pattern): every VGPR and LDS word of every CU holds `pattern` when the next kernel of the current stream starts."""
+
+    def __init__(self):
+        import ctypes
+        self.lib = ctypes.CDLL(build_poison())
+        self.lib.hr_poison.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.hr_poison.restype = ctypes.c_int
+        self.touched = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def __call__(self, pattern):
+        rc = self.lib.hr_poison(int(pattern) & 0xFFFFFFFF, self.touched.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, f'hr_poison: {rc}'

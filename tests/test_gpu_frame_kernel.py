@@ -38,7 +38,9 @@ def _render(fn, rays_t, frame_kernel, sample_waves=None):
 @pytest.mark.parametrize('case', FUSABLE)
 def test_fusable_models_take_the_frame_kernel(case):
     g, fn = _fns(case)
-    assert fn.model.frame_kernel_active()              # the default plan where the head tile fits
+    assert not fn.model.frame_kernel_active()          # the default plan is two kernels per chunk (round 5: level in time, tighter tail)
+    fn.model.set_execution(frame_kernel=True)
+    assert fn.model.frame_kernel_active()              # opt-in: fits wherever the head tile fits
     fn.model.set_execution(frame_kernel=False)
     assert not fn.model.frame_kernel_active()
     fn.model.set_execution(frame_kernel=True)
