@@ -712,6 +712,17 @@ def main():
             'what': 'the reference algorithm as stock PyTorch-ROCm ops (grid_sample, addmm, sort, cumprod) on the same MI355X',
             'speedup_of_value': round(value / best[0], 1),
             'linf_vs_hip': float((out_t - rgb).abs().max())}
+        try:     # the REFERENCE ITSELF, timed once on an MI355X lease next to this port (oracle/refgen/time_reference_gpu.py): the port's calibration
+            cal = json.load(open(os.path.join(ROOT, 'profiles', 'r05_gpu_calibration.json')))
+            run = max(cal['runs'], key=lambda r: r['reference_mrays_s'])
+            result['pytorch_gpu_baseline']['calibration'] = {
+                'source': 'profiles/r05_gpu_calibration.json: /root/reference shipped to one MI355X lease, render_chunked over this frame, no cuda->cpu rewrite',
+                'reference_mrays_s': round(run['reference_mrays_s'], 3), 'port_mrays_s': round(run['port_mrays_s'], 3), 'chunk': run['chunk'],
+                'port_over_reference': round(run['port_over_reference'], 3), 'linf_port_vs_reference': run['linf_port_vs_reference'],
+                'linf_hip_vs_reference_full_frame': run['linf_hip_vs_reference'], 'rays_over_1e-4_hip_vs_reference': run['rays_over_1e-4_hip_vs_reference']}
+            result['pytorch_gpu_baseline']['speedup_of_value_vs_reference_itself'] = round(value / (best[0] / run['port_over_reference']), 1)
+        except (OSError, KeyError, ValueError):
+            pass
 
     if extras and args.model == 'donerf_sphere':
         try:

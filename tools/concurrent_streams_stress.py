@@ -26,4 +26,9 @@ for case, gd in (('immersive_sphere_small', 'fp32'), ('donerf_sphere_small', 'fp
                         f.model.render(rays, out=o)
             torch.cuda.synchronize()
             bad += int(not (torch.equal(outs[0], ref) and torch.equal(outs[1], ref)))
+            for i, o in enumerate(outs):
+                if not torch.equal(o, ref):
+                    rr = (o != ref).any(-1).nonzero().flatten().cpu().numpy()
+                    print(f'    iter {it} model {i}: {len(rr)} rays differ: {rr[:8].tolist()} (ray % 8 = {(rr[:8] % 8).tolist()}), max |d| {float((o - ref).abs().max()):.3e}, '
+                          f'got {o[rr[0]].cpu().numpy().tolist()} alone {ref[rr[0]].cpu().numpy().tolist()}', flush=True)
         print(case, gd, 'plan', 'frame_kernel' if fns[0].model.frame_kernel_active() else 'two_kernels', 'runs with a differing image:', bad, '/ 40', flush=True)
