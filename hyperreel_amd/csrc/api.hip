@@ -71,6 +71,18 @@ struct hr_model {
     float act_max[HR_MAX_LAYERS] = {};    // calibration: max |input feature|, max |pre-activation| of hidden Linear l - 1
     int calibrated = 0;                   // 0: not calibrated (cascade rows / unsupported width), 1: synthetic rays (finalize), 2: the caller's rays
     unsigned* flags = nullptr;            // sticky device status word (HrMlpArgs::flags)
+    // verified fast path: the MLP runs f16f8, rays with a comparison at risk (or a range bit) are listed on the device and rendered
+    // again with the f16x3 tiles below by a second, list-driven pass at the end of hr_render
+    int verified = 0;
+    void* wsplit_safe[HR_MAX_LAYERS] = {};
+    float* bias_safe[HR_MAX_LAYERS] = {};
+    float winv_safe[HR_MAX_LAYERS] = {};
+    int n_tiles_safe[HR_MAX_LAYERS] = {};
+    int64_t mlp_bytes_safe = 0;
+    int* redo_list = nullptr;
+    unsigned* redo_count = nullptr;
+    int redo_cap = 0;
+    float redo_band = 0.0f;
     int64_t mlp_bytes = 0;
     // packed grids
     float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
@@ -204,7 +216,7 @@ int validate(const hr_config& c, bool coarse = false)
     for (int i = 0; i < 3; ++i)
         if (c.grid[i] < 2) return fail(HR_E_INVALID, "grid size must be >= 2 on every axis");
     if (c.shading == HR_SHADING_RGB ? c.app_dim != 3 : c.app_dim != 27) return fail(HR_E_INVALID, "app_dim must be 3 (RGB) or 27 (SH)");
-    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16F8) return fail(HR_E_INVALID, "unknown mlp_precision");
+    if (c.mlp_precision < HR_MLP_FP32 || c.mlp_precision > HR_MLP_F16F8V) return fail(HR_E_INVALID, "unknown mlp_precision");
     if (c.mlp_layers != 0 && c.mlp_precision != HR_MLP_FP32 && c.mlp_precision != HR_MLP_AUTO && c.mlp_hidden != 256)      // (AUTO resolves to fp32 there)
         return fail(HR_E_INVALID, "the split (bf16x3 / f16x3) MLP needs mlp_hidden == 256");
     if (c.grid_dtype != HR_GRID_FP32 && c.grid_dtype != HR_GRID_FP16) return fail(HR_E_INVALID, "unknown grid_dtype");
@@ -505,12 +517,20 @@ static void f8_exponents(hr_model* m)
     }
 }
 
-static int pack_mlp(hr_model* m)
+struct HrPackOut {                       // where one packing of the MLP goes (the model's primary tiles, or the verified path's f16x3 ones)
+    float4** wpack;
+    void** wsplit;
+    float** bias;
+    float* winv;
+    int* n_tiles;
+    int64_t* bytes;
+};
+
+static int pack_mlp_as(hr_model* m, const int precision, const HrPackOut o)
 {
-    f8_exponents(m);
     const hr_config& c = m->cfg;
     char name[64];
-    m->mlp_bytes = 0;
+    *o.bytes = 0;
     // ---- MLP: MFMA B-operand tiles (layout documented in hr_kernels.h)
     const int W = c.mlp_hidden;
     m->k0p = (c.mlp_in + 15) & ~15;
@@ -526,9 +546,9 @@ static int pack_mlp(hr_model* m)
         const bool first = (l == 0);
         const bool skip = (c.mlp_skip_mask >> l) & 1;
         const int Kp = first ? m->k0p : (skip ? m->k0p + W : W);
-        const bool split = (m->active_precision != HR_MLP_FP32);
-        const bool f8lo = (m->active_precision == HR_MLP_F16F8);
-        const bool half = (m->active_precision == HR_MLP_F16X3 || m->active_precision == HR_MLP_F16X2 || f8lo);
+        const bool split = (precision != HR_MLP_FP32);
+        const bool f8lo = (precision == HR_MLP_F16F8);
+        const bool half = (precision == HR_MLP_F16X3 || precision == HR_MLP_F16X2 || f8lo);
         const int tile_n = split ? 32 : 16;
         const int nt = (N + tile_n - 1) / tile_n;
         std::vector<float> w((size_t)N_user * Kt), b(N_user);
@@ -552,15 +572,15 @@ static int pack_mlp(hr_model* m)
             const int row = last ? (n / P_live) * P_user + live_cols[n % P_live] : n;
             return w[(size_t)row * Kt + col];
         };
-        free_dev(reinterpret_cast<float*&>(m->wpack[l]));
-        free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
-        free_dev(m->bias[l]);
+        if (o.wpack) free_dev(reinterpret_cast<float*&>(o.wpack[l]));
+        free_dev(reinterpret_cast<float*&>(o.wsplit[l]));
+        free_dev(o.bias[l]);
         // fp16 modes: the weights of these MLPs are ~1/sqrt(fan_in), so the low half w - half(w) (~2^-12 w) would be a
         // subnormal half with an ABSOLUTE rounding error of 2^-25.  Packing w * 2^s (exact), with s putting the largest
         // weight of the layer into [2^13, 2^14), keeps every low half of a weight above max|w| * 2^-16 normal; the
         // epilogue multiplies the accumulator by 2^-s (exact again).  bf16 halves have the fp32 exponent range: s = 0.
         float wmul = 1.0f;
-        m->winv[l] = 1.0f;
+        o.winv[l] = 1.0f;
         if (half) {
             float mx = 0.0f;
             for (float v : w) mx = fmaxf(mx, fabsf(v));
@@ -570,7 +590,7 @@ static int pack_mlp(hr_model* m)
                 int sft = 14 - e;
                 sft = sft < -14 ? -14 : (sft > 40 ? 40 : sft);
                 wmul = ldexpf(1.0f, sft);
-                m->winv[l] = ldexpf(1.0f, -sft);
+                o.winv[l] = ldexpf(1.0f, -sft);
             }
         }
         if (!split) {
@@ -580,9 +600,9 @@ static int pack_mlp(hr_model* m)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int s = 0; s < 4; ++s)
                             pk[(((size_t)kt * nt + t) * 64 + lane) * 4 + s] = wk(16 * t + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
-            HR_HIP(hipMalloc((void**)&m->wpack[l], pk.size() * sizeof(float)));
-            HR_HIP(hipMemcpy(m->wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-            m->mlp_bytes += (int64_t)pk.size() * sizeof(float);
+            HR_HIP(hipMalloc((void**)&o.wpack[l], pk.size() * sizeof(float)));
+            HR_HIP(hipMemcpy(o.wpack[l], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+            *o.bytes += (int64_t)pk.size() * sizeof(float);
         } else {
             // hi = bf16(w), lo = bf16(w - hi), both round-to-nearest-even (layout: hr_kernels.h)
             std::vector<uint16_t> pk((size_t)(Kp / 16) * nt * 2 * 64 * 8, 0);
@@ -613,18 +633,54 @@ static int pack_mlp(hr_model* m)
                                 bytes[at + 8 + j] = e4m3_rne(ldexpf(v, -6));
                             }
             }
-            HR_HIP(hipMalloc((void**)&m->wsplit[l], pk.size() * sizeof(uint16_t)));
-            HR_HIP(hipMemcpy(m->wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            m->mlp_bytes += (int64_t)pk.size() * sizeof(uint16_t);
+            HR_HIP(hipMalloc((void**)&o.wsplit[l], pk.size() * sizeof(uint16_t)));
+            HR_HIP(hipMemcpy(o.wsplit[l], pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            *o.bytes += (int64_t)pk.size() * sizeof(uint16_t);
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
         for (int i = 0; i < N; ++i) bp[i] = b[last ? (i / P_live) * P_user + live_cols[i % P_live] : i];
-        HR_HIP(hipMalloc((void**)&m->bias[l], nb * sizeof(float)));
-        HR_HIP(hipMemcpy(m->bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
-        m->n_tiles[l] = nt;
-        m->mlp_bytes += (int64_t)nb * sizeof(float);
+        HR_HIP(hipMalloc((void**)&o.bias[l], nb * sizeof(float)));
+        HR_HIP(hipMemcpy(o.bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+        o.n_tiles[l] = nt;
+        *o.bytes += (int64_t)nb * sizeof(float);
     }
+    return HR_OK;
+}
+
+static void free_safe_pack(hr_model* m)
+{
+    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+        free_dev(reinterpret_cast<float*&>(m->wsplit_safe[l]));
+        free_dev(m->bias_safe[l]);
+    }
+    m->mlp_bytes_safe = 0;
+}
+
+// the primary tiles in the active arithmetic, and -- verified fast path -- the f16x3 tiles of the second pass
+static int pack_mlp(hr_model* m)
+{
+    f8_exponents(m);
+    m->k0p = (m->cfg.mlp_in + 15) & ~15;
+    m->n_out = samples_per_row(m->cfg) * m->p_live;
+    int64_t b1 = 0;
+    int rc = pack_mlp_as(m, m->active_precision, HrPackOut{m->wpack, m->wsplit, m->bias, m->winv, m->n_tiles, &b1});
+    if (rc != HR_OK) return rc;
+    free_safe_pack(m);
+    if (m->verified) {
+        rc = pack_mlp_as(m, HR_MLP_F16X3, HrPackOut{nullptr, m->wsplit_safe, m->bias_safe, m->winv_safe, m->n_tiles_safe, &m->mlp_bytes_safe});
+        if (rc != HR_OK) return rc;
+        if (!m->redo_count) HR_HIP(hipMalloc((void**)&m->redo_count, 2 * sizeof(unsigned)));      // [0]: the counter, [1]: the second pass's copy
+        HR_HIP(hipMemset(m->redo_count, 0, 2 * sizeof(unsigned)));
+        // a comparison is "at risk" within this length (HrRisk::band): 2.5e-6 of the scene's extent -- the largest |d distance| between
+        // f16f8 and f16x3 measured on the four 800x800 benchmark frames (160 M samples) is 7e-7 in scenes of extent 2 (tools/band_probe.py,
+        // profiles/r05_band_probe.json), and the z-plane families have live samples from 1e-5 of `near` on
+        float ext = 1.0f;
+        for (int i = 0; i < 6; ++i) if (std::isfinite(m->cfg.aabb[i])) ext = fmaxf(ext, fabsf(m->cfg.aabb[i]));
+        ext = fmaxf(ext, std::isfinite(m->cfg.near) ? fabsf(m->cfg.near) : 0.0f);
+        m->redo_band = 2.5e-6f * ext;
+    }
+    m->mlp_bytes = b1 + m->mlp_bytes_safe;
     return HR_OK;
 }
 
@@ -641,6 +697,7 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     const int want = c.mlp_precision;
     for (int l = 0; l < HR_MAX_LAYERS; ++l) m->act_max[l] = 0.0f;
     m->calibrated = 0;
+    m->verified = 0;
     if (c.mlp_layers == 0 || want == HR_MLP_FP32 || want == HR_MLP_BF16X3) {
         m->active_precision = (c.mlp_layers == 0 && want == HR_MLP_AUTO) ? HR_MLP_F16X3 : want;
         return HR_OK;
@@ -703,15 +760,23 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
         mx = fmaxf(mx, m->act_max[l]);
     }
     const bool fits = finite && mx < HR_F16_CALIBRATION_LIMIT;
+    // the verified fast path: f16f8 + a list-driven second pass in f16x3.  What it needs: a ray's samples inside one wavefront
+    // (the list entry is written from a wave-level vote), no cascade (the point MLP's rows are internal), no occupancy-dependent structure
+    const bool can_verify = !m->coarse && !m->is_coarse && c.z_channels <= 64 && c.mlp_layers >= 2 && c.mlp_hidden == 256;
+    m->verified = 0;
     if (want == HR_MLP_AUTO) {
-        m->active_precision = fits ? HR_MLP_F16X3 : HR_MLP_BF16X3;
+        m->active_precision = fits ? (can_verify ? HR_MLP_F16F8 : HR_MLP_F16X3) : HR_MLP_BF16X3;
+        m->verified = (fits && can_verify) ? 1 : 0;
         return HR_OK;
     }
+    if (want == HR_MLP_F16F8V && !can_verify)
+        return fail(HR_E_INVALID, "mlp_precision f16f8v (verified) needs a plain ray MLP of width 256 and at most 64 samples per ray");
     if (!fits)
         return fail(HR_E_RANGE, "mlp_precision %s was requested, but the MLP's activations reach %.4g on the calibration rays (limit %.4g = "
                     "65504 / 8): IEEE-half operands would overflow.  Use HR_MLP_AUTO (falls back to bf16x3) or HR_MLP_BF16X3",
                     want == HR_MLP_F16X3 ? "f16x3" : (want == HR_MLP_F16X2 ? "f16x2" : "f16f8"), (double)mx, (double)HR_F16_CALIBRATION_LIMIT);
-    m->active_precision = want;
+    m->active_precision = (want == HR_MLP_F16F8V) ? HR_MLP_F16F8 : want;
+    m->verified = (want == HR_MLP_F16F8V) ? 1 : 0;
     return HR_OK;
 }
 
@@ -867,19 +932,20 @@ int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float
     if (!m->finalized) return fail(HR_E_STATE, "hr_model_calibrate before hr_model_finalize");
     if (m->coarse || m->is_coarse) return fail(HR_E_INVALID, "hr_model_calibrate: cascades are calibrated by hr_model_finalize (the point MLP's rows are internal)");
     if (!rays_dev || n_rays <= 0) return fail(HR_E_INVALID, "hr_model_calibrate needs rays");
-    const int before = m->active_precision, calibrated_before = m->calibrated;
+    const int before = m->active_precision, calibrated_before = m->calibrated, verified_before = m->verified;
     float act_before[HR_MAX_LAYERS];
     for (int l = 0; l < HR_MAX_LAYERS; ++l) act_before[l] = m->act_max[l];
     int rc = resolve_precision(m, rays_dev, n_rays, (hipStream_t)stream);
     if (rc != HR_OK) {                         // the model stays exactly as it was
         m->active_precision = before;
+        m->verified = verified_before;
         m->calibrated = calibrated_before;
         for (int l = 0; l < HR_MAX_LAYERS; ++l) m->act_max[l] = act_before[l];
         return rc;
     }
     HR_HIP(hipMemset(m->flags, 0, sizeof(unsigned)));
     f8_exponents(m);
-    if (m->active_precision != before) {
+    if (m->active_precision != before || m->verified != verified_before) {
         m->packed_bytes -= m->mlp_bytes;
         rc = pack_mlp(m);
         if (rc != HR_OK) return rc;
@@ -940,32 +1006,50 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
         HR_HIP(hipMalloc((void**)&m->rows, sizeof(float) * n_rows * m->cfg.casc_row_dim));
     }
     m->chunk = rays_per_chunk;
+    // verified fast path: the list of rays the second pass renders again.  Capacity: 10 % of a 640 000-ray frame (measured: 0.05 - 3 %), never
+    // more than a chunk (the second pass uses the chunk's head workspace); beyond it the kernels raise bit 2 of the status word (HR_OPT_REDO_OVERFLOW)
+    free_dev(reinterpret_cast<float*&>(m->redo_list));
+    m->redo_cap = (int)(rays_per_chunk < 65536 ? rays_per_chunk : 65536);
+    HR_HIP(hipMalloc((void**)&m->redo_list, sizeof(int) * (size_t)m->redo_cap));
+    if (!m->redo_count) {
+        HR_HIP(hipMalloc((void**)&m->redo_count, 2 * sizeof(unsigned)));
+        HR_HIP(hipMemset(m->redo_count, 0, 2 * sizeof(unsigned)));
+    }
     return HR_OK;
 }
 
-static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st)
+// safe: the verified fast path's f16x3 tiles (fill_mlp_args(..., true)) instead of the model's primary arithmetic
+static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st, bool safe = false)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
-    if (m->active_precision == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
-    else if (m->active_precision == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
-    else if (m->active_precision == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
-    else if (m->active_precision == HR_MLP_F16F8) hr_launch_mlp_f16f8(c, a, st);
+    const int prec = safe ? HR_MLP_F16X3 : m->active_precision;
+    if (prec == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
+    else if (prec == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
+    else if (prec == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
+    else if (prec == HR_MLP_F16F8) hr_launch_mlp_f16f8(c, a, st);
     else hr_launch_mlp(c, a, st);
 }
 
-static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n)
+static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n, bool safe = false)
 {
     a.rays = rays;
     a.n_rays = n;
     a.head = m->head;
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         a.wpack[l] = m->wpack[l];
-        a.wsplit[l] = m->wsplit[l];
-        a.bias[l] = m->bias[l];
-        a.winv[l] = m->winv[l];
-        a.xexp[l] = m->xexp[l];
-        a.n_tiles[l] = m->n_tiles[l];
+        a.wsplit[l] = safe ? m->wsplit_safe[l] : m->wsplit[l];
+        a.bias[l] = safe ? m->bias_safe[l] : m->bias[l];
+        a.winv[l] = safe ? m->winv_safe[l] : m->winv[l];
+        a.xexp[l] = safe ? 0 : m->xexp[l];
+        a.n_tiles[l] = safe ? m->n_tiles_safe[l] : m->n_tiles[l];
     }
+    a.ray0 = 0;
+    a.ray_index = nullptr;
+    a.n_rays_dev = nullptr;
+    a.n_rays_copy = nullptr;
+    a.redo_list = nullptr;
+    a.redo_count = nullptr;
+    a.redo_cap = 0;
     a.n_out = m->n_out;
     a.nq = (m->n_out + 3) / 4;
     a.k0p = m->k0p;
@@ -1010,6 +1094,15 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
         if (it != m->raw.end()) a.color_table = it->second.p;
     }
     a.dbg_mode = 0;
+    a.ray0 = 0;
+    a.ray_index = nullptr;
+    a.n_rays_dev = nullptr;
+    a.zero_word = nullptr;
+    a.redo_list = nullptr;
+    a.redo_count = nullptr;
+    a.redo_cap = 0;
+    a.redo_band = 0.0f;
+    a.flags = m->flags;
     a.occ = m->occ;
     a.occ_cells = m->occ_cells;
     a.occ_w = m->occ_n[0]; a.occ_h = m->occ_n[1]; a.occ_d = m->occ_n[2];
@@ -1042,21 +1135,30 @@ static void launch_cascade_front(hr_model* m, const float* rays, int64_t n, hipS
     launch_mlp(m, kc, mb, st);
 }
 
-static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st)
+// redo0 >= 0: first pass of the verified fast path -- tiles that raise a range bit list their rays (indices start at redo0);
+// safe: the whole launch with the f16x3 tiles (hr_render_fields with diagnostics: one arithmetic for every output)
+static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st, int64_t redo0 = -1, bool safe = false)
 {
     if (m->coarse) {
         launch_cascade_front(m, rays, n, st);
         return;
     }
     HrMlpArgs ma;
-    fill_mlp_args(m, ma, rays, n);
-    launch_mlp(m, m->kcfg, ma, st);
+    fill_mlp_args(m, ma, rays, n, safe);
+    if (redo0 >= 0) {
+        ma.ray0 = redo0;
+        ma.redo_list = m->redo_list;
+        ma.redo_count = m->redo_count;
+        ma.redo_cap = m->redo_cap;
+    }
+    launch_mlp(m, m->kcfg, ma, st, safe);
 }
 
 // The frame kernel (fused_impl.inc) for the whole ray list; false: the model does not fit it (nothing launched)
 static bool launch_frame(hr_model* m, const float* rays, int64_t n, float* rgb, bool probe, hipStream_t st)
 {
     if (!m->opt_frame_kernel || m->coarse || m->is_coarse || m->cfg.mlp_layers == 0) return false;
+    if (m->verified) return false;               // the verified fast path is a two-pass plan over the HBM workspace
     if (n > ((int64_t)1 << 36)) return false;
     HrMlpArgs ma;
     fill_mlp_args(m, ma, rays, n);
@@ -1097,12 +1199,23 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     //  measured twice -- plain, and with the MLP limited to one workgroup per CU so that sample
     //  blocks could co-reside -- and is slower than back-to-back launches: 3.0-3.9 vs 2.79 ms per
     //  800x800 frame; the two kernels do not interleave on the CUs.)
+    // verified fast path: first pass in f16f8 with the rays at risk listed on the device, second pass over the list in f16x3.
+    // With diagnostics requested every output comes from ONE arithmetic: the f16x3 tiles throughout.
+    const bool verify = m->verified && !fields && n_rays < ((int64_t)1 << 31);
+    const bool safe_all = m->verified && !verify;
     for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
         const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
         const float* rays = rays_dev + r0 * c.ray_dim;
-        launch_front(m, rays, n, st);
+        launch_front(m, rays, n, st, verify ? r0 : -1, safe_all);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
+        if (verify) {
+            sa.ray0 = r0;
+            sa.redo_list = m->redo_list;
+            sa.redo_count = m->redo_count;
+            sa.redo_cap = m->redo_cap;
+            sa.redo_band = m->redo_band;
+        }
         if (fields) {
             if (fields->distances_dev) sa.fields.distances_dev = fields->distances_dev + r0 * Z;
             if (fields->points_dev) sa.fields.points_dev = fields->points_dev + r0 * Z * 3;
@@ -1112,6 +1225,23 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
                 hr_launch_head_export(m->head, fields->head_dev + r0 * (int64_t)Z * c.preds_per_z, n, Z, c.preds_per_z, m->p_live,
                                       (m->n_out + 3) / 4, rows_per_ray(c), m->col_map, st);
         }
+        hr_launch_samples(m->kcfg, sa, st);
+    }
+    if (verify && n_rays > 0) {
+        // second pass: the listed rays (count on the device: the launches are sized for the list's capacity, blocks past the count leave at
+        // once) through the f16x3 tiles, gathered from / scattered to the caller's buffers by index.  The head workspace is free again.
+        HrMlpArgs ma;
+        fill_mlp_args(m, ma, rays_dev, m->redo_cap, true);
+        // (the counter is cleared for the next call by the last launch of this one, which reads the copy the launch before it made)
+        ma.ray_index = m->redo_list;
+        ma.n_rays_dev = m->redo_count;
+        ma.n_rays_copy = m->redo_count + 1;
+        launch_mlp(m, m->kcfg, ma, st, true);
+        HrSampleArgs sa;
+        fill_sample_args(m, sa, rays_dev, m->redo_cap, rgb_dev);
+        sa.ray_index = m->redo_list;
+        sa.n_rays_dev = m->redo_count + 1;
+        sa.zero_word = m->redo_count;
         hr_launch_samples(m->kcfg, sa, st);
     }
     HR_HIP(hipGetLastError());
@@ -1230,11 +1360,21 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
     else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
-    else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW || option == HR_OPT_MLP_F8_SATURATED) {
+    else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW || option == HR_OPT_MLP_F8_SATURATED ||
+             option == HR_OPT_MLP_VERIFIED || option == HR_OPT_REDO_OVERFLOW || option == HR_OPT_REDO_COUNT) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         if (option == HR_OPT_MLP_PRECISION_ACTIVE) *value = m->active_precision;
         else if (option == HR_OPT_MLP_CALIBRATED) *value = m->calibrated;
-        else {
+        else if (option == HR_OPT_MLP_VERIFIED) *value = m->verified;
+        else if (option == HR_OPT_REDO_COUNT) {
+            unsigned n = 0;
+            if (m->redo_count) HR_HIP(hipMemcpy(&n, m->redo_count + 1, sizeof(unsigned), hipMemcpyDeviceToHost));      // the second pass's copy
+            *value = (int32_t)n;
+        } else if (option == HR_OPT_REDO_OVERFLOW) {
+            unsigned f = 0;
+            HR_HIP(hipMemcpy(&f, m->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
+            *value = (int32_t)((f >> 2) & 1u);
+        } else {
             unsigned f = 0;
             HR_HIP(hipMemcpy(&f, m->flags, sizeof(unsigned), hipMemcpyDeviceToHost));
             if (m->coarse) {
@@ -1845,6 +1985,9 @@ void hr_model_destroy(hr_model* m)
         free_dev(reinterpret_cast<float*&>(m->wsplit[l]));
         free_dev(m->bias[l]);
     }
+    free_safe_pack(m);
+    free_dev(reinterpret_cast<float*&>(m->redo_list));
+    free_dev(reinterpret_cast<float*&>(m->redo_count));
     for (int j = 0; j < 3; ++j) {
         free_dev(m->grid_a[j]);
         free_dev(m->grid_b[j]);

@@ -81,7 +81,19 @@ struct HrMlpArgs {
     unsigned long long* trace;   // bf16x3 kernel: optional phase timeline, 64 stamps per wave (hr_debug_trace_mlp)
     unsigned* flags;             // sticky status word of the model: bit 0 = an fp16-split kernel saw an input feature or hidden activation
                                  //   at or beyond the IEEE-half range (HR_OPT_MLP_OVERFLOW); bit 1 = the f16 + fp8 split saturated an fp8 image
-                                 //   of a hidden activation (HR_OPT_MLP_F8_SATURATED)
+                                 //   of a hidden activation (HR_OPT_MLP_F8_SATURATED); bit 2 = the redo list overflowed
+    // verified fast path (split kernels only).  First pass: redo_list != NULL -- a tile in which a range bit was raised (half
+    // overflow, fp8 saturation) appends its rays as ray0 + index (ray0: where `rays` starts in the caller's buffer).  Second pass: `rays` is the
+    // caller's whole buffer and ray_index != NULL -- head row i is the caller's ray ray_index[i], *n_rays_dev of them (n_rays: capacity).
+    int64_t ray0;
+    const int* ray_index;
+    const unsigned* n_rays_dev;
+    unsigned* n_rays_copy;       // second pass: workgroup 0 copies *n_rays_dev here (what the second pass's sample kernel reads, so that IT can clear the
+                                 //   counter for the next call -- a memset node between the calls does not survive hipGraph replay: the second
+                                 //   replay found 0x40404040 there)
+    int* redo_list;
+    unsigned* redo_count;
+    int redo_cap;
 };
 
 // ---------------------------------------------------------------- sample stage (sample_kernel.hip)
@@ -118,6 +130,19 @@ struct HrSampleArgs {
     int occ_w, occ_h, occ_d;
     float occ_lo[3], occ_inv[3];   // g = (p - lo) * inv - 1
     int dbg_mode;           // measurement builds only (-DHR_TUNING, HR_SAMPLE_DBG): 1 = skip the feature gather
+    // verified fast path.  First pass: redo_list != NULL -- a ray with a comparison within redo_band of flipping is appended as
+    // ray0 + (its index in this launch): ray0 = where the launch's `rays` / `rgb` start in the caller's buffers (hr_render walks them in chunks).
+    // Second pass: `rays` / `rgb` are the caller's whole buffers and ray_index != NULL -- position i of the launch (head row i) is the caller's
+    // ray ray_index[i]; *n_rays_dev of them (n_rays is then the launch's capacity).
+    int64_t ray0;
+    const int* ray_index;
+    const unsigned* n_rays_dev;
+    unsigned* zero_word;    // second pass: cleared by workgroup 0 (the list's counter, for the next call; this launch reads its copy)
+    int* redo_list;
+    unsigned* redo_count;
+    int redo_cap;
+    float redo_band;
+    unsigned* flags;        // the model's sticky status word (bit 2: the redo list overflowed)
 };
 
 // training forward (mlp_split_impl.inc, HR_SPLIT_TRAIN_KERNEL): where the output of hidden Linear l (after its LeakyReLU) goes besides LDS --

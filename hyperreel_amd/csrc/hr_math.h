@@ -254,18 +254,36 @@ HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, f
     }
 }
 
+// ---------------------------------------------------------------- decisions at risk (the verified fast path)
+// The per-sample stage is continuous in the MLP's head EXCEPT at a handful of comparisons (near / far mask, the quadratic's discriminant and root
+// choice, the new primitives' recycling test, the bounding box, a positive weight threshold).  A cheaper MLP arithmetic moves the head by
+// ~1e-5 of its range and every continuous quantity by < 1e-6 of the scene's size -- invisible at the 1e-4 bar -- but a comparison whose two
+// sides are closer than that error may fall the other way and change a pixel by 1e-2.  With a non-NULL HrRisk the functions below also report
+// whether any comparison they made was within `band` (a length: ~4e-6 of the scene's extent, six times the largest distance error
+// measured on 160 M samples, tools/band_probe.py) or `rel` (relative, for products) of flipping; the sample kernel collects the
+// rays that have such a sample and hr_render renders them again with the reference-grade arithmetic.  NULL (the default): nothing is computed.
+struct HrRisk {
+    float band;     // lengths: distances, radii, coordinates
+    float rel;      // relative margin for compound quantities (the discriminant)
+    bool hit;
+};
+#define HR_RISK_ABS(risk, x, y) do { if (risk) (risk)->hit = (risk)->hit || (fabsf((x) - (y)) <= (risk)->band); } while (0)
+
 // ---------------------------------------------------------------- ray / primitive intersection
 // utils/intersect_utils.py:45-84 (sphere) and :86-125 (cylinder: the xz components)
-HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius)
+HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius, HrRisk* risk = nullptr)
 {
     float a = dd;
     float b = 2.0f * od;
     float cc = oo - radius * radius;
     float disc = b * b - 4.0f * a * cc;
+    // at risk: the discriminant's sign (relative to the two terms it is the difference of) and the radius' sign
+    if (risk) risk->hit = risk->hit || (fabsf(disc) <= risk->rel * (b * b + fabsf(4.0f * a * cc))) || (fabsf(radius) <= risk->band);
     disc = (disc < 0.0f) ? 0.0f : disc;
     float sq = HR_SQRT(disc + 1e-8f);
     float t1 = HR_DIV(-b + sq, 2.0f * a);
     float t2 = HR_DIV(-b - sq, 2.0f * a);
+    if (risk) risk->hit = risk->hit || (fabsf(t2) <= risk->band);        // ... and the sign of the near root (which root is returned)
     t1 = (disc <= 0.0f) ? 0.0f : t1;
     t2 = (disc <= 0.0f) ? 0.0f : t2;
     return ((t2 < 0.0f) || (radius < 0.0f)) ? t1 : t2;
@@ -322,7 +340,7 @@ HR_FN float hr_process_z(const hr_config& c, float z, float scale, float anchor)
 // IntersectSphereNew / IntersectCylinderNew .intersect (primitive.py:498-545, :313-363): the ray is
 // moved into the primitive's frame, intersected, and samples whose primitive the ray misses are
 // recycled as offsets from the ray's closest point to the axis/centre.
-HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m, const float* ro, const float* rd)
+HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m, const float* ro, const float* rd, HrRisk* risk = nullptr)
 {
     float org[3] = {0.0f, 0.0f, 0.0f};
     if (c.origin_scale != 0.0f)
@@ -343,14 +361,14 @@ HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m
     float t, min_radius, base_distance;
     if (c.isect_type == HR_ISECT_SPHERE_NEW) {
         t = hr_quadratic_t(o[0] * o[0] + o[1] * o[1] + o[2] * o[2], dn[0] * dn[0] + dn[1] * dn[1] + dn[2] * dn[2],
-                           o[0] * dn[0] + o[1] * dn[1] + o[2] * dn[2], radius);
+                           o[0] * dn[0] + o[1] * dn[1] + o[2] * dn[2], radius, risk);
         float pos[3];
         hr_pluecker_pos(o, dn, pos);                                           // also min_sphere_radius' vector
         min_radius = HR_SQRT(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
         const float diff[3] = {pos[0] - o[0], pos[1] - o[1], pos[2] - o[2]};
         base_distance = hr_signed_base_distance(dn, diff);
     } else {
-        t = hr_quadratic_t(o[0] * o[0] + o[2] * o[2], dn[0] * dn[0] + dn[2] * dn[2], o[0] * dn[0] + o[2] * dn[2], radius);
+        t = hr_quadratic_t(o[0] * o[0] + o[2] * o[2], dn[0] * dn[0] + dn[2] * dn[2], o[0] * dn[0] + o[2] * dn[2], radius, risk);
         const float oc[3] = {o[0], 0.0f, o[2]}, dc[3] = {dn[0], 0.0f, dn[2]};
         float pos[3];
         hr_pluecker_pos(oc, dc, pos);
@@ -358,6 +376,7 @@ HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m
         const float diff[3] = {pos[0] - oc[0], pos[1] - oc[1], pos[2] - oc[2]};
         base_distance = HR_DIV(hr_signed_base_distance(dc, diff), HR_SQRT(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]));
     }
+    HR_RISK_ABS(risk, fabsf(radius), min_radius + 4.0f * c.z_scale);
     if (fabsf(radius) < min_radius + 4.0f * c.z_scale) t = raw + base_distance;
     return HR_DIV(t, dnorm + 1e-5f);
 }
@@ -366,7 +385,7 @@ HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m
 // head activation -> z activation * (1 - sigma) -> anchors/scale -> inverse contraction
 // -> closed-form intersection -> near/far mask.  `hk` points at the P raw head values of
 // sample k; `ro`/`rd` are the ray origin (minus intersect origin) and direction.
-HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const float* ro, const float* rd)
+HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const float* ro, const float* rd, HrRisk* risk = nullptr)
 {
     float sigma = 0.0f;
     if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
@@ -392,15 +411,15 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
             float oo = ox * ox + oy * oy + oz * oz;
             float dd = dx * dx + dy * dy + dz * dz;
             float od = ox * dx + oy * dy + oz * dz;
-            dist = hr_quadratic_t(oo, dd, od, radius);
+            dist = hr_quadratic_t(oo, dd, od, radius, risk);
         } else {
             float oo = ox * ox + oz * oz;
             float dd = dx * dx + dz * dz;
             float od = ox * dx + oz * dz;
-            dist = hr_quadratic_t(oo, dd, od, radius);
+            dist = hr_quadratic_t(oo, dd, od, radius, risk);
         }
     } else if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) {
-        dist = hr_isect_new(c, hk, k, one_m, ro, rd);
+        dist = hr_isect_new(c, hk, k, one_m, ro, rd, risk);
     } else if (c.isect_type == HR_ISECT_VOXEL_GRID) {
         // voxel.py:72-112: samples are (Z/3, 3) axis planes; sample k is a plane orthogonal to axis k % 3
         const int axis = k % 3;
@@ -423,6 +442,7 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
         const float dplane = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
         const float o_n = (ro[0] * n[0] + ro[1] * n[1]) + ro[2] * n[2];
         float d_n = (rd[0] * n[0] + rd[1] * n[1]) + rd[2] * n[2];
+        HR_RISK_ABS(risk, fabsf(d_n), 1e-5f);
         d_n = (fabsf(d_n) < 1e-5f) ? 1e12f : d_n;
         dist = HR_DIV(dplane - o_n, d_n);
     } else {                                                         // euclidean_distance_unified, primitive.py:162-176
@@ -433,6 +453,7 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
         dist = z + hr_signed_base_distance(rd, diff);
     }
     if (!c.isect_mask_off) {
+        if (risk) risk->hit = risk->hit || (fabsf(dist - c.near) <= risk->band) || (fabsf(dist - c.far) <= risk->band);
         bool mask = (dist <= c.near) || (dist >= c.far);             // base.py:194
         dist = mask ? 0.0f : dist;
     }
@@ -492,8 +513,14 @@ HR_FN void hr_sample_point(const hr_config& c, const float* hk, float dist_sorte
 }
 
 // valid_mask (tensorf_base.py:349-353) & (distances > 0) (tensorf_no_sample.py:156)
-HR_FN bool hr_sample_valid(const hr_config& c, const float* p, float dist)
+HR_FN bool hr_sample_valid(const hr_config& c, const float* p, float dist, HrRisk* risk = nullptr)
 {
+    if (risk && dist > 0.0f) {                  // a live sample within `band` of a face of the box
+        float m = fminf(fabsf(p[0] - c.aabb[0]), fabsf(p[0] - c.aabb[3]));
+        m = fminf(m, fminf(fabsf(p[1] - c.aabb[1]), fabsf(p[1] - c.aabb[4])));
+        m = fminf(m, fminf(fabsf(p[2] - c.aabb[2]), fabsf(p[2] - c.aabb[5])));
+        risk->hit = risk->hit || (m <= risk->band);
+    }
     bool out = (c.aabb[0] > p[0]) || (p[0] > c.aabb[3]) || (c.aabb[1] > p[1]) || (p[1] > c.aabb[4]) ||
                (c.aabb[2] > p[2]) || (p[2] > c.aabb[5]);
     return (!out) && (dist > 0.0f);

@@ -6,5 +6,6 @@
 #define HR_SPLIT_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define HR_SPLIT_KERNEL hr_mlp_f16x3_kernel
 #define HR_SPLIT_LAUNCH hr_launch_mlp_f16x3
+#define HR_SPLIT_LIST_NW8 1         // list-driven launches (the verified fast path's second pass) take the eight-wavefront form
 #define HR_W_LOAD_AUX 0            // weights through buffer loads (mlp_split_core.inc, hr_load_w)
 #include "mlp_split_impl.inc"

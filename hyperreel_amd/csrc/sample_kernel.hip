@@ -30,8 +30,19 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     const int64_t ray_base = (int64_t)bid * RPB;
-    const int64_t ray = ray_base + rib;
-    const bool ray_ok = ray < a.n_rays;
+    const int64_t lrow = ray_base + rib;           // position in this launch = row of the head
+    // second pass of the verified fast path: the launch is sized for the list's capacity, *n_rays_dev rays are there.  (Workgroups that walk
+    // the list from a fixed grid would save the ~14 us of dispatching empty workgroups -- and cost every launch of this kernel 44 registers and
+    // 52 bytes of scratch: the loop makes the compiler hoist the body's invariants.)
+    int64_t n_rays = a.n_rays;
+    if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0u;
+    if (a.n_rays_dev) {
+        const int64_t nd = (int64_t)*a.n_rays_dev;
+        n_rays = nd < n_rays ? nd : n_rays;
+    }
+    if (ray_base >= n_rays) return;                // (block-uniform, before any barrier)
+    const bool ray_ok = lrow < n_rays;
+    const int64_t ray = (a.ray_index && ray_ok) ? (int64_t)a.ray_index[lrow] : lrow;     // the caller's ray
 
     // ---- stage this block's head into LDS: per feature quad the block's RPB rays are RPB x 16
     //      contiguous bytes in the HQ layout (RPB divides 64, so a block never straddles a 64-ray group)
@@ -45,7 +56,7 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     } else {                                       // cascade: RPB * RPR rows of the point MLP's head, any alignment
         const float4* src4 = reinterpret_cast<const float4*>(a.head);
         const int NR = RPB * RPR;
-        const int64_t row0 = ray_base * RPR, n_rows = a.n_rays * RPR;
+        const int64_t row0 = ray_base * RPR, n_rows = n_rays * RPR;
         for (int i = tid; i < a.nq * NR; i += 256) {
             const int q = i / NR, r = i - q * NR;
             const int64_t row = row0 + r;

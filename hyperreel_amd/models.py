@@ -637,6 +637,19 @@ class HipLightfieldModel(nn.Module):
         """The arithmetic the MLP kernels run ('auto' resolved by the library's activation-range calibration)."""
         return {0: 'fp32', 1: 'bf16x3', 2: 'f16x3', 3: 'f16x2', 5: 'f16f8'}[self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)]
 
+    def mlp_verified(self):
+        """True when render() runs the verified fast path: f16f8 first, then the rays with a comparison at risk again with the f16x3 tiles
+        (HR_MLP_F16F8V; what 'auto' resolves to for a plain ray MLP with at most 64 samples per ray)."""
+        return bool(self._get_option(_lib.HR_OPT_MLP_VERIFIED))
+
+    def redo_count(self):
+        """Rays the last render() listed for its second pass (synchronises)."""
+        return self._get_option(_lib.HR_OPT_REDO_COUNT)
+
+    def redo_overflowed(self):
+        """Sticky: a render() listed more rays than the list holds (min(chunk, 65536)); the excess kept their first-pass pixels."""
+        return bool(self._get_option(_lib.HR_OPT_REDO_OVERFLOW))
+
     def mlp_overflowed(self):
         """True when an fp16-split kernel saw an activation at the IEEE-half range on a rendered ray (sticky; synchronises)."""
         return bool(self._get_option(_lib.HR_OPT_MLP_OVERFLOW))

@@ -314,7 +314,7 @@ class _Affine:
 
 
 # --------------------------------------------------------------------------- the compiler
-MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3, 'auto': 4, 'f16f8': 5}
+MLP_PRECISION = {'fp32': 0, 'bf16x3': 1, 'f16x3': 2, 'f16x2': 3, 'auto': 4, 'f16f8': 5, 'f16f8v': 6}
 
 
 GRID_DTYPE = {'fp32': 0, 'fp16': 1}
@@ -745,11 +745,13 @@ def compile_config(cfg, dataset, grid_size, mlp_precision='auto', grid_dtype='fp
     # raw head within 1e-6 of the exact fp32 chain (bf16x3: 7e-6, same cost), which is what keeps the reference's threshold decisions
     # (`dist <= near`, intersect/base.py:194-203) from flipping -- wherever hr_model_finalize's activation-range calibration shows the
     # MLP's activations to stay below 65504 / 8 (fp16 halves saturate at 65504; the reference's BaseMLP is fp32, nlf/nets/mlp.py:127-172),
-    # and 'bf16x3' (fp32 exponent range) otherwise.  A forced 'f16x3' / 'f16x2' that fails the same test is refused by name
+    # and 'bf16x3' (fp32 exponent range) otherwise.  Round 5: where the model allows it (a plain ray MLP, <= 64 samples per ray) 'auto' is 'f16f8v' --
+    # the f16 + fp8 arithmetic (two thirds of f16x3's matrix-pipe time) with every ray that has a comparison within 2.5e-6 of the scene's extent of
+    # flipping rendered again with the f16x3 tiles by a second, list-driven pass on the device (include/hyperreel_hip.h, HR_MLP_F16F8V).  A forced 'f16x3' / 'f16x2' that fails the same test is refused by name
     # (HR_E_RANGE).  'fp32' is the exact fp32 MFMA; other hidden widths only have that.
     if mlp_precision == 'auto' or hc.mlp_layers == 0:
         mlp_precision = 'auto' if hc.mlp_hidden == 256 else 'fp32'
-    if mlp_precision in ('bf16x3', 'f16x3', 'f16x2', 'f16f8') and hc.mlp_hidden != 256:
+    if mlp_precision in ('bf16x3', 'f16x3', 'f16x2', 'f16f8', 'f16f8v') and hc.mlp_hidden != 256:
         raise NotImplementedError(f'{mlp_precision} MLP needs hidden_channels == 256')
     hc.mlp_precision = MLP_PRECISION[mlp_precision]
     if grid_dtype not in GRID_DTYPE:

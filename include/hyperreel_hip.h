@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 24
+#define HR_ABI_VERSION 25
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -110,7 +110,18 @@ enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
         * fp8 (OCP e4m3) K=64 MFMA per 32 k with power-of-two block scales -- two thirds of F16X3's matrix-pipe time at ~2^-16 relative
         * per product (F16X3 2^-22, F16X2 2^-12).  Same range rule as F16X3, plus a per-layer exponent for the fp8 images taken from the
         * calibration (16x headroom); an activation beyond either range sets HR_OPT_MLP_OVERFLOW.  gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4). */
-       HR_MLP_F16F8 = 5 };
+       HR_MLP_F16F8 = 5,
+       /* F16F8 with its discrete decisions VERIFIED (what HR_MLP_AUTO resolves to where it applies: a plain ray MLP of width 256, at most 64
+        * samples per ray, activations inside the fp16 range).  The per-sample stage is continuous in the MLP's head except at a few
+        * comparisons -- `dist <= near` / `>= far` (nlf/intersect/base.py:194), the quadratic's discriminant and root choice
+        * (utils/intersect_utils.py:45-125), the bounding box (nlf/nets/tensorf_base.py:349-353), a positive weight threshold -- and F16F8's head
+        * error (2e-5 of the head's range; distances move by < 1e-6 of the scene's extent) only shows when one of them falls the other way.  The
+        * sample kernel therefore lists, on the device, every ray with a comparison inside a band of 2.5e-6 of the scene's extent (and the MLP
+        * kernel every tile that raised a range bit), and hr_render / hr_render_frame end with a second, list-driven pass that renders exactly
+        * those rays (0.05 - 1.5 % of a frame) again with F16X3's tiles.  Both passes are ordinary launches on the caller's stream: capturable.
+        * hr_render_fields with diagnostics renders everything with the F16X3 tiles (one arithmetic for every output).  HR_OPT_MLP_PRECISION_ACTIVE
+        * reports HR_MLP_F16F8, HR_OPT_MLP_VERIFIED 1. */
+       HR_MLP_F16F8V = 6 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
  * stays fp32 -- results equal the fp32 path run on the rounded grids) */
@@ -310,9 +321,13 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * the IEEE-half range (reading it synchronises the device; cleared by hr_model_finalize / hr_model_calibrate); HR_OPT_MLP_F8_SATURATED the
  * sticky bit HR_MLP_F16F8's kernels set when a hidden activation of a rendered ray was beyond the range of its fp8 image (16x the calibration's
  * largest activation of that layer): the image saturates, the ray's correction products lose accuracy (towards HR_MLP_F16X2's), nothing
- * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit. */
+ * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit.
+ * HR_OPT_MLP_VERIFIED 1 when hr_render runs the verified fast path (HR_MLP_F16F8V); HR_OPT_REDO_COUNT the number of rays the last hr_render listed
+ * for its second pass (reading it synchronises the device); HR_OPT_REDO_OVERFLOW the sticky bit raised when a call listed more rays than the
+ * list holds (min(chunk, 65 536)): the excess rays keep their first-pass pixels -- re-create the model with HR_MLP_F16X3 for such scenes. */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
-       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6, HR_OPT_MLP_F8_SATURATED = 7 };
+       HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6, HR_OPT_MLP_F8_SATURATED = 7,
+       HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

@@ -25,18 +25,21 @@ def scaled_network(sd, log2_s):
     return out
 
 
-def test_auto_resolves_to_f16x3_on_the_shipped_families_and_no_ray_overflows():
+AUTO = 'f16f8'       # what 'auto' resolves to on the shipped families since round 5: the verified fast path (HR_MLP_F16F8V), fp16 halves like f16x3
+
+
+def test_auto_resolves_to_the_verified_fp16_path_on_the_shipped_families_and_no_ray_overflows():
     from gpu_common import make_render_fn, render_np
     for case in ('donerf_sphere_small', 'technicolor_z_plane_small'):
         g = Golden(case)
         fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
-        assert fn.model.mlp_precision_active() == 'f16x3'
+        assert fn.model.mlp_precision_active() == AUTO and fn.model.mlp_verified()
         got = render_np(fn, g.rays)['rgb']
         assert linf(got, g.rgb) <= 1e-4
         assert not fn.model.mlp_overflowed()
         # the same decision on real rays, with the measured range: O(1-100) for these MLPs, three orders below the limit
         amax = fn.model.calibrate(torch.from_numpy(g.rays).cuda())
-        assert fn.model.mlp_precision_active() == 'f16x3'
+        assert fn.model.mlp_precision_active() == AUTO and fn.model.mlp_verified()
         assert len(amax) == len([k for k in g.state_dict if k.startswith(L) and k.endswith('weight')])
         assert 0.0 < max(amax) < 65504.0 / 8.0, amax
 
@@ -78,7 +81,7 @@ def test_sticky_overflow_bit_reports_rendered_rays_that_leave_the_half_range():
     for frame_kernel in (True, False):
         fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
         fn.model.set_execution(frame_kernel=frame_kernel)
-        assert fn.model.mlp_precision_active() == 'f16x3'
+        assert fn.model.mlp_precision_active() == AUTO
         render_np(fn, g.rays)
         assert not fn.model.mlp_overflowed()
         far = g.rays.copy()
@@ -103,7 +106,7 @@ def test_first_render_call_checks_the_bit_and_falls_back_to_bf16x3():
     far = g.rays.copy()
     far[:, :3] *= 1e6
     fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
-    assert fn.model.mlp_precision_active() == 'f16x3'
+    assert fn.model.mlp_precision_active() == AUTO
     with pytest.warns(UserWarning, match='IEEE-half range'):
         img = render_np(fn, far)['rgb']
     assert fn.model.mlp_precision_active() == 'bf16x3' and not fn.model.mlp_overflowed()

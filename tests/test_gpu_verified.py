@@ -1,0 +1,134 @@
+"""`-m gpu`: the verified fast path (HR_MLP_F16F8V; what mlp_precision='auto' resolves to for a plain ray MLP with <= 64 samples per ray).
+
+First pass: the MLP in f16 + fp8 (two thirds of f16x3's matrix-pipe time); the sample kernel lists, on the device, every ray with a
+comparison within 2.5e-6 of the scene's extent of flipping -- `dist <= near` (nlf/intersect/base.py:194), the quadratic's discriminant and
+root choice (utils/intersect_utils.py:45-125), the box test (nlf/nets/tensorf_base.py:349-353).  Second pass: exactly those rays again with
+the f16x3 tiles.  What is held here:
+  * every pixel is, bit for bit, either the plain f16f8 pixel or the plain f16x3 pixel of that ray, and at most `redo_count` are the latter;
+  * on the full 800x800 frames of all four families NO ray is further than 1e-4 from the f16x3 image (plain f16f8 leaves 3 rays of the
+    Neural-3D frame 0.06 - 0.08 away: flipped `dist <= near` decisions, profiles/r04_f8_flip_diagnosis.txt) -- and against the CPU restatement
+    of the reference tests/test_gpu_parity.py::test_full_size_frames_have_no_ray_over_the_bar[auto] counts the same zero;
+  * ragged counts, repeat calls, hipGraph replay, hr_render_frame."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden
+from hyperreel_amd import config as C
+from hyperreel_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLDENS = ['donerf_sphere_small', 'donerf_cylinder_small', 'technicolor_z_plane_small', 'immersive_sphere_small', 'neural_3d_z_plane_small', 'config1_random_z16']
+
+
+def _three(cfg, ds, sd, **kw):
+    from gpu_common import make_render_fn
+    return {p: make_render_fn(cfg, ds, sd, mlp_precision=p, **kw) for p in ('auto', 'f16f8', 'f16x3')}
+
+
+@pytest.mark.parametrize('grid_dtype', ['fp32', 'fp16'])
+@pytest.mark.parametrize('case', GOLDENS)
+def test_every_pixel_is_the_fast_or_the_reference_grade_pixel(case, grid_dtype):
+    g = Golden(case)
+    fns = _three(g.cfg, g.dataset, g.state_dict, grid_dtype=grid_dtype, iteration=g.iteration)
+    m = fns['auto'].model
+    rays = torch.from_numpy(np.concatenate([g.rays] * 8 + [g.rays[:37]], 0)).cuda()
+    img = {p: f.model.render(rays)['rgb'].clone() for p, f in fns.items()}
+    torch.cuda.synchronize()
+    assert m.mlp_precision_active() == 'f16f8' and m.mlp_verified() and not m.frame_kernel_active()
+    assert not fns['f16f8'].model.mlp_verified() and not fns['f16x3'].model.mlp_verified()
+    n_redo = m.redo_count()
+    fast = (img['auto'] == img['f16f8']).all(-1)
+    safe = (img['auto'] == img['f16x3']).all(-1)
+    assert bool((fast | safe).all()), f'{int((~(fast | safe)).sum())} pixels are neither arithmetic\'s'
+    assert int((safe & ~fast).sum()) <= n_redo <= rays.shape[0]
+    assert not m.redo_overflowed()
+    if grid_dtype == 'fp32':
+        assert float(np.abs(img['auto'][:g.rays.shape[0]].cpu().numpy() - g.rgb).max()) <= 1e-4
+    # again, and a ragged prefix: the same pixels
+    assert torch.equal(m.render(rays)['rgb'], img['auto'])
+    for n in (0, 1, 63, 65, 1000):
+        part = m.render(rays[:n].contiguous())['rgb']
+        assert part.shape == (n, 3) and torch.equal(part, img['auto'][:n])
+
+
+@pytest.mark.parametrize('model', ['donerf_sphere', 'technicolor_z_plane', 'immersive_sphere', 'neural_3d_z_plane'])
+def test_full_frames_no_ray_further_than_the_bar_from_the_f16x3_image(model):
+    cfg, ds = C.model_config(model), C.dataset_scalars(model)
+    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    rays_np = scenes.benchmark_rays(model, 800, 800, frame=7)
+    rays = torch.from_numpy(rays_np).cuda()
+    fns = _three(cfg, ds, sd)
+    m = fns['auto'].model
+    img = {p: f.model.render(rays)['rgb'].clone() for p, f in fns.items()}
+    torch.cuda.synchronize()
+    assert m.mlp_verified()
+    n_redo = m.redo_count()
+    d_fast = (img['f16f8'] - img['f16x3']).abs().amax(-1)
+    d_ver = (img['auto'] - img['f16x3']).abs().amax(-1)
+    flips = int((d_fast > 1e-4).sum())
+    assert int((d_ver > 1e-4).sum()) == 0, (f'{model}: {int((d_ver > 1e-4).sum())} rays over 1e-4 after the second pass (plain f16f8: {flips}); worst {float(d_ver.max()):.3e} '
+                                            f'at ray {int(d_ver.argmax())}; {n_redo} rays were listed')
+    assert n_redo <= 0.08 * rays.shape[0], f'{model}: {n_redo} rays listed'
+    if model in ('donerf_sphere', 'neural_3d_z_plane'):
+        assert n_redo > 0
+    assert not m.redo_overflowed()
+    fast = (img['auto'] == img['f16f8']).all(-1)
+    safe = (img['auto'] == img['f16x3']).all(-1)
+    assert bool((fast | safe).all())
+    if model != 'donerf_sphere':          # hr_render_frame: the same statement for the frame entry (its own summation order in the time planes)
+        t = float(rays_np[0, -1])
+        fi = {p: f.model.render(rays, frame_time=t)['rgb'].clone() for p, f in fns.items()}
+        d = (fi['auto'] - fi['f16x3']).abs().amax(-1)
+        assert int((d > 1e-4).sum()) == 0, f'{model} through hr_render_frame: worst {float(d.max()):.3e}'
+    print(f'{model}: {n_redo} rays listed ({100.0 * n_redo / rays.shape[0]:.3f} %), plain f16f8 flips {flips}, worst after the second pass {float(d_ver.max()):.2e}')
+
+
+def test_the_two_passes_replay_from_a_hipgraph():
+    g = Golden('donerf_sphere_small')
+    from gpu_common import make_render_fn
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    m = fn.model
+    rays = torch.from_numpy(np.concatenate([g.rays] * 40, 0)).cuda()
+    eager = m.render(rays)['rgb'].clone()
+    torch.cuda.synchronize()
+    assert m.mlp_verified()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.render(rays)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        out = m.render(rays)['rgb']
+    for _ in range(3):
+        out.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+
+
+def test_diagnostics_come_from_one_arithmetic():
+    """hr_render_fields with intermediates: every output (rgb included) from the f16x3 tiles."""
+    g = Golden('technicolor_z_plane_small')
+    from gpu_common import make_render_fn
+    a = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).model
+    b = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3', iteration=g.iteration).model
+    rays = torch.from_numpy(g.rays).cuda()
+    want = ('distances', 'points', 'render_weights', 'head')
+    oa, ob = a.render(rays, want=want), b.render(rays, want=want)
+    assert a.mlp_verified()
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+
+
+def test_forced_f16f8v_is_refused_where_it_cannot_apply():
+    from gpu_common import make_render_fn
+    g = Golden('sweep/shiny_z_plane_cascaded')
+    with pytest.raises(Exception, match='f16f8v'):
+        make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16f8v').model.native()
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)          # 'auto' there: the layered default, unverified
+    fn.model.native()
+    assert not fn.model.mlp_verified()

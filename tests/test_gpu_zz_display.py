@@ -128,7 +128,7 @@ def test_occupancy_early_reject_equals_the_reference_with_its_mask_enabled():
     cfg = C.model_config(r['model'])
     cfg['color']['net']['alpha_mask_thre'] = r['thre']
     sd = scenes.make_state_dict(cfg, r['dataset'], r['grid'], r['seed'], 'dense', 1.0)
-    fn = make_render_fn(cfg, r['dataset'], sd)
+    fn = make_render_fn(cfg, r['dataset'], sd, mlp_precision='f16x3')     # (both execution plans below: 'auto' -- the verified two-pass plan -- has only one)
     net = fn.model.color_model.net
     rays = torch.from_numpy(np.ascontiguousarray(z['rays'], np.float32)).cuda()
     plain = fn.model.render(rays)['rgb'].cpu().numpy()

@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import Golden
 from gpu_common import make_render_fn
+if os.environ.get('HR_LIB'):          # a measurement build (tools/build_variant.py)
+    from hyperreel_amd import lib as _hl
+    _hl.LIB_PATH = os.path.abspath(os.environ['HR_LIB'])
 for case, gd in (('immersive_sphere_small', 'fp32'), ('donerf_sphere_small', 'fp16'), ('config1_random_z16', 'fp16')):
     g = Golden(case)
     rep = max(1, 160000 // g.rays.shape[0])
