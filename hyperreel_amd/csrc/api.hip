@@ -1854,12 +1854,16 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         ad.d_basis = reinterpret_cast<float*>(m->grad_fx + off_basis);
         ad.d_color_table = n_ct ? reinterpret_cast<float*>(m->grad_fx + off_ct) : nullptr;
         hr_launch_train_det(m->cfg, &ad, sizeof(ad), st);
+        const float* fx_inv = nullptr;
+        const unsigned* fx_bad = nullptr;
+        hr_train_det_scale(&fx_inv, &fx_bad);
+        if (!fx_inv || !fx_bad) return fail(HR_E_HIP, "deterministic training: the fixed-point unit's device symbols are not available");
         for (int j = 0; j < 3; ++j) {
-            if (n_a[j]) hr_launch_fixed_to_float(m->grad_fx + off_a[j], m->grad_a[j], (int64_t)n_a[j], st);
-            if (n_b[j]) hr_launch_fixed_to_float(m->grad_fx + off_b[j], m->grad_b[j], (int64_t)n_b[j], st);
+            if (n_a[j]) hr_launch_fixed_to_float(m->grad_fx + off_a[j], m->grad_a[j], (int64_t)n_a[j], fx_inv, fx_bad, st);
+            if (n_b[j]) hr_launch_fixed_to_float(m->grad_fx + off_b[j], m->grad_b[j], (int64_t)n_b[j], fx_inv, fx_bad, st);
         }
-        hr_launch_fixed_to_float(m->grad_fx + off_basis, d_basis, (int64_t)n_basis, st);
-        if (n_ct) hr_launch_fixed_to_float(m->grad_fx + off_ct, grads->color_table, (int64_t)n_ct, st);
+        hr_launch_fixed_to_float(m->grad_fx + off_basis, d_basis, (int64_t)n_basis, fx_inv, fx_bad, st);
+        if (n_ct) hr_launch_fixed_to_float(m->grad_fx + off_ct, grads->color_table, (int64_t)n_ct, fx_inv, fx_bad, st);
     } else {
         hr_launch_train(m->cfg, a, st);
     }

@@ -28,13 +28,23 @@
 // Gradient accumulators (texel gradients, basis_mat's, the colour table's, the per-ray decode-matrix gradient in LDS) are `hr_acc_t`.
 // Default build: float, hardware fp32 atomics -- fast, and the sum depends on the order the memory system retires them in (two runs of
 // the same step differ in the last bits).  HR_TRAIN_DET (train_det_kernel.hip, HR_OPT_TRAIN_DETERMINISTIC): 64-bit FIXED POINT
-// (2^-40 units: +-8.4e6 at 9e-13 resolution) through integer atomics -- integer addition is associative, so every run of a step
-// produces the same bits whatever the order; the totals are converted to float once, after the last add.
+// through integer atomics -- integer addition is associative, so every run of a step produces the same bits whatever the order; the totals
+// are converted to float once, after the last add.  The unit is a power of two chosen PER STEP from the step's largest |dL/d rgb|
+// (hr_fx_scale_kernel: max |d_rgb| = 2^32 units): every gradient is linear in d_rgb, so a contribution 2^-32 of the largest still has its
+// leading bit and a sum may reach 2^31 times the largest -- a fixed 2^-40 unit (round 4) dropped most bits of late-training gradients
+// (d_rgb = 2 err / 3B ~ 1e-10).  A non-finite contribution raises hr_fx_bad and the step's totals convert to NaN (the fp32 path
+// would have produced inf / NaN there; __float2ll_rn alone turns NaN into 0).
 #if defined(__HIPCC__) && defined(HR_TRAIN_DET)
 typedef long long hr_acc_t;
-#define HR_ACC_ONE 1099511627776.0f                 // 2^40
-__device__ __forceinline__ long long hr_to_fixed(float v) { return __float2ll_rn(v * HR_ACC_ONE); }
-#define HR_ACC_VALUE(x) ((float)((double)(x) * (1.0 / 1099511627776.0)))
+__device__ float hr_fx_one = 1099511627776.0f;      // units per 1.0, a power of two (set per step)
+__device__ float hr_fx_inv = 1.0f / 1099511627776.0f;
+__device__ unsigned hr_fx_bad = 0u;
+__device__ __forceinline__ long long hr_to_fixed(float v)
+{
+    if (!(fabsf(v) <= 3.0e38f)) hr_fx_bad = 1u;     // NaN or infinity (a plain store of the same value from any lane: no atomic needed)
+    return __float2ll_rn(v * hr_fx_one);
+}
+#define HR_ACC_VALUE(x) ((float)((double)(x) * (double)hr_fx_inv))
 #define HR_ATOMIC_ADD(p, v) (void)atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)hr_to_fixed(v))
 #define HR_ATOMIC_ADD_ACC(p, x) (void)atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(x))      // an accumulated total onto another (exact)
 #define HR_ATOMIC_ADD_RAY(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) long long*)(p), hr_to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)

@@ -344,18 +344,21 @@ void hr_launch_blend_rows(const float* b, float* line, int row_floats, int i0, i
 }
 
 // 64-bit fixed-point gradient totals of the deterministic training build (hr_train.h: 2^-40 units) -> float, once, after the last add
-__global__ __launch_bounds__(256) void hr_fixed_to_float_kernel(const long long* __restrict__ src, float* __restrict__ dst, int64_t n)
+__global__ __launch_bounds__(256) void hr_fixed_to_float_kernel(const long long* __restrict__ src, float* __restrict__ dst, int64_t n,
+                                                                 const float* __restrict__ inv_dev, const unsigned* __restrict__ bad_dev)
 {
+    const double inv = (double)*inv_dev;                 // the step's unit (a power of two: exact)
+    const bool bad = *bad_dev != 0u;                     // a non-finite contribution: the fp32 path would hold inf / NaN somewhere -- say so everywhere
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        dst[i] = (float)((double)src[i] * (1.0 / 1099511627776.0));
+        dst[i] = bad ? __builtin_nanf("") : (float)((double)src[i] * inv);
 }
 
-void hr_launch_fixed_to_float(const long long* src, float* dst, int64_t n, hipStream_t stream)
+void hr_launch_fixed_to_float(const long long* src, float* dst, int64_t n, const float* inv_dev, const unsigned* bad_dev, hipStream_t stream)
 {
     if (n <= 0) return;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(hr_fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
+    hipLaunchKernelGGL(hr_fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n, inv_dev, bad_dev);
 }
 
 

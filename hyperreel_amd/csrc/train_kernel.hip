@@ -834,6 +834,34 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
 }
 
 #ifdef HR_TRAIN_DET
+// the step's fixed-point unit: max |d_rgb| -> 2^32 units (hr_train.h); one workgroup, before the step's first accumulating kernel
+__global__ __launch_bounds__(1024) void hr_fx_scale_kernel(const float* __restrict__ d_rgb, int64_t n)
+{
+    __shared__ float s_max[16];
+    __shared__ unsigned s_bad;
+    if (threadIdx.x == 0) s_bad = 0u;
+    __syncthreads();
+    float mx = 0.0f;
+    bool bad = false;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float v = fabsf(d_rgb[i]);
+        if (!(v <= 3.0e38f)) bad = true; else mx = fmaxf(mx, v);
+    }
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (bad) s_bad = 1u;
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_max[w]);
+        int e = 0;
+        if (mx > 0.0f) (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+        int sh = 32 - e;                                // mx * 2^sh in [2^31, 2^32)
+        sh = sh < -60 ? -60 : (sh > 120 ? 120 : sh);
+        hr_fx_one = ldexpf(1.0f, sh);
+        hr_fx_inv = ldexpf(1.0f, -sh);
+        hr_fx_bad = s_bad;
+    }
+}
 }   // namespace hr_det
 // the caller's HrTrainArgs is the default build's (float pointers); the structs differ in pointee types only
 void hr_launch_train_det(const hr_config& cfg, const void* args_flt, size_t args_bytes, hipStream_t stream)
@@ -841,7 +869,15 @@ void hr_launch_train_det(const hr_config& cfg, const void* args_flt, size_t args
     hr_det::HrTrainArgs a;
     if (args_bytes != sizeof(a)) return;
     memcpy(&a, args_flt, sizeof(a));
+    if (a.d_rgb && a.n_rays > 0) hipLaunchKernelGGL(hr_det::hr_fx_scale_kernel, dim3(1), dim3(1024), 0, stream, a.d_rgb, a.n_rays * 3);
     hr_det::hr_launch_train_impl(cfg, a, stream);
+}
+// where the step's unit and its non-finite flag live (device addresses): hr_launch_fixed_to_float reads them
+void hr_train_det_scale(const float** inv_dev, const unsigned** bad_dev)
+{
+    void* p = nullptr;
+    *inv_dev = (hipGetSymbolAddress(&p, HIP_SYMBOL(hr_det::hr_fx_inv)) == hipSuccess) ? static_cast<const float*>(p) : nullptr;
+    *bad_dev = (hipGetSymbolAddress(&p, HIP_SYMBOL(hr_det::hr_fx_bad)) == hipSuccess) ? static_cast<const unsigned*>(p) : nullptr;
 }
 #else
 // Coarse level of a point_prediction cascade (hr_ray_rows ... in hr_train.h): rows forward per ray, then per sample the

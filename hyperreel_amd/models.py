@@ -426,12 +426,13 @@ class HipLightfieldModel(nn.Module):
     def grid_size(self):
         # gridSize is a buffer and lives on the device with the model: read it back only when it changed (forward_train asks every step --
         # a device-to-host copy there stalls the host behind the queue and cannot be captured into a graph)
+        # The cache holds the TENSOR it read (shrink / upsample_volume_grid / load_state_dict replace gridSize by fresh tensors whose _version is 0
+        # again and whose storage the allocator may hand out at a freed tensor's address: identity, not data_ptr, is the key -- ADVICE r4)
         gs = self.color_model.net.gridSize
-        key = (gs.data_ptr(), gs._version, gs.device)
         cached = getattr(self, '_grid_size_host', None)
-        if cached is None or cached[0] != key:
-            cached = self._grid_size_host = (key, [int(v) for v in gs.tolist()])
-        return list(cached[1])
+        if cached is None or cached[0] is not gs or cached[1] != gs._version:
+            cached = self._grid_size_host = (gs, gs._version, [int(v) for v in gs.tolist()])
+        return list(cached[2])
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts reference checkpoints: strips a leading `render_fn.model.` / `model.`,
@@ -743,11 +744,11 @@ class HipLightfieldModel(nn.Module):
         """The fp16 split arithmetic ('auto' -> f16x3) was chosen on CALIBRATION rays (hr_model_finalize: synthetic origins in and around
         the scene box); real cameras may stand further out, and activations beyond the IEEE-half range would render inf / NaN where the
         reference's fp32 BaseMLP (nlf/nets/mlp.py:159-172) does not.  The kernels raise a sticky bit when that happens; it is read here
-        on the model's first render call, its 16th and every 1024th (one 4-byte read behind a synchronise; never inside a stream
+        on the model's first 16 render calls and every 256th after (one 4-byte read behind a synchronise; never inside a stream
         capture).  If set: the arithmetic is re-decided on the offending rays -- 'auto' re-packs as bf16x3 (fp32 exponent range), a forced
         fp16 mode raises HipRangeError -- and the caller renders the batch again.  Returns True when it did so."""
         n = self._render_calls = getattr(self, '_render_calls', 0) + 1
-        if not (n == 1 or n == 16 or n % 1024 == 0) or torch.cuda.is_current_stream_capturing():
+        if not (n <= 16 or n % 256 == 0) or torch.cuda.is_current_stream_capturing():
             return False
         active = self._get_option(_lib.HR_OPT_MLP_PRECISION_ACTIVE)
         if active not in (2, 3, 5):                                      # f16x3, f16x2, f16f8
@@ -756,7 +757,19 @@ class HipLightfieldModel(nn.Module):
         if self.mlp_overflowed():
             warnings.warn('hyperreel_amd: an MLP activation reached the IEEE-half range on rendered rays (the fp16 split arithmetic had been chosen '
                           'on calibration rays); re-deciding the arithmetic on these rays and rendering the batch again')
-            self.calibrate(rays)
+            try:
+                self.calibrate(rays)
+            except RuntimeError as e:
+                # a point_prediction cascade cannot be calibrated on the caller's rays (the point MLP's rows are internal: hr_model_calibrate
+                # refuses): 'auto' re-creates the native model with the fp32-range split, a forced fp16 mode is refused by name
+                if 'cascades' not in str(e):
+                    raise
+                if self.mlp_precision != 'auto':
+                    raise _lib.HipRangeError(f'mlp_precision {self.mlp_precision!r} overflowed the IEEE-half range on rendered rays of a point_prediction '
+                                             'cascade; use mlp_precision="auto" or "bf16x3"') from e
+                self.mlp_precision = 'bf16x3'
+                self._native_key = None
+                self.native()
             return True
         if active == 5 and self.mlp_f8_saturated():
             # f16f8: the fp8 images of a layer's output are scaled from the calibration's largest activation of that layer.  Beyond 16x that they
@@ -865,11 +878,19 @@ class HipLightfieldModel(nn.Module):
         extra = ()
         if hc.color_table_views > 0:                            # ColorTransformEmbedding's table (point.py:558-602)
             extra = (self.embedding_model.embeddings[types.index('color_transform')].color_embedding,)
+        # (the request travels as a class attribute: autograd.Function.apply takes tensors.  Whatever happens inside, neither the request nor a
+        #  previous call's fields may outlive this call -- ADVICE r4)
+        T.SampleStage.fields_out = None
+        T.SampleStage.want_fields = hc.z_channels if want_fields else None
+        try:
+            rgb = T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm), *extra)
+            f = T.SampleStage.fields_out
+        finally:
+            T.SampleStage.want_fields = None
+            T.SampleStage.fields_out = None
         if want_fields:
-            T.SampleStage.want_fields = hc.z_channels
-        rgb = T.SampleStage.apply(h, rays, head, white_bg, vm.basis_mat.weight, *T.grid_parameters(vm), *extra)
-        if want_fields:
-            f, T.SampleStage.fields_out = T.SampleStage.fields_out, None
+            if f is None:
+                raise RuntimeError('forward_train(want_fields=True): the sample stage returned no fields')
             f['head'] = head.detach()
             return rgb, f
         return rgb

@@ -27,6 +27,21 @@ class HipAdam(torch.optim.Optimizer):
         ps, gs, ms, vs, ns, hp = [], [], [], [], [], []
         keep = []
         dev = None
+        # validate EVERYTHING before any state is touched: a raise must not leave some parameters' step counts advanced
+        for group in self.param_groups:
+            if group.get('amsgrad', False) or group.get('maximize', False):
+                raise RuntimeError('HipAdam implements plain Adam: amsgrad / maximize are not supported (use torch.optim.Adam for those groups)')
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.device.type != 'cuda':
+                    raise RuntimeError('HipAdam steps parameters on the HIP device; there is no CPU path')
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
+                    raise RuntimeError('HipAdam: contiguous float32 parameters with dense float32 gradients')
+                if dev is None:
+                    dev = p.device
+                elif p.device != dev:
+                    raise RuntimeError('HipAdam: all parameters of one optimizer on one device')
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:

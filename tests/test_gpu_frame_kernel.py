@@ -93,7 +93,7 @@ def test_keyframe_frame_kernel_full_frame_every_word_and_repeats(model):
     from gpu_common import make_render_fn
     cfg, ds = C.model_config(model), C.dataset_scalars(model)
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
-    fn = make_render_fn(cfg, ds, sd)
+    fn = make_render_fn(cfg, ds, sd, mlp_precision="f16x3")
     rays = torch.from_numpy(scenes.benchmark_rays(model, 800, 800, frame=7)).cuda()
     two = _render(fn, rays, False)
     one = _render(fn, rays, 2)
@@ -136,7 +136,7 @@ def test_frame_kernel_full_frame_every_word_and_repeats(waves):
     from gpu_common import make_render_fn
     cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
-    fn = make_render_fn(cfg, ds, sd)
+    fn = make_render_fn(cfg, ds, sd, mlp_precision="f16x3")
     rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800, frame=7)).cuda()
     two = _render(fn, rays, False)
     one = _render(fn, rays, True, waves)
@@ -154,7 +154,7 @@ def test_frame_kernel_under_a_concurrent_stream():
     from gpu_common import make_render_fn
     cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
     sd = scenes.make_state_dict(cfg, ds, [96, 96, 96], seed=3, density='dense', app_scale=1.0)
-    fn = make_render_fn(cfg, ds, sd)
+    fn = make_render_fn(cfg, ds, sd, mlp_precision="f16x3")
     rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 400, 400, frame=3)).cuda()
     two = _render(fn, rays, False)
     fn.model.set_execution(frame_kernel=True)
