@@ -74,14 +74,18 @@ struct hr_model {
     // verified fast path: the MLP runs f16f8, rays with a comparison at risk (or a range bit) are listed on the device and rendered
     // again with the f16x3 tiles below by a second, list-driven pass at the end of hr_render
     int verified = 0;
-    void* wsplit_safe[HR_MAX_LAYERS] = {};
-    float* bias_safe[HR_MAX_LAYERS] = {};
-    float winv_safe[HR_MAX_LAYERS] = {};
-    int n_tiles_safe[HR_MAX_LAYERS] = {};
-    int64_t mlp_bytes_safe = 0;
-    int* redo_list = nullptr;
-    unsigned* redo_count = nullptr;
+    // tier 1: the f16x3 tiles of the second pass; tier 2: bf16x3 tiles (fp32 exponent range) for the third pass -- the tiles of the second pass in
+    // which an activation left the IEEE-half range (what the reference's fp32 BaseMLP, nlf/nets/mlp.py:159-172, cannot do)
+    void* wsplit_safe[2][HR_MAX_LAYERS] = {};
+    float* bias_safe[2][HR_MAX_LAYERS] = {};
+    float winv_safe[2][HR_MAX_LAYERS] = {};
+    int n_tiles_safe[2][HR_MAX_LAYERS] = {};
+    int64_t mlp_bytes_safe[2] = {};
+    int* redo_list = nullptr;            // the second pass's rays
+    int* wide_list = nullptr;            // the third pass's rays
+    unsigned* redo_count = nullptr;      // [0] second-pass counter, [1] its copy, [2] third-pass counter, [3] its copy
     int redo_cap = 0;
+    int wide_cap = 0;
     float redo_band = 0.0f;
     int64_t mlp_bytes = 0;
     // packed grids
@@ -650,11 +654,13 @@ static int pack_mlp_as(hr_model* m, const int precision, const HrPackOut o)
 
 static void free_safe_pack(hr_model* m)
 {
-    for (int l = 0; l < HR_MAX_LAYERS; ++l) {
-        free_dev(reinterpret_cast<float*&>(m->wsplit_safe[l]));
-        free_dev(m->bias_safe[l]);
+    for (int t = 0; t < 2; ++t) {
+        for (int l = 0; l < HR_MAX_LAYERS; ++l) {
+            free_dev(reinterpret_cast<float*&>(m->wsplit_safe[t][l]));
+            free_dev(m->bias_safe[t][l]);
+        }
+        m->mlp_bytes_safe[t] = 0;
     }
-    m->mlp_bytes_safe = 0;
 }
 
 // the primary tiles in the active arithmetic, and -- verified fast path -- the f16x3 tiles of the second pass
@@ -668,10 +674,12 @@ static int pack_mlp(hr_model* m)
     if (rc != HR_OK) return rc;
     free_safe_pack(m);
     if (m->verified) {
-        rc = pack_mlp_as(m, HR_MLP_F16X3, HrPackOut{nullptr, m->wsplit_safe, m->bias_safe, m->winv_safe, m->n_tiles_safe, &m->mlp_bytes_safe});
+        rc = pack_mlp_as(m, HR_MLP_F16X3, HrPackOut{nullptr, m->wsplit_safe[0], m->bias_safe[0], m->winv_safe[0], m->n_tiles_safe[0], &m->mlp_bytes_safe[0]});
         if (rc != HR_OK) return rc;
-        if (!m->redo_count) HR_HIP(hipMalloc((void**)&m->redo_count, 2 * sizeof(unsigned)));      // [0]: the counter, [1]: the second pass's copy
-        HR_HIP(hipMemset(m->redo_count, 0, 2 * sizeof(unsigned)));
+        rc = pack_mlp_as(m, HR_MLP_BF16X3, HrPackOut{nullptr, m->wsplit_safe[1], m->bias_safe[1], m->winv_safe[1], m->n_tiles_safe[1], &m->mlp_bytes_safe[1]});
+        if (rc != HR_OK) return rc;
+        if (!m->redo_count) HR_HIP(hipMalloc((void**)&m->redo_count, 4 * sizeof(unsigned)));
+        HR_HIP(hipMemset(m->redo_count, 0, 4 * sizeof(unsigned)));
         // a comparison is "at risk" within this length (HrRisk::band): 2.5e-6 of the scene's extent -- the largest |d distance| between
         // f16f8 and f16x3 measured on the four 800x800 benchmark frames (160 M samples) is 7e-7 in scenes of extent 2 (tools/band_probe.py,
         // profiles/r05_band_probe.json), and the z-plane families have live samples from 1e-5 of `near` on
@@ -680,7 +688,7 @@ static int pack_mlp(hr_model* m)
         ext = fmaxf(ext, std::isfinite(m->cfg.near) ? fabsf(m->cfg.near) : 0.0f);
         m->redo_band = 2.5e-6f * ext;
     }
-    m->mlp_bytes = b1 + m->mlp_bytes_safe;
+    m->mlp_bytes = b1 + m->mlp_bytes_safe[0] + m->mlp_bytes_safe[1];
     return HR_OK;
 }
 
@@ -1009,20 +1017,23 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     // verified fast path: the list of rays the second pass renders again.  Capacity: 10 % of a 640 000-ray frame (measured: 0.05 - 3 %), never
     // more than a chunk (the second pass uses the chunk's head workspace); beyond it the kernels raise bit 2 of the status word (HR_OPT_REDO_OVERFLOW)
     free_dev(reinterpret_cast<float*&>(m->redo_list));
+    free_dev(reinterpret_cast<float*&>(m->wide_list));
     m->redo_cap = (int)(rays_per_chunk < 65536 ? rays_per_chunk : 65536);
+    m->wide_cap = (int)(rays_per_chunk < 8192 ? rays_per_chunk : 8192);       // third pass: 128 tiles (rays outside the calibrated range are the exception)
     HR_HIP(hipMalloc((void**)&m->redo_list, sizeof(int) * (size_t)m->redo_cap));
+    HR_HIP(hipMalloc((void**)&m->wide_list, sizeof(int) * (size_t)m->wide_cap));
     if (!m->redo_count) {
-        HR_HIP(hipMalloc((void**)&m->redo_count, 2 * sizeof(unsigned)));
-        HR_HIP(hipMemset(m->redo_count, 0, 2 * sizeof(unsigned)));
+        HR_HIP(hipMalloc((void**)&m->redo_count, 4 * sizeof(unsigned)));
+        HR_HIP(hipMemset(m->redo_count, 0, 4 * sizeof(unsigned)));
     }
     return HR_OK;
 }
 
-// safe: the verified fast path's f16x3 tiles (fill_mlp_args(..., true)) instead of the model's primary arithmetic
-static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st, bool safe = false)
+// tier: 0 = the model's primary arithmetic; the verified fast path's later passes: 1 = its f16x3 tiles, 2 = its bf16x3 tiles (fill_mlp_args(..., tier))
+static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a, hipStream_t st, int tier = 0)
 {
     if (c.mlp_layers == 0) return;               // ZeroMLP: the workspace already holds the (all-zero) head
-    const int prec = safe ? HR_MLP_F16X3 : m->active_precision;
+    const int prec = tier == 1 ? HR_MLP_F16X3 : (tier == 2 ? HR_MLP_BF16X3 : m->active_precision);
     if (prec == HR_MLP_BF16X3) hr_launch_mlp_bf16x3(c, a, st);
     else if (prec == HR_MLP_F16X3) hr_launch_mlp_f16x3(c, a, st);
     else if (prec == HR_MLP_F16X2) hr_launch_mlp_f16x2(c, a, st);
@@ -1030,18 +1041,20 @@ static void launch_mlp(const hr_model* m, const hr_config& c, const HrMlpArgs& a
     else hr_launch_mlp(c, a, st);
 }
 
-static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n, bool safe = false)
+static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, int64_t n, int tier = 0)
 {
+    const bool safe = tier > 0;
+    const int ti = tier > 0 ? tier - 1 : 0;
     a.rays = rays;
     a.n_rays = n;
     a.head = m->head;
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {
         a.wpack[l] = m->wpack[l];
-        a.wsplit[l] = safe ? m->wsplit_safe[l] : m->wsplit[l];
-        a.bias[l] = safe ? m->bias_safe[l] : m->bias[l];
-        a.winv[l] = safe ? m->winv_safe[l] : m->winv[l];
+        a.wsplit[l] = safe ? m->wsplit_safe[ti][l] : m->wsplit[l];
+        a.bias[l] = safe ? m->bias_safe[ti][l] : m->bias[l];
+        a.winv[l] = safe ? m->winv_safe[ti][l] : m->winv[l];
         a.xexp[l] = safe ? 0 : m->xexp[l];
-        a.n_tiles[l] = safe ? m->n_tiles_safe[l] : m->n_tiles[l];
+        a.n_tiles[l] = safe ? m->n_tiles_safe[ti][l] : m->n_tiles[l];
     }
     a.ray0 = 0;
     a.ray_index = nullptr;
@@ -1137,21 +1150,21 @@ static void launch_cascade_front(hr_model* m, const float* rays, int64_t n, hipS
 
 // redo0 >= 0: first pass of the verified fast path -- tiles that raise a range bit list their rays (indices start at redo0);
 // safe: the whole launch with the f16x3 tiles (hr_render_fields with diagnostics: one arithmetic for every output)
-static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st, int64_t redo0 = -1, bool safe = false)
+static void launch_front(hr_model* m, const float* rays, int64_t n, hipStream_t st, int64_t redo0 = -1, int tier = 0)
 {
     if (m->coarse) {
         launch_cascade_front(m, rays, n, st);
         return;
     }
     HrMlpArgs ma;
-    fill_mlp_args(m, ma, rays, n, safe);
+    fill_mlp_args(m, ma, rays, n, tier);
     if (redo0 >= 0) {
         ma.ray0 = redo0;
         ma.redo_list = m->redo_list;
         ma.redo_count = m->redo_count;
         ma.redo_cap = m->redo_cap;
     }
-    launch_mlp(m, m->kcfg, ma, st, safe);
+    launch_mlp(m, m->kcfg, ma, st, tier);
 }
 
 // The frame kernel (fused_impl.inc) for the whole ray list; false: the model does not fit it (nothing launched)
@@ -1206,7 +1219,7 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
         const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
         const float* rays = rays_dev + r0 * c.ray_dim;
-        launch_front(m, rays, n, st, verify ? r0 : -1, safe_all);
+        launch_front(m, rays, n, st, verify ? r0 : -1, safe_all ? 1 : 0);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
         if (verify) {
@@ -1231,17 +1244,32 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
         // second pass: the listed rays (count on the device: the launches are sized for the list's capacity, blocks past the count leave at
         // once) through the f16x3 tiles, gathered from / scattered to the caller's buffers by index.  The head workspace is free again.
         HrMlpArgs ma;
-        fill_mlp_args(m, ma, rays_dev, m->redo_cap, true);
-        // (the counter is cleared for the next call by the last launch of this one, which reads the copy the launch before it made)
+        fill_mlp_args(m, ma, rays_dev, m->redo_cap, 1);
+        // (the counter is cleared for the next call by the last launch of this pass, which reads the copy the launch before it made)
         ma.ray_index = m->redo_list;
         ma.n_rays_dev = m->redo_count;
         ma.n_rays_copy = m->redo_count + 1;
-        launch_mlp(m, m->kcfg, ma, st, true);
+        ma.redo_list = m->wide_list;               // a tile of THIS pass in which an activation leaves the half range goes on to the third
+        ma.redo_count = m->redo_count + 2;
+        ma.redo_cap = m->wide_cap;
+        launch_mlp(m, m->kcfg, ma, st, 1);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays_dev, m->redo_cap, rgb_dev);
         sa.ray_index = m->redo_list;
         sa.n_rays_dev = m->redo_count + 1;
         sa.zero_word = m->redo_count;
+        hr_launch_samples(m->kcfg, sa, st);
+        // third pass: those tiles' rays with the bf16x3 tiles -- halves with the fp32 exponent range, nothing to overflow.  What a captured
+        // viewer loop gets where the host's guard (models.py: a sticky bit read between calls) cannot reach
+        fill_mlp_args(m, ma, rays_dev, m->wide_cap, 2);
+        ma.ray_index = m->wide_list;
+        ma.n_rays_dev = m->redo_count + 2;
+        ma.n_rays_copy = m->redo_count + 3;
+        launch_mlp(m, m->kcfg, ma, st, 2);
+        fill_sample_args(m, sa, rays_dev, m->wide_cap, rgb_dev);
+        sa.ray_index = m->wide_list;
+        sa.n_rays_dev = m->redo_count + 3;
+        sa.zero_word = m->redo_count + 2;
         hr_launch_samples(m->kcfg, sa, st);
     }
     HR_HIP(hipGetLastError());
@@ -1361,14 +1389,14 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
     else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
     else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW || option == HR_OPT_MLP_F8_SATURATED ||
-             option == HR_OPT_MLP_VERIFIED || option == HR_OPT_REDO_OVERFLOW || option == HR_OPT_REDO_COUNT) {
+             option == HR_OPT_MLP_VERIFIED || option == HR_OPT_REDO_OVERFLOW || option == HR_OPT_REDO_COUNT || option == HR_OPT_WIDE_COUNT) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
         if (option == HR_OPT_MLP_PRECISION_ACTIVE) *value = m->active_precision;
         else if (option == HR_OPT_MLP_CALIBRATED) *value = m->calibrated;
         else if (option == HR_OPT_MLP_VERIFIED) *value = m->verified;
-        else if (option == HR_OPT_REDO_COUNT) {
+        else if (option == HR_OPT_REDO_COUNT || option == HR_OPT_WIDE_COUNT) {
             unsigned n = 0;
-            if (m->redo_count) HR_HIP(hipMemcpy(&n, m->redo_count + 1, sizeof(unsigned), hipMemcpyDeviceToHost));      // the second pass's copy
+            if (m->redo_count) HR_HIP(hipMemcpy(&n, m->redo_count + (option == HR_OPT_REDO_COUNT ? 1 : 3), sizeof(unsigned), hipMemcpyDeviceToHost));      // the pass's copy
             *value = (int32_t)n;
         } else if (option == HR_OPT_REDO_OVERFLOW) {
             unsigned f = 0;
@@ -1991,6 +2019,7 @@ void hr_model_destroy(hr_model* m)
     }
     free_safe_pack(m);
     free_dev(reinterpret_cast<float*&>(m->redo_list));
+    free_dev(reinterpret_cast<float*&>(m->wide_list));
     free_dev(reinterpret_cast<float*&>(m->redo_count));
     for (int j = 0; j < 3; ++j) {
         free_dev(m->grid_a[j]);

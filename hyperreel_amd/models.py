@@ -647,6 +647,10 @@ class HipLightfieldModel(nn.Module):
         """Rays the last render() listed for its second pass (synchronises)."""
         return self._get_option(_lib.HR_OPT_REDO_COUNT)
 
+    def wide_count(self):
+        """Rays the last render() passed on to its third pass (bf16x3 tiles) because an activation left the IEEE-half range (synchronises)."""
+        return self._get_option(_lib.HR_OPT_WIDE_COUNT)
+
     def redo_overflowed(self):
         """Sticky: a render() listed more rays than the list holds (min(chunk, 65536)); the excess kept their first-pass pixels."""
         return bool(self._get_option(_lib.HR_OPT_REDO_OVERFLOW))

@@ -324,10 +324,13 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit.
  * HR_OPT_MLP_VERIFIED 1 when hr_render runs the verified fast path (HR_MLP_F16F8V); HR_OPT_REDO_COUNT the number of rays the last hr_render listed
  * for its second pass (reading it synchronises the device); HR_OPT_REDO_OVERFLOW the sticky bit raised when a call listed more rays than the
- * list holds (min(chunk, 65 536)): the excess rays keep their first-pass pixels -- re-create the model with HR_MLP_F16X3 for such scenes. */
+ * list holds (min(chunk, 65 536)): the excess rays keep their first-pass pixels -- re-create the model with HR_MLP_F16X3 for such scenes.
+ * HR_OPT_WIDE_COUNT: rays the last hr_render passed on to the THIRD pass (bf16x3 tiles: halves with the fp32 exponent range) because an activation of
+ * theirs left the IEEE-half range in the second -- the device-side form of the overflow fallback, inside a captured graph too.  In the verified
+ * mode HR_OPT_MLP_OVERFLOW / HR_OPT_MLP_F8_SATURATED are raised only for rays that could not be listed (a full list). */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
        HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6, HR_OPT_MLP_F8_SATURATED = 7,
-       HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10 };
+       HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10, HR_OPT_WIDE_COUNT = 11 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

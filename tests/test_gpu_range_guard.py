@@ -75,37 +75,45 @@ def test_forced_fp16_arithmetic_is_refused_by_name_when_it_would_overflow(forced
 
 def test_sticky_overflow_bit_reports_rendered_rays_that_leave_the_half_range():
     """calibration cannot see every ray: rays whose Pluecker moment is ~1e6 (origins a million scene units away) put input features
-    beyond 65504 -- the kernels must say so (HR_OPT_MLP_OVERFLOW), on both execution plans"""
+    beyond 65504 -- a forced fp16 arithmetic must say so (HR_OPT_MLP_OVERFLOW), on both execution plans; the default (the verified path)
+    repairs those rays on the device instead (f16f8 -> f16x3 -> bf16x3 tiles, tests/test_gpu_verified.py) and has nothing to report"""
     from gpu_common import make_render_fn, render_np
     g = Golden('donerf_sphere_small')
+    far = g.rays.copy()
+    far[:, :3] *= 1e6
     for frame_kernel in (True, False):
-        fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+        fn = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3')
         fn.model.set_execution(frame_kernel=frame_kernel)
-        assert fn.model.mlp_precision_active() == AUTO
         render_np(fn, g.rays)
         assert not fn.model.mlp_overflowed()
-        far = g.rays.copy()
-        far[:, :3] *= 1e6
-        fn.model._render_calls = 16           # past the calls on which render() polls the bit itself (and would fall back: the test below)
+        fn.model._render_calls = 16           # past the calls on which render() polls the bit itself (and would refuse: the test below)
         render_np(fn, far)
         assert fn.model.mlp_overflowed()
         fn.model.calibrate(torch.from_numpy(g.rays).cuda())      # a new calibration clears the bit
         assert not fn.model.mlp_overflowed()
         with pytest.raises(Exception, match='bf16x3'):
-            # `auto` on THOSE rays falls back; forcing f16x3 on them is refused
+            # forcing f16x3 on THOSE rays is refused
             make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3').model.calibrate(torch.from_numpy(far).cuda())
-        fn.model.calibrate(torch.from_numpy(far).cuda())
-        assert fn.model.mlp_precision_active() == 'bf16x3'
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+    assert fn.model.mlp_precision_active() == AUTO
+    img = render_np(fn, far)['rgb']
+    ref = render_np(make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='bf16x3'), far)['rgb']
+    assert np.isfinite(img).all() and np.array_equal(img, ref) and fn.model.wide_count() >= far.shape[0]
+    assert not fn.model.mlp_overflowed() and fn.model.mlp_precision_active() == AUTO
+    fn.model.calibrate(torch.from_numpy(far).cuda())             # `auto` calibrated on THOSE rays takes the fp32-range split outright
+    assert fn.model.mlp_precision_active() == 'bf16x3'
 
 
 def test_first_render_call_checks_the_bit_and_falls_back_to_bf16x3():
     """the arithmetic is chosen on synthetic calibration rays; a model whose FIRST real batch leaves the half range must not
-    return an image made from saturated operands -- render() reads the sticky bit on the first call, re-decides on those rays (auto ->
-    bf16x3) and renders the batch again"""
+    return an image made from saturated operands.  The verified default repairs such rays on the device up to its third list's capacity
+    (8192 rays); a batch with more of them fills the list, the kernels raise the sticky bit, and render() -- which reads it on the first
+    calls -- re-decides on those rays (auto -> bf16x3) and renders the batch again"""
     from gpu_common import make_render_fn, render_np
     g = Golden('donerf_sphere_small')
-    far = g.rays.copy()
+    far = np.concatenate([g.rays] * 80, 0)
     far[:, :3] *= 1e6
+    assert far.shape[0] > 2 * 8192
     fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
     assert fn.model.mlp_precision_active() == AUTO
     with pytest.warns(UserWarning, match='IEEE-half range'):
