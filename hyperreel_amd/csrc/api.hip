@@ -17,7 +17,7 @@
 
 // sample wavefronts per workgroup of the frame kernel when the caller does not say (measured: DESIGN.md section 3)
 #ifndef HR_DEFAULT_SAMPLE_WAVES
-#define HR_DEFAULT_SAMPLE_WAVES 0      // the plan's own choice (8)
+#define HR_DEFAULT_SAMPLE_WAVES 0      // the plan's own choice (4 on 64-ray tiles, 8 on 32-ray tiles)
 #endif
 
 namespace {
@@ -1084,6 +1084,10 @@ static HrGridPlane render_plane(const hr_model* m, int j)
     return g;
 }
 
+#ifdef HR_DEBUG_HSUM
+static unsigned* g_dbg_hsum = nullptr;
+extern "C" void hr_debug_set_hsum(void* p) { g_dbg_hsum = (unsigned*)p; }
+#endif
 static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* rays, int64_t n, float* rgb)
 {
     a.cfg_dev = m->kcfg_dev;
@@ -1116,6 +1120,9 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.redo_cap = 0;
     a.redo_band = 0.0f;
     a.flags = m->flags;
+#ifdef HR_DEBUG_HSUM
+    a.dbg_hsum = g_dbg_hsum;
+#endif
     a.occ = m->occ;
     a.occ_cells = m->occ_cells;
     a.occ_w = m->occ_n[0]; a.occ_h = m->occ_n[1]; a.occ_d = m->occ_n[2];

@@ -143,6 +143,9 @@ struct HrSampleArgs {
     int redo_cap;
     float redo_band;
     unsigned* flags;        // the model's sticky status word (bit 2: the redo list overflowed)
+#ifdef HR_DEBUG_HSUM        // measurement builds (tools/hsum_bisect.py): per ray, the XOR of the bits of every head value the sample stage read, and of its sorted distances
+    unsigned* dbg_hsum;     // [n_rays][2]
+#endif
 };
 
 // training forward (mlp_split_impl.inc, HR_SPLIT_TRAIN_KERNEL): where the output of hidden Linear l (after its LeakyReLU) goes besides LDS --

@@ -1,0 +1,58 @@
+"""Which side differs when a frame-kernel render differs from itself?  (the open run-to-run difference.)
+A -DHR_DEBUG_HSUM build makes the sample stage write, per ray, the XOR of the bits of every head value it READ and of its sorted distances.
+The same rays are rendered again and again on one stream; when an image differs from the first, the checksums of the differing ray say whether
+the HEAD it read differed (MLP side / hand-over) or the head was the same and the sample stage computed something else from it.
+    HR_LIB=tools/_bin/libhr_hsum.so python tools/hsum_bisect.py [--iters 200] [--waves 8] [--plan frame|two]
+GPU box; measurement aid."""
+import argparse, ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from hyperreel_amd import lib as hl
+hl.LIB_PATH = os.path.abspath(os.environ['HR_LIB'])
+from helpers import Golden
+from gpu_common import make_render_fn
+ap = argparse.ArgumentParser()
+ap.add_argument('--iters', type=int, default=200)
+ap.add_argument('--waves', type=int, default=8)
+ap.add_argument('--plan', default='frame')
+ap.add_argument('--case', default='donerf_sphere_small')
+ap.add_argument('--precision', default='f16x3')
+args = ap.parse_args()
+g = Golden(args.case)
+rep = max(1, 160000 // g.rays.shape[0])
+rays = torch.from_numpy(np.concatenate([g.rays] * rep + [g.rays[:37]], 0)).cuda()
+fns = [make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision=args.precision) for _ in range(2)]
+for f in fns:
+    f.model.set_execution(frame_kernel=(args.plan == 'frame'), sample_waves=args.waves)
+    f.model.native()
+L = hl.load()
+L.hr_debug_set_hsum.argtypes = [ctypes.c_void_p]
+L.hr_debug_set_hsum.restype = None
+n = rays.shape[0]
+hs = torch.zeros((n, 8), dtype=torch.int32, device='cuda')
+L.hr_debug_set_hsum(ctypes.c_void_p(hs.data_ptr()))
+ref = fns[0].model.render(rays)['rgb'].clone()
+torch.cuda.synchronize()
+ref_hs = hs.clone()
+print('plan', 'frame kernel' if fns[0].model.frame_kernel_active() else 'two kernels', 'waves', args.waves, flush=True)
+out = torch.empty_like(ref)
+bad = 0
+rows = []
+for it in range(args.iters):
+    for f in fns:
+        for _ in range(3):
+            hs.zero_()
+            f.model.render(rays, out=out)
+            torch.cuda.synchronize()
+            if not torch.equal(out, ref):
+                bad += 1
+                rr = (out != ref).any(-1).nonzero().flatten()
+                r = int(rr[0])
+                rows += [int(x) % 64 for x in rr.cpu().numpy()]
+                print(f'   head as read BEFORE the distance {"DIFFERS" if int(hs[r, 4]) != int(ref_hs[r, 4]) else "same"}; ray / anchors {"DIFFER" if int(hs[r, 5]) != int(ref_hs[r, 5]) else "same"}')
+                print(f'iter {it}: {len(rr)} rays differ; ray {r} (ray % 8 = {r % 8}), |d| {float((out[r] - ref[r]).abs().max()):.3e}; head checksum {"DIFFERS" if int(hs[r, 0]) != int(ref_hs[r, 0]) else "same"}, '
+                      f'distance before the sort {"DIFFERS" if int(hs[r, 2]) != int(ref_hs[r, 2]) else "same"}, after the sort {"DIFFERS" if int(hs[r, 3]) != int(ref_hs[r, 3]) else "same"}, '
+                      f'final distance {"DIFFERS" if int(hs[r, 1]) != int(ref_hs[r, 1]) else "same"}', flush=True)
+print(f'{bad} of {args.iters * 6} renders differed; rows of the 64-ray tile that differed: {sorted(set(rows))}', flush=True)
+os._exit(0)
