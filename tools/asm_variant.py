@@ -6,6 +6,10 @@ Modes (hipcc inserts what the ISA manual lists; these add MORE, to find which di
   trans:N     s_nop N after every transcendental (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos)
   divfmas:N   s_nop N in front of every v_div_fmas (reads the VCC its v_div_scale wrote)
   cndmask:N   s_nop N in front of every v_cndmask
+  readlane:N  s_nop N after every v_readlane / v_readfirstlane (VALU writes an SGPR: the restores of spilled SGPRs)
+  vcmp:N      s_nop N after every v_cmp
+  sgprwar:N   s_nop N in front of every instruction that writes an SGPR a vector instruction read within the last HR_ASM_WINDOW (4) instructions
+  padsample:N / padmlp:N  s_nop N in front of every instruction of one role of the frame kernel
 Measurement aid; the product build is hyperreel_amd/build.py."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,19 +46,89 @@ def patch_region(text, kind, n):
     return '\n'.join(out), cnt
 
 
+def sgprs(tok):
+    """SGPR numbers named by an operand token ('s12', 's[12:15]', 'vcc' -> {'vcc'})"""
+    tok = tok.strip()
+    m = re.fullmatch(r's(\d+)', tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r's\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    if tok in ('vcc', 'vcc_lo', 'vcc_hi'):
+        return {'vcc'}
+    return set()
+
+
+def patch_sgpr_war(text, n, window):
+    """sgprwar:N -- write-after-read on scalar registers: when an instruction WRITES an SGPR (a scalar ALU result, v_readlane / v_readfirstlane, a
+    v_cmp mask) that a vector instruction READ as an operand within the last `window` instructions, s_nop N in front of the writer.  (No such
+    rule exists in the ISA manual or in the compiler; the question is whether a vector instruction delayed beside co-issued MFMA wavefronts can
+    still be reading the register for its later lanes.)"""
+    out, cnt = [], 0
+    last_read = {}            # sgpr -> index of the last VALU instruction that read it
+    idx = 0
+    for ln in text.split('\n'):
+        m = re.match(r'^\s+([vs]_\w+|ds_\w+|global_\w+|buffer_\w+|scratch_\w+|flat_\w+)\s*(.*?)\s*(;.*)?$', ln)
+        if not m or ln.lstrip().startswith(('.', ';')):
+            if re.match(r'^[\w.$]+:', ln):
+                last_read.clear()             # a label: control flow joins, start over
+            out.append(ln)
+            continue
+        op, rest = m.group(1), m.group(2)
+        ops = [t for t in re.split(r',\s*', rest)] if rest else []
+        writes, reads = set(), set()
+        if op.startswith('s_'):
+            if not re.match(r's_(nop|waitcnt|barrier|branch|cbranch|endpgm|sleep|setprio|cmp|bitcmp|store|dcache|icache|sendmsg|sethalt|trap|setkill)', op) and ops:
+                writes = sgprs(ops[0])
+                if re.match(r's_(and|or|andn2|orn2|xor|nand|nor|xnor)_saveexec', op):
+                    pass
+        elif op.startswith('v_'):
+            if re.match(r'v_read(first)?lane_b32', op):
+                writes = sgprs(ops[0]); ops = ops[1:]
+            elif re.match(r'v_cmpx?_', op):
+                if op.endswith('_e32') or (ops and not sgprs(ops[0]) and not ops[0].startswith('s')):
+                    writes = {'vcc'}
+                else:
+                    writes = sgprs(ops[0]); ops = ops[1:]
+            elif re.match(r'v_(div_scale|add_co|sub_co|subrev_co|addc_co|subb_co|subbrev_co|mad_u64_u32|mad_i64_i32)', op) and len(ops) > 1:
+                writes = sgprs(ops[1]); ops = [ops[0]] + ops[2:]
+            for t in ops[1:] if not re.match(r'v_cmpx?_', op) else ops:
+                reads |= sgprs(t)
+            if re.match(r'v_(div_fmas|cndmask_b32_e32|addc_co_u32_e32|subb_co_u32_e32)', op):
+                reads.add('vcc')
+        hot = [r for r in writes if r in last_read and idx - last_read[r] <= window]
+        if hot:
+            out.append(f'\ts_nop {n}'); cnt += 1
+        out.append(ln)
+        if op.startswith('v_'):
+            for r in reads:
+                last_read[r] = idx
+        idx += 1
+    return '\n'.join(out), cnt
+
+
 def patch(text, mode):
     kind, _, n = mode.partition(':')
     n = int(n or 3)
     if kind in ('padsample', 'padmlp'):
         return patch_region(text, kind, n)
+    if kind == 'sgprwar':
+        return patch_sgpr_war(text, n, int(os.environ.get('HR_ASM_WINDOW', '4')))
     out, cnt = [], 0
     for ln in text.split('\n'):
         if kind == 'divfmas' and re.match(r'^\s+v_div_fmas', ln):
             out.append(f'\ts_nop {n}'); cnt += 1
         if kind == 'cndmask' and re.match(r'^\s+v_cndmask', ln):
             out.append(f'\ts_nop {n}'); cnt += 1
+        if kind == 'salumask' and re.match(r'^\s+s_(and|or|andn2|orn2|xor|and_saveexec|or_saveexec|andn2_saveexec|mov)_b64|^\s+s_cbranch_(vcc|exec)', ln):     # scalar readers of lane masks
+            out.append(f'\ts_nop {n}'); cnt += 1
         out.append(ln)
         if kind == 'trans' and TRANS.match(ln):
+            out.append(f'\ts_nop {n}'); cnt += 1
+        if kind == 'readlane' and re.match(r'^\s+v_read(first)?lane_b32', ln):     # a VALU instruction that writes an SGPR (SGPR-spill restores)
+            out.append(f'\ts_nop {n}'); cnt += 1
+        if kind == 'vcmp' and re.match(r'^\s+v_cmp', ln):                            # ... a lane mask
             out.append(f'\ts_nop {n}'); cnt += 1
     return '\n'.join(out), cnt
 

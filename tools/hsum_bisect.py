@@ -30,7 +30,7 @@ L = hl.load()
 L.hr_debug_set_hsum.argtypes = [ctypes.c_void_p]
 L.hr_debug_set_hsum.restype = None
 n = rays.shape[0]
-hs = torch.zeros((n, 8), dtype=torch.int32, device='cuda')
+hs = torch.zeros((n, 16), dtype=torch.int32, device='cuda')
 L.hr_debug_set_hsum(ctypes.c_void_p(hs.data_ptr()))
 ref = fns[0].model.render(rays)['rgb'].clone()
 torch.cuda.synchronize()
@@ -38,13 +38,16 @@ ref_hs = hs.clone()
 print('plan', 'frame kernel' if fns[0].model.frame_kernel_active() else 'two kernels', 'waves', args.waves, flush=True)
 out = torch.empty_like(ref)
 bad = 0
+mism_total = 0
 rows = []
+firsts = []
 for it in range(args.iters):
     for f in fns:
         for _ in range(3):
             hs.zero_()
             f.model.render(rays, out=out)
             torch.cuda.synchronize()
+            mism_total += int(hs[:, 6].sum())
             if not torch.equal(out, ref):
                 bad += 1
                 rr = (out != ref).any(-1).nonzero().flatten()
@@ -54,5 +57,11 @@ for it in range(args.iters):
                 print(f'iter {it}: {len(rr)} rays differ; ray {r} (ray % 8 = {r % 8}), |d| {float((out[r] - ref[r]).abs().max()):.3e}; head checksum {"DIFFERS" if int(hs[r, 0]) != int(ref_hs[r, 0]) else "same"}, '
                       f'distance before the sort {"DIFFERS" if int(hs[r, 2]) != int(ref_hs[r, 2]) else "same"}, after the sort {"DIFFERS" if int(hs[r, 3]) != int(ref_hs[r, 3]) else "same"}, '
                       f'final distance {"DIFFERS" if int(hs[r, 1]) != int(ref_hs[r, 1]) else "same"}', flush=True)
+                names = ['activated head value (sigmoid: exp, division)', 'radius (inverse contraction)', 'o.o', 'o.d', 'discriminant', 'sqrt', 't1 (division)', 't2 (division)']
+                first = [nm for i, nm in enumerate(names) if int(hs[r, 8 + i]) != int(ref_hs[r, 8 + i])]
+                firsts.append(first[0] if first else 'none of the intermediates')
+                print('   intermediates that differ, in evaluation order:', first, flush=True)
+print('first differing intermediate:', {k: firsts.count(k) for k in set(firsts)})
+print(f'double reads of the head that disagreed (all renders): {mism_total};', end=' ')
 print(f'{bad} of {args.iters * 6} renders differed; rows of the 64-ray tile that differed: {sorted(set(rows))}', flush=True)
 os._exit(0)
