@@ -7,6 +7,8 @@
 //   C     two products and two sums as the compiler emits them
 //   pk    v_pk_mul_f32 then v_pk_add_f32
 //   sel   v_pk_mul_f32 with op_sel_hi:[1,0] (high result = a.hi * b.lo), the form in the frame kernel, then v_pk_add_f32
+//   mov   the same, its source pair written by two v_mov_b32 directly in front of it (as in the frame kernel)
+//   exec  'mov' in a data-dependent half of the lanes, the scalar form in the others (partial EXEC)
 // every product and sum of two floats is exactly defined, so the host computes every lane's checksum.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/coissue_pk_ubench.hip -o tools/_bin/coissue_pk_ubench && tools/_bin/coissue_pk_ubench
 #include <hip/hip_runtime.h>
@@ -61,10 +63,18 @@ __global__ __launch_bounds__(768) void k(unsigned* out, int iters, int mfma_on)
             const unsigned long long a = ((unsigned long long)__builtin_bit_cast(unsigned, a1) << 32) | __builtin_bit_cast(unsigned, a0);
             const unsigned long long b = ((unsigned long long)__builtin_bit_cast(unsigned, b1) << 32) | __builtin_bit_cast(unsigned, b0);
             unsigned long long p, q;
-            if (HOW == 1) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));                          // {a0 b0, a1 b1}
-            else          asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));          // {a0 b0, a1 b0}: the form in the frame kernel
-            asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(q) : "v"(p), "v"(a));
-            q0 = __builtin_bit_cast(float, (unsigned)q); q1 = __builtin_bit_cast(float, (unsigned)(q >> 32));
+            const bool scalar_lane = (HOW == 4) && (s & 0x10000u);              // HOW 4: a data-dependent half of the lanes takes the scalar form (partial EXEC around the packed one)
+            if (scalar_lane) {
+                const float p0 = a0 * b0, p1 = a1 * b0;
+                q0 = p0 + a0; q1 = p1 + a1;
+            } else {
+                if (HOW == 1) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));                          // {a0 b0, a1 b1}
+                else if (HOW == 2) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));     // {a0 b0, a1 b0}: the form in the frame kernel
+                else          // ... and its surroundings there: the register pair is written by two v_mov_b32 DIRECTLY in front of the packed instruction
+                    asm volatile("v_mov_b32 v20, %1\n\tv_mov_b32 v21, %2\n\tv_pk_mul_f32 %0, v[20:21], %3 op_sel_hi:[1,0]" : "=v"(p) : "v"(a0), "v"(a1), "v"(b) : "v20", "v21");
+                asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(q) : "v"(p), "v"(a));
+                q0 = __builtin_bit_cast(float, (unsigned)q); q1 = __builtin_bit_cast(float, (unsigned)(q >> 32));
+            }
         }
         unsigned w0 = __builtin_bit_cast(unsigned, q0), w1 = __builtin_bit_cast(unsigned, q1);
         h = (h ^ w0) * 31u;               // (not h * 31 + w: this hipcc selects v_mad_u64_u32 for it and hands the SAME 64-bit register pair to both steps -- q[1] is never added)
@@ -89,7 +99,7 @@ static int run(const char* name, int cus, int iters, int rounds)
                 s = lcg(s); const float a1 = unit(s);
                 s = lcg(s); const float b0 = unit(s);
                 s = lcg(s); const float b1 = unit(s);
-                volatile float p0 = a0 * b0, p1 = a1 * (HOW == 2 ? b0 : b1);
+                volatile float p0 = a0 * b0, p1 = a1 * (HOW >= 2 ? b0 : b1);
                 const float q0 = p0 + a0, q1 = p1 + a1;
                 h = (h ^ bits(q0)) * 31u; h = (h ^ bits(q1)) * 2654435761u;
             }
@@ -126,5 +136,7 @@ int main(int argc, char** argv)
     run<0>("C", cus, iters, rounds);
     run<1>("pk", cus, iters, rounds);
     run<2>("sel", cus, iters, rounds);
+    run<3>("mov", cus, iters, rounds);
+    run<4>("exec", cus, iters, rounds);
     return 0;
 }
