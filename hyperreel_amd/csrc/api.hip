@@ -17,7 +17,7 @@
 
 // sample wavefronts per workgroup of the frame kernel when the caller does not say (measured: DESIGN.md section 3)
 #ifndef HR_DEFAULT_SAMPLE_WAVES
-#define HR_DEFAULT_SAMPLE_WAVES 0      // the plan's own choice (4 on 64-ray tiles, 8 on 32-ray tiles)
+#define HR_DEFAULT_SAMPLE_WAVES 0      // the plan's own choice (8)
 #endif
 
 namespace {

@@ -308,8 +308,7 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         2: additionally the keyframe families (480-column heads, 960 at 64 samples per ray;
  *                         nlf/nets/tensorf_dynamic.py:645-839) on 32-ray tiles, two head buffers where they fit: same images, no
  *                         head workspace traffic, measured as fast as or slower than two kernels (hence not part of 1).
- *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default -- 4 on 64-ray tiles since round 5: with 8,
- *                         repeated launches of the same frame differ in a single ray now and then; 8 on 32-ray tiles).
+ *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default, 8).
  *   HR_OPT_TRAIN_DETERMINISTIC  1: hr_train_backward accumulates every gradient that many samples add to -- texel gradients, basis_mat's,
  *                         the colour table's -- as 64-bit fixed point (2^-40 units) with integer atomics instead of fp32 atomics: the
  *                         result does not depend on the order of the adds, so two runs of the same step agree bit for bit (the
