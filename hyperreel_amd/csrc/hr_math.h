@@ -282,14 +282,14 @@ HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius, HrRisk* r
     float disc = b * b - 4.0f * a * cc;
     // at risk: the discriminant's sign (relative to the two terms it is the difference of) and the radius' sign
     if (risk) risk->hit = risk->hit || (fabsf(disc) <= risk->rel * (b * b + fabsf(4.0f * a * cc))) || (fabsf(radius) <= risk->band);
-#ifdef HR_DEBUG_HSUM
+#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
     if (risk) risk->dbg[4] = disc;
 #endif
     disc = (disc < 0.0f) ? 0.0f : disc;
     float sq = HR_SQRT(disc + 1e-8f);
     float t1 = HR_DIV(-b + sq, 2.0f * a);
     float t2 = HR_DIV(-b - sq, 2.0f * a);
-#ifdef HR_DEBUG_HSUM
+#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
     if (risk) { risk->dbg[5] = sq; risk->dbg[6] = t1; risk->dbg[7] = t2; }
 #endif
     if (risk) risk->hit = risk->hit || (fabsf(t2) <= risk->band);        // ... and the sign of the near root (which root is returned)
@@ -414,17 +414,22 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
             sz = hr_zval(c, hk, 2, one_m) * c.origin_scale + c.origin_initial[2];
         }
         float radius = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
-#ifdef HR_DEBUG_HSUM
+#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
         if (risk) { risk->dbg[0] = hr_zval(c, hk, 3, one_m); risk->dbg[1] = radius; }
 #endif
         float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
         float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
+#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM == 2      // -DHR_DEBUG_HSUM=2: the six products and the two sums, per lane (tools/hsum_bisect.py --lanes)
+        if (risk) { risk->dbg[0] = ox; risk->dbg[1] = oy; risk->dbg[2] = oz; risk->dbg[3] = dx; risk->dbg[4] = dy; risk->dbg[5] = dz; }
+#endif
         if (c.isect_type == HR_ISECT_SPHERE) {
             float oo = ox * ox + oy * oy + oz * oz;
             float dd = dx * dx + dy * dy + dz * dz;
             float od = ox * dx + oy * dy + oz * dz;
-#ifdef HR_DEBUG_HSUM
+#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
             if (risk) { risk->dbg[2] = oo; risk->dbg[3] = od; }
+#elif defined(HR_DEBUG_HSUM)
+            if (risk) { risk->dbg[6] = oo; risk->dbg[7] = od; }
 #endif
             dist = hr_quadratic_t(oo, dd, od, radius, risk);
         } else {

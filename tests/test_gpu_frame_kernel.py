@@ -131,7 +131,7 @@ def test_frame_kernel_ragged_ray_counts(n):
 @pytest.mark.parametrize('waves', [4, 8])
 def test_frame_kernel_full_frame_every_word_and_repeats(waves):
     """BASELINE configs[1] at full size: 640 000 rays = 10 000 tiles, 39-40 per persistent workgroup.  Every rgb word equals
-    the two-kernel path; ten more launches (hand-over timing differs from run to run) reproduce it exactly; rays in a
+    the two-kernel path; thirty more launches (hand-over timing differs from run to run) reproduce it exactly; rays in a
     different order (other tiles share a workgroup) give the same pixels.
     waves = 8: until round 5 a launch could differ from the two-kernel image in ONE ray (lanes 32-63 of a sample wavefront that shares its SIMD
     with MFMA wavefronts computed a sum of products whose last bits differed, about once per 10^7 rays); the library is now built without the

@@ -18,6 +18,7 @@ ap.add_argument('--waves', type=int, default=8)
 ap.add_argument('--plan', default='frame')
 ap.add_argument('--case', default='donerf_sphere_small')
 ap.add_argument('--precision', default='f16x3')
+ap.add_argument('--lanes', action='store_true', help='a -DHR_DEBUG_HSUM=2 build: per-lane raw values of the six products ro * s, rd * s and of o.o, o.d')
 args = ap.parse_args()
 g = Golden(args.case)
 rep = max(1, 160000 // g.rays.shape[0])
@@ -30,7 +31,7 @@ L = hl.load()
 L.hr_debug_set_hsum.argtypes = [ctypes.c_void_p]
 L.hr_debug_set_hsum.restype = None
 n = rays.shape[0]
-hs = torch.zeros((n, 16), dtype=torch.int32, device='cuda')
+hs = torch.zeros((n, 280 if args.lanes else 16), dtype=torch.int32, device='cuda')
 L.hr_debug_set_hsum(ctypes.c_void_p(hs.data_ptr()))
 ref = fns[0].model.render(rays)['rgb'].clone()
 torch.cuda.synchronize()
@@ -41,6 +42,7 @@ bad = 0
 mism_total = 0
 rows = []
 firsts = []
+lane_cols = []
 for it in range(args.iters):
     for f in fns:
         for _ in range(3):
@@ -57,10 +59,21 @@ for it in range(args.iters):
                 print(f'iter {it}: {len(rr)} rays differ; ray {r} (ray % 8 = {r % 8}), |d| {float((out[r] - ref[r]).abs().max()):.3e}; head checksum {"DIFFERS" if int(hs[r, 0]) != int(ref_hs[r, 0]) else "same"}, '
                       f'distance before the sort {"DIFFERS" if int(hs[r, 2]) != int(ref_hs[r, 2]) else "same"}, after the sort {"DIFFERS" if int(hs[r, 3]) != int(ref_hs[r, 3]) else "same"}, '
                       f'final distance {"DIFFERS" if int(hs[r, 1]) != int(ref_hs[r, 1]) else "same"}', flush=True)
+                if args.lanes:
+                    got = hs[r, 16:272].view(32, 8).cpu().numpy().view(np.float32); want = ref_hs[r, 16:272].view(32, 8).cpu().numpy().view(np.float32)
+                    rr_ = hs[r, 272:278].cpu().numpy().view(np.float32)
+                    lab = ['ox', 'oy', 'oz', 'dx', 'dy', 'dz', 'o.o', 'o.d']
+                    for ln in np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(-1))[0][:4]:
+                        bad_cols = np.nonzero(got[ln].view(np.uint32) != want[ln].view(np.uint32))[0]
+                        print(f'   lane {ln} of the ray (ro {rr_[:3].tolist()}, rd {rr_[3:].tolist()}): ' + '; '.join(f'{lab[c]} got {got[ln, c]!r} ({got[ln, c].view(np.uint32):#010x}) alone {want[ln, c]!r} ({want[ln, c].view(np.uint32):#010x})' for c in bad_cols), flush=True)
+                        print('      all eight, got  :', [float(x) for x in got[ln]]); print('      all eight, alone:', [float(x) for x in want[ln]], flush=True)
+                    lane_cols.append(tuple(sorted(set(int(c) for ln in range(32) for c in np.nonzero(got[ln].view(np.uint32) != want[ln].view(np.uint32))[0]))))
+                    continue
                 names = ['activated head value (sigmoid: exp, division)', 'radius (inverse contraction)', 'o.o', 'o.d', 'discriminant', 'sqrt', 't1 (division)', 't2 (division)']
                 first = [nm for i, nm in enumerate(names) if int(hs[r, 8 + i]) != int(ref_hs[r, 8 + i])]
                 firsts.append(first[0] if first else 'none of the intermediates')
                 print('   intermediates that differ, in evaluation order:', first, flush=True)
+if args.lanes: print('which of (ox oy oz dx dy dz o.o o.d) differ, per differing render:', {k: lane_cols.count(k) for k in set(lane_cols)})
 print('first differing intermediate:', {k: firsts.count(k) for k in set(firsts)})
 print(f'double reads of the head that disagreed (all renders): {mism_total};', end=' ')
 print(f'{bad} of {args.iters * 6} renders differed; rows of the 64-ray tile that differed: {sorted(set(rows))}', flush=True)
