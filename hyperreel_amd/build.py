@@ -19,12 +19,12 @@ HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by
 # operation (the reference never fuses a multiply with an add across torch ops); the
 # places where fusion is wanted use __builtin_fmaf explicitly.
-# -fno-slp-vectorize: no packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 with op_sel modifiers) built by the compiler out of the
-# sample stage's scalar arithmetic.  With them, a sample wavefront that shares its SIMD with MFMA wavefronts (the frame kernel with 8 sample
-# wavefronts; the MLP kernel of one stream beside the sample kernel of another) computes, once in ~1e8 samples and only in lanes 32-63, a sum
-# of products that differs in the last bits from the one it computes alone -- the first differing intermediate is o.o of the sphere
-# intersection, exactly the values those instructions produce (profiles/r05_frame_kernel_difference_bisect.txt).  Without them:
-# 0 differing renders in 600 + 960 + 480 (was 600, 2-13 per 80, 0-6 per 40), the same bits everywhere else, and no cost (K2 0.697 vs 0.700 ms).
+# -fno-slp-vectorize: no packed-fp32 instructions built by the compiler out of the sample stage's scalar arithmetic.  One of them -- an
+# in-place  v_pk_mul_f32 v[2:3], v[52:53], v[2:3] op_sel:[0,1]  in the sphere intersection -- loses its low result in the last 16 lanes of a
+# sample wavefront that shares its SIMD with MFMA wavefronts (the frame kernel with 8 sample wavefronts; the MLP kernel of one stream beside the
+# sample kernel of another), about once in 1e8 samples: pinned at the assembly level, not reproducible in isolation (DESIGN 4,
+# profiles/r05_frame_kernel_difference_bisect.txt).  Without the flag's packed forms: 0 differing renders in 600 + 960 + 480 (was 600, 2-13
+# per 80, 0-6 per 40), the same bits everywhere else, no cost (K2 0.697 vs 0.700 ms).  The gather's hand-written packed instructions stay.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize',
          '-fno-math-errno', '-Wall', '-Wno-unused-function']
 # 1-ulp hardware exp (+ rcp inside sigmoid/tanh) for VALUES that are never compared against a threshold; divisions, square

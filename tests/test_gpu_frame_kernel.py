@@ -133,9 +133,10 @@ def test_frame_kernel_full_frame_every_word_and_repeats(waves):
     """BASELINE configs[1] at full size: 640 000 rays = 10 000 tiles, 39-40 per persistent workgroup.  Every rgb word equals
     the two-kernel path; thirty more launches (hand-over timing differs from run to run) reproduce it exactly; rays in a
     different order (other tiles share a workgroup) give the same pixels.
-    waves = 8: until round 5 a launch could differ from the two-kernel image in ONE ray (lanes 32-63 of a sample wavefront that shares its SIMD
-    with MFMA wavefronts computed a sum of products whose last bits differed, about once per 10^7 rays); the library is now built without the
-    compiler's packed-fp32 instructions (hyperreel_amd/build.py) and the form is held to the same "every word, every launch" again."""
+    waves = 8: until round 5 a launch could differ from the two-kernel image in ONE ray (the last 16 lanes of a sample wavefront that shares its
+    SIMD with MFMA wavefronts lost one term of a sum of products, about once per 10^7 rays: one compiler-formed packed-fp32 instruction); the
+    library is now built without the compiler's packed-fp32 instructions (hyperreel_amd/build.py) and the form is held to the same
+    "every word, every launch" again."""
     from gpu_common import make_render_fn
     cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf')
     sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)

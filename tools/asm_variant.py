@@ -9,6 +9,8 @@ Modes (hipcc inserts what the ISA manual lists; these add MORE, to find which di
   readlane:N  s_nop N after every v_readlane / v_readfirstlane (VALU writes an SGPR: the restores of spilled SGPRs)
   vcmp:N      s_nop N after every v_cmp
   sgprwar:N   s_nop N in front of every instruction that writes an SGPR a vector instruction read within the last HR_ASM_WINDOW (4) instructions
+  nopat:F@L:N s_nop N in front of body line L of the kernels whose mangled name starts with F
+  scalarpk[:dist|:rest|:at=F@a-b]  every v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 of the sample role replaced by two 32-bit instructions (same roundings)
   padsample:N / padmlp:N  s_nop N in front of every instruction of one role of the frame kernel
 Measurement aid; the product build is hyperreel_amd/build.py."""
 import os, re, subprocess, sys
@@ -108,9 +110,128 @@ def patch_sgpr_war(text, n, window):
     return '\n'.join(out), cnt
 
 
+PK = re.compile(r'^\s+v_pk_(mul|add|fma)_f32\s+(.*?)\s*(;.*)?$')
+
+
+def _pk_operand(tok, sel):
+    """element `sel` (0 / 1) of a packed-fp32 operand as a 32-bit operand string; None = cannot be expressed"""
+    tok = tok.strip()
+    m = re.fullmatch(r'([vs])\[(\d+):(\d+)\]', tok)
+    if m:
+        return f'{m.group(1)}{int(m.group(2)) + sel}'
+    if re.fullmatch(r'-?\d+(\.\d+)?|0x[0-9a-fA-F]+', tok):          # inline constant / literal: only its low half is the constant
+        return tok if sel == 0 else None
+    return None
+
+
+def scalarize_pk(line):
+    """v_pk_{mul,add,fma}_f32 D, A, B[, C] with op_sel / op_sel_hi / neg_lo / neg_hi  ->  two 32-bit instructions with the same roundings.
+    Returns the replacement lines, or None where it cannot be done without a temporary register."""
+    m = PK.match(line)
+    if not m:
+        return None
+    op, rest = m.group(1), m.group(2)
+    mods = dict((k, [int(x) for x in v.split(',')]) for k, v in re.findall(r'(op_sel_hi|op_sel|neg_lo|neg_hi):\[([\d,]+)\]', rest))
+    rest = re.sub(r'\s*(op_sel_hi|op_sel|neg_lo|neg_hi):\[[\d,]+\]', '', rest)
+    toks = [t.strip() for t in rest.split(',')]
+    nsrc = 3 if op == 'fma' else 2
+    if len(toks) != nsrc + 1:
+        return None
+    dm = re.fullmatch(r'v\[(\d+):(\d+)\]', toks[0])
+    if not dm:
+        return None
+    dst = [f'v{int(dm.group(1))}', f'v{int(dm.group(1)) + 1}']
+    sel = [mods.get('op_sel', [0] * nsrc), mods.get('op_sel_hi', [1] * nsrc)]
+    neg = [mods.get('neg_lo', [0] * nsrc), mods.get('neg_hi', [0] * nsrc)]
+    halves = []
+    for h in (0, 1):
+        srcs = []
+        for i in range(nsrc):
+            o = _pk_operand(toks[1 + i], sel[h][i] if i < len(sel[h]) else (h if sel[h] is None else 0))
+            if o is None:
+                return None
+            srcs.append(('-' if (i < len(neg[h]) and neg[h][i]) else '') + o)
+        halves.append(srcs)
+    if sum(1 for x in set(o.lstrip('-') for hs in halves for o in hs) if x.startswith('s')) > 1:
+        return None                      # more than one scalar register through the constant bus
+    mn = {'mul': 'v_mul_f32_e64', 'add': 'v_add_f32_e64', 'fma': 'v_fma_f32'}[op]
+    ins = [f'\t{mn} {dst[h]}, ' + ', '.join(halves[h]) for h in (0, 1)]
+    reads = [set(o.lstrip('-') for o in halves[h]) for h in (0, 1)]
+    if dst[0] not in reads[1]:
+        return ins
+    if dst[1] not in reads[0]:
+        return [ins[1], ins[0]]
+    return None
+
+
+def patch_scalarize(text, where=''):
+    """scalarpk -- every packed-fp32 multiply / add / fma of the SAMPLE role of the frame kernels (everything in front of a kernel's first
+    s_setprio) as two 32-bit instructions.  where = 'dist' / 'rest' (-DHR_PHASE_MARK builds): only those between the phase markers 102 (frame kernel: 10) and 0
+    (head activation, intersection, near / far mask) / only the others"""
+    lines = text.split('\n')
+    out, done, kept = [], 0, 0
+    in_dist = False
+    i = 0
+    while i < len(lines):
+        if not re.match(r'^(_Z\w+):', lines[i]):
+            out.append(lines[i]); i += 1; continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith('.Lfunc_end'):
+            j += 1
+        body = lines[i:j]
+        first = min((t for t, ln in enumerate(body) if re.match(r'^\s+s_setprio', ln)), default=-1)
+        for t, ln in enumerate(body):
+            pm = re.search(r'; HRPHASE (\d+)', ln)
+            if pm:
+                in_dist = pm.group(1) in ('102', '10')          # stand-alone kernel: 102, frame kernel: 10 = the marker in front of the sample body
+            if where.startswith('at='):          # at=FUNCTION_PREFIX@first-last: only body lines first..last of the kernels whose mangled name starts so
+                fn, _, rng = where[3:].partition('@')
+                lo, _, hi = rng.partition('-')
+                take = body[0].startswith(fn) and int(lo) <= t <= int(hi)
+            else:
+                take = not where or (where == 'dist') == in_dist
+            if 0 <= t < first and PK.match(ln) and take:
+                r = scalarize_pk(ln)
+                if r is None:
+                    kept += 1; out.append(ln)
+                else:
+                    done += 1; out.extend(r)
+            else:
+                out.append(ln)
+        i = j
+    print('packed instructions left as they were (would need a temporary):', kept, flush=True)
+    return '\n'.join(out), done
+
+
+def patch_nop_at(text, spec):
+    """nopat:FUNCTION_PREFIX@line:N -- s_nop N in front of ONE instruction: body line `line` of the kernels whose mangled name starts with the prefix"""
+    fn, _, rest = spec.partition('@')
+    line, _, n = rest.partition(':')
+    lines = text.split('\n')
+    out, cnt, i = [], 0, 0
+    while i < len(lines):
+        if not re.match(r'^(_Z\w+):', lines[i]):
+            out.append(lines[i]); i += 1; continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith('.Lfunc_end'):
+            j += 1
+        for t, ln in enumerate(lines[i:j]):
+            if lines[i].startswith(fn) and t == int(line):
+                out.append(f'\ts_nop {int(n or 1)}'); cnt += 1
+            out.append(ln)
+        i = j
+    return '\n'.join(out), cnt
+
+
 def patch(text, mode):
     kind, _, n = mode.partition(':')
+    if kind == 'nopat':
+        return patch_nop_at(text, n)
+    if kind == 'scalarpk':
+        return patch_scalarize(text, n)
     n = int(n or 3)
+    if kind == 'scalarpk':
+        return patch_scalarize(text, mode.partition(':')[2])
     if kind in ('padsample', 'padmlp'):
         return patch_region(text, kind, n)
     if kind == 'sgprwar':

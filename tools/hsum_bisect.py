@@ -18,6 +18,7 @@ ap.add_argument('--waves', type=int, default=8)
 ap.add_argument('--plan', default='frame')
 ap.add_argument('--case', default='donerf_sphere_small')
 ap.add_argument('--precision', default='f16x3')
+ap.add_argument('--lanes-mode', type=int, default=2, help='2: -DHR_DEBUG_HSUM=2 (products), 3: -DHR_DEBUG_HSUM=3 (the eight intermediates)')
 ap.add_argument('--lanes', action='store_true', help='a -DHR_DEBUG_HSUM=2 build: per-lane raw values of the six products ro * s, rd * s and of o.o, o.d')
 args = ap.parse_args()
 g = Golden(args.case)
@@ -62,11 +63,31 @@ for it in range(args.iters):
                 if args.lanes:
                     got = hs[r, 16:272].view(32, 8).cpu().numpy().view(np.float32); want = ref_hs[r, 16:272].view(32, 8).cpu().numpy().view(np.float32)
                     rr_ = hs[r, 272:278].cpu().numpy().view(np.float32)
-                    lab = ['ox', 'oy', 'oz', 'dx', 'dy', 'dz', 'o.o', 'o.d']
+                    lab = ['ox', 'oy', 'oz', 'dx', 'dy', 'dz', 'o.o', 'o.d'] if args.lanes_mode == 2 else ['act', 'radius', 'o.o', 'o.d', 'disc', 'sqrt', 't1', 't2']
                     for ln in np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(-1))[0][:4]:
                         bad_cols = np.nonzero(got[ln].view(np.uint32) != want[ln].view(np.uint32))[0]
                         print(f'   lane {ln} of the ray (ro {rr_[:3].tolist()}, rd {rr_[3:].tolist()}): ' + '; '.join(f'{lab[c]} got {got[ln, c]!r} ({got[ln, c].view(np.uint32):#010x}) alone {want[ln, c]!r} ({want[ln, c].view(np.uint32):#010x})' for c in bad_cols), flush=True)
                         print('      all eight, got  :', [float(x) for x in got[ln]]); print('      all eight, alone:', [float(x) for x in want[ln]], flush=True)
+                    if args.lanes_mode == 3:        # forensic: which float32 evaluation of o.o / o.d reproduces the value that was got?
+                        hc = fns[0].model._hc
+                        sc = np.array([float(hc.origin_initial[i]) for i in range(3)], np.float32)
+                        o = rr_[:3].astype(np.float32) * sc; d = rr_[3:].astype(np.float32) * sc
+                        f32 = np.float32
+                        def fma(a, b, c): return f32(np.float64(a) * np.float64(b) + np.float64(c))
+                        sq = [f32(x * x) for x in o]; od_ = [f32(a * b) for a, b in zip(o, d)]
+                        cands = {}
+                        import itertools
+                        for perm in itertools.permutations(range(3)):
+                            i, j, k_ = perm
+                            cands[f'oo ({i}+{j})+{k_}'] = f32(f32(sq[i] + sq[j]) + sq[k_])
+                            cands[f'oo fma({i},{i},sq{j})+{k_}'] = f32(fma(o[i], o[i], sq[j]) + sq[k_])
+                            cands[f'oo fma({k_},{k_},({i}+{j}))'] = fma(o[k_], o[k_], f32(sq[i] + sq[j]))
+                            cands[f'od ({i}+{j})+{k_}'] = f32(f32(od_[i] + od_[j]) + od_[k_])
+                            cands[f'od fma({k_},({i}+{j}))'] = fma(o[k_], d[k_], f32(od_[i] + od_[j]))
+                        print('      scale', sc.tolist(), 'o', o.tolist(), 'd', d.tolist())
+                        for ln in np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(-1))[0][:2]:
+                            for c, nm in ((2, 'oo'), (3, 'od')):
+                                print(f'      lane {ln} {nm}: got matches', [k for k, v in cands.items() if k.startswith(nm) and v.view(np.uint32) == got[ln, c].view(np.uint32)][:6], '| alone matches', [k for k, v in cands.items() if k.startswith(nm) and v.view(np.uint32) == want[ln, c].view(np.uint32)][:6], flush=True)
                     lane_cols.append(tuple(sorted(set(int(c) for ln in range(32) for c in np.nonzero(got[ln].view(np.uint32) != want[ln].view(np.uint32))[0]))))
                     continue
                 names = ['activated head value (sigmoid: exp, division)', 'radius (inverse contraction)', 'o.o', 'o.d', 'discriminant', 'sqrt', 't1 (division)', 't2 (division)']
