@@ -25,7 +25,13 @@ HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 
 # sample kernel of another), about once in 1e8 samples: pinned at the assembly level, not reproducible in isolation (DESIGN 4,
 # profiles/r05_frame_kernel_difference_bisect.txt).  Without the flag's packed forms: 0 differing renders in 600 + 960 + 480 (was 600, 2-13
 # per 80, 0-6 per 40), the same bits everywhere else, no cost (K2 0.697 vs 0.700 ms).  The gather's hand-written packed instructions stay.
+# -target-feature -packed-fp32-ops (device side; the host side of hipcc prints "not a recognized feature ... ignoring"): NO packed-fp32
+# instruction at all -- the gather's hand-written 2-float arithmetic becomes pairs of 32-bit instructions too.  Its register allocation had
+# produced the same class of instruction (in place, the overwritten pair read across halves: 348 in the sample kernel); none was ever seen to
+# fail, and removing them is free: a packed-fp32 instruction takes two issue passes like the two it replaces (DoNeRF frame 1.775 / 1.779 ms
+# with, 1.768 / 1.784 without, K2 0.689 vs 0.690 ms; profiles/r05_no_packed_fp32_ab.txt).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize',
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops',
          '-fno-math-errno', '-Wall', '-Wno-unused-function']
 # 1-ulp hardware exp (+ rcp inside sigmoid/tanh) for VALUES that are never compared against a threshold; divisions, square
 # roots and sin/cos keep their IEEE forms so that the reference's exact comparisons fall the same way (csrc/hr_math.h)
@@ -100,7 +106,13 @@ def build(force=False, verbose=False, extra_flags=()):
         cmd = [hipcc(), *flags, '-c', os.path.join(CSRC, s), '-o', _obj(s)]
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        # the device-side target feature is offered to the host compilation too, which says so once per translation unit
+        err = '\n'.join(ln for ln in r.stderr.split('\n') if "'-packed-fp32-ops' is not a recognized feature" not in ln).strip()
+        if err:
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
 
     # objects of translation units that are no longer part of the library do not travel with the tree
     keep = {os.path.basename(_obj(s)) for s in SOURCES}
