@@ -527,8 +527,10 @@ def main():
                  'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays (L2 / Infinity-Cache resident: not an HBM figure)',
                  'note': 'the sample stage is bound by vector-ALU issue, not by bytes: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, '
                          'the committed PMC pass) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue '
-                         'rate for plain fp32 instructions; the stage\'s mix of DPP, packed and transcendental instructions issues slower: '
-                         'profiles/r03_valu_ilp_ubench.txt)'}
+                         'rate for plain fp32 instructions; the stage\'s mix of DPP and transcendental instructions issues slower: '
+                         'profiles/r03_valu_ilp_ubench.txt).  The library contains no packed-fp32 instructions since the end of round 5 (DESIGN.md 4): '
+                         'the same arithmetic counted 1 169 instructions per sample slot with 184 of them packed, at the same time per launch '
+                         '(a packed-fp32 instruction takes two issue passes; profiles/r05_no_packed_fp32_ab.txt)'}
         # counters measured separately with rocprofv3 --pmc (never inside a timed run) and committed under profiles/;
         # attached only when the workload matches the profiled one
         tr, state, src = load_counters('', lambda w: (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid
