@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_build')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperreel_hip.so')
 SOURCES = ['api.hip', 'mlp_kernel.hip', 'mlp_bf16x3_kernel.hip', 'mlp_f16x3_kernel.hip', 'mlp_f16x2_kernel.hip', 'mlp_f16f8_kernel.hip', 'fused_bf16x3_kernel.hip', 'fused_f16x3_kernel.hip', 'fused_f16x2_kernel.hip', 'fused_f16f8_kernel.hip',
-           'sample_kernel.hip', 'range_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_det_kernel.hip', 'train_gemm_kernel.hip']
+           'sample_kernel.hip', 'range_kernel.hip', 'band_kernel.hip', 'pack_kernels.hip', 'train_kernel.hip', 'train_det_kernel.hip', 'train_gemm_kernel.hip']
 HEADERS = ['hr_kernels.h', 'hr_math.h', 'hr_grid.h', 'hr_train.h', 'hr_mask.h', 'mlp_split_impl.inc', 'mlp_split_core.inc', 'sample_core.inc', 'fused_impl.inc', 'train_kernel.hip', os.path.join('..', '..', 'include', 'hyperreel_hip.h')]
 
 # -ffp-contract=off: the per-sample arithmetic follows the reference operation by

@@ -84,9 +84,15 @@ struct hr_model {
     int* redo_list = nullptr;            // the second pass's rays
     int* wide_list = nullptr;            // the third pass's rays
     unsigned* redo_count = nullptr;      // [0] second-pass counter, [1] its copy, [2] third-pass counter, [3] its copy
-    int redo_cap = 0;
+    int redo_cap = 0;                    // entries the list holds (hr_model_reserve); a call uses max(65 536, n_rays / 8) of them
     int wide_cap = 0;
-    float redo_band = 0.0f;
+    float redo_band = 0.0f;              // the margins of THIS model (calibrate_band; hr_math.h HrRisk): of zc,
+    float redo_band_q = 0.0f;            //   of a point coordinate per unit of amplification,
+    float redo_band_off = 0.0f;          //   of the point-offset / flow heads
+    hr_verify_info vinfo = {};
+    float* calib_rays = nullptr;         // the rays the arithmetic was decided on (synthetic, or a strided sample of the caller's): kept for the band
+    int64_t calib_n = 0;
+    bool band_stale = false;             // hr_model_update_config changed the activations' constants: the band is measured again before the next render
     int64_t mlp_bytes = 0;
     // packed grids
     float* grid_a[3] = {};   // texel storage (floats, or halfs when cfg.grid_dtype == HR_GRID_FP16)
@@ -663,6 +669,18 @@ static void free_safe_pack(hr_model* m)
     }
 }
 
+static const float HR_BAND_FLOOR = 1e-6f;
+static const float HR_VERIFY_RGB_LIMIT = 6e-5f;   // on <= 65 536 calibration rays; the shipped families measure 1.5e-5 - 5e-5 here and 2.3e-5 - 5.4e-5 on their 640 000-ray frames
+static const float HR_VERIFY_AMP_CUT = 2.0f;      // a ray with a live sample beyond it (60 degrees off a plane's normal; a sphere nearly tangent) is not what the margins
+                                                  // are measured on -- its errors are the geometry's, the MLP's two-plane / Pluecker inputs included -- and is always listed
+
+static float scene_extent(const hr_config& c)
+{
+    float ext = 1.0f;
+    for (int i = 0; i < 6; ++i) if (std::isfinite(c.aabb[i])) ext = fmaxf(ext, fabsf(c.aabb[i]));
+    return fmaxf(ext, std::isfinite(c.near) ? fabsf(c.near) : 0.0f);
+}
+
 // the primary tiles in the active arithmetic, and -- verified fast path -- the f16x3 tiles of the second pass
 static int pack_mlp(hr_model* m)
 {
@@ -680,13 +698,11 @@ static int pack_mlp(hr_model* m)
         if (rc != HR_OK) return rc;
         if (!m->redo_count) HR_HIP(hipMalloc((void**)&m->redo_count, 4 * sizeof(unsigned)));
         HR_HIP(hipMemset(m->redo_count, 0, 4 * sizeof(unsigned)));
-        // a comparison is "at risk" within this length (HrRisk::band): 2.5e-6 of the scene's extent -- the largest |d distance| between
-        // f16f8 and f16x3 measured on the four 800x800 benchmark frames (160 M samples) is 7e-7 in scenes of extent 2 (tools/band_probe.py,
-        // profiles/r05_band_probe.json), and the z-plane families have live samples from 1e-5 of `near` on
-        float ext = 1.0f;
-        for (int i = 0; i < 6; ++i) if (std::isfinite(m->cfg.aabb[i])) ext = fmaxf(ext, fabsf(m->cfg.aabb[i]));
-        ext = fmaxf(ext, std::isfinite(m->cfg.near) ? fabsf(m->cfg.near) : 0.0f);
-        m->redo_band = 2.5e-6f * ext;
+        // the margins of the decisions at risk (HrRisk): here their floor -- four float32 ulps of the largest |zc|; the model's own are measured
+        // by calibrate_band once the workspace exists
+        m->redo_band = m->redo_band_q = HR_BAND_FLOOR;
+        m->redo_band_off = 0.0f;
+        m->band_stale = true;
     }
     m->mlp_bytes = b1 + m->mlp_bytes_safe[0] + m->mlp_bytes_safe[1];
     return HR_OK;
@@ -719,9 +735,20 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     float* synth = nullptr;
     float* d_max = nullptr;
     hipError_t e = hipSuccess;
+    const int rd = m->coarse ? c.casc_row_dim : c.ray_dim;
+    if (rays_dev) {
+        // the caller's rays: a strided sample of at most 65 536 of them stays with the model (the band of the verified fast path is measured
+        // on it, again after hr_model_update_config)
+        const int64_t stride = (n + 65535) / 65536, keep = (n + stride - 1) / stride;
+        free_dev(m->calib_rays);
+        m->calib_n = 0;
+        e = hipMalloc((void**)&m->calib_rays, sizeof(float) * keep * rd);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(m->calib_rays, sizeof(float) * rd, rays_dev, sizeof(float) * rd * stride, sizeof(float) * rd, keep,
+                                                  hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) m->calib_n = keep;
+    }
     if (!rays_dev) {
         n = 4096;
-        const int rd = m->coarse ? c.casc_row_dim : c.ray_dim;
         e = hipMalloc((void**)&synth, sizeof(float) * n * rd);
         if (e == hipSuccess) {
             // where rays start: the model's own box, or (cascade rows, whose first columns are points) the same box.  Real cameras may stand
@@ -758,7 +785,11 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (d_max) (void)hipFree(d_max);
-    if (synth) (void)hipFree(synth);
+    if (synth && e == hipSuccess) {            // kept (see above)
+        free_dev(m->calib_rays);
+        m->calib_rays = synth;
+        m->calib_n = n;
+    } else if (synth) (void)hipFree(synth);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HR_E_HIP, "activation-range calibration: %s", hipGetErrorString(e)); }
     m->calibrated = synth ? 1 : 2;
     float mx = 0.0f;
@@ -769,8 +800,14 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     }
     const bool fits = finite && mx < HR_F16_CALIBRATION_LIMIT;
     // the verified fast path: f16f8 + a list-driven second pass in f16x3.  What it needs: a ray's samples inside one wavefront
-    // (the list entry is written from a wave-level vote), no cascade (the point MLP's rows are internal), no occupancy-dependent structure
-    const bool can_verify = !m->coarse && !m->is_coarse && c.z_channels <= 64 && c.mlp_layers >= 2 && c.mlp_hidden == 256;
+    // (the list entry is written from a wave-level vote), no cascade (the point MLP's rows are internal).  (An occupancy volume adds a
+    // head-dependent decision the band does not cover: hr_render then takes the f16x3 tiles throughout, see hr_render_fields.)
+    // The per-sample margins (hr_math.h, HrRisk) are derived for: axis planes, sphere / cylinder with fixed origins, the euclidean distance;
+    // the identity, affine and MIP-NeRF contractions.
+    const bool isect_ok = c.isect_type == HR_ISECT_Z_PLANE || c.isect_type == HR_ISECT_VOXEL_GRID || c.isect_type == HR_ISECT_EUCLIDEAN_UNIFIED ||
+                          ((c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) && c.origin_scale == 0.0f);
+    const bool can_verify = !m->coarse && !m->is_coarse && c.z_channels <= 64 && c.mlp_layers >= 2 && c.mlp_hidden == 256 && isect_ok &&
+                            c.contract_type != HR_CONTRACT_DONERF;
     m->verified = 0;
     if (want == HR_MLP_AUTO) {
         m->active_precision = fits ? (can_verify ? HR_MLP_F16F8 : HR_MLP_F16X3) : HR_MLP_BF16X3;
@@ -778,7 +815,8 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
         return HR_OK;
     }
     if (want == HR_MLP_F16F8V && !can_verify)
-        return fail(HR_E_INVALID, "mlp_precision f16f8v (verified) needs a plain ray MLP of width 256 and at most 64 samples per ray");
+        return fail(HR_E_INVALID, "mlp_precision f16f8v (verified) needs a plain ray MLP of width 256, at most 64 samples per ray and an intersection "
+                    "the margins are derived for (axis planes, sphere / cylinder with fixed origins, euclidean; not DoNeRFContract)");
     if (!fits)
         return fail(HR_E_RANGE, "mlp_precision %s was requested, but the MLP's activations reach %.4g on the calibration rays (limit %.4g = "
                     "65504 / 8): IEEE-half operands would overflow.  Use HR_MLP_AUTO (falls back to bf16x3) or HR_MLP_BF16X3",
@@ -787,6 +825,8 @@ static int resolve_precision(hr_model* m, const float* rays_dev, int64_t n, hipS
     m->verified = (want == HR_MLP_F16F8V) ? 1 : 0;
     return HR_OK;
 }
+
+static int calibrate_band(hr_model* m, hipStream_t st);
 
 int hr_model_finalize(hr_model* m)
 {
@@ -928,9 +968,10 @@ int hr_model_finalize(hr_model* m)
         int64_t rays = (256ll << 20) / (nq * 16 * rows_per_ray(m->cfg));
         if (rays >= 16384) rays &= ~(int64_t)16383;
         rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
-        return hr_model_reserve(m, rays);
+        const int rc = hr_model_reserve(m, rays);
+        if (rc != HR_OK) return rc;
     }
-    return HR_OK;
+    return calibrate_band(m, nullptr);
 }
 
 // the configuration with every schedule-dependent constant blanked: what hr_model_update_config may not change
@@ -962,7 +1003,8 @@ int hr_model_calibrate(hr_model* m, const float* rays_dev, int64_t n_rays, float
     }
     if (act_max)
         for (int l = 0; l < m->cfg.mlp_layers; ++l) act_max[l] = m->act_max[l];
-    return HR_OK;
+    m->band_stale = true;
+    return calibrate_band(m, (hipStream_t)stream);
 }
 
 static hr_config structure_of(const hr_config& in)
@@ -991,6 +1033,7 @@ int hr_model_update_config(hr_model* m, const hr_config* cfg, void* stream)
     analyse_live_columns(m);                                  // same live columns (structure unchanged): rebuilds kcfg
     if (m->kcfg_dev) HR_HIP(hipMemcpy(m->kcfg_dev, &m->kcfg, sizeof(hr_config), hipMemcpyHostToDevice));
     if (m->ucfg_dev) HR_HIP(hipMemcpy(m->ucfg_dev, &m->cfg, sizeof(hr_config), hipMemcpyHostToDevice));
+    m->band_stale = true;                                     // the activations' constants feed the distances: measured again before the next render
     return HR_OK;
 }
 
@@ -1014,11 +1057,12 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
         HR_HIP(hipMalloc((void**)&m->rows, sizeof(float) * n_rows * m->cfg.casc_row_dim));
     }
     m->chunk = rays_per_chunk;
-    // verified fast path: the list of rays the second pass renders again.  Capacity: 10 % of a 640 000-ray frame (measured: 0.05 - 3 %), never
-    // more than a chunk (the second pass uses the chunk's head workspace); beyond it the kernels raise bit 2 of the status word (HR_OPT_REDO_OVERFLOW)
+    // verified fast path: the list of rays the second pass renders again.  The buffer holds 4 M entries (16 MB); a call uses
+    // max(65 536, n_rays / 8) of them (measured: 0.05 - 3 % of a frame's rays are listed; the calibration gives the fast path up above 10 %)
+    // and walks them in slices of the chunk's head workspace.  Beyond that the kernels raise bit 2 of the status word (HR_OPT_REDO_OVERFLOW)
     free_dev(reinterpret_cast<float*&>(m->redo_list));
     free_dev(reinterpret_cast<float*&>(m->wide_list));
-    m->redo_cap = (int)(rays_per_chunk < 65536 ? rays_per_chunk : 65536);
+    m->redo_cap = 1 << 22;
     m->wide_cap = (int)(rays_per_chunk < 8192 ? rays_per_chunk : 8192);       // third pass: 128 tiles (rays outside the calibrated range are the exception)
     HR_HIP(hipMalloc((void**)&m->redo_list, sizeof(int) * (size_t)m->redo_cap));
     HR_HIP(hipMalloc((void**)&m->wide_list, sizeof(int) * (size_t)m->wide_cap));
@@ -1059,6 +1103,7 @@ static void fill_mlp_args(const hr_model* m, HrMlpArgs& a, const float* rays, in
     a.ray0 = 0;
     a.ray_index = nullptr;
     a.n_rays_dev = nullptr;
+    a.list_off = 0;
     a.n_rays_copy = nullptr;
     a.redo_list = nullptr;
     a.redo_count = nullptr;
@@ -1114,11 +1159,12 @@ static void fill_sample_args(const hr_model* m, HrSampleArgs& a, const float* ra
     a.ray0 = 0;
     a.ray_index = nullptr;
     a.n_rays_dev = nullptr;
+    a.list_off = 0;
     a.zero_word = nullptr;
     a.redo_list = nullptr;
     a.redo_count = nullptr;
     a.redo_cap = 0;
-    a.redo_band = 0.0f;
+    a.redo_band = a.redo_band_q = a.redo_band_off = a.redo_amp_cut = 0.0f;
     a.flags = m->flags;
 #ifdef HR_DEBUG_HSUM
     a.dbg_hsum = g_dbg_hsum;
@@ -1204,6 +1250,253 @@ static int check_render(const hr_model* m, const float* rays, int64_t n, const f
     return HR_OK;
 }
 
+// The verified fast path over one call's rays: first pass in f16f8 with the rays at risk listed on the device, then the list
+// again with the f16x3 tiles (in slices of the chunk's head workspace), then whatever left the half range there with the bf16x3 tiles.
+// list_cap: entries of the list this call may use.
+static void render_verified(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, int list_cap, hipStream_t st)
+{
+    const hr_config& c = m->cfg;
+    for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
+        const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
+        const float* rays = rays_dev + r0 * c.ray_dim;
+        HrMlpArgs ma;
+        fill_mlp_args(m, ma, rays, n, 0);
+        ma.ray0 = r0;                                  // tiles that raise a range bit list their rays (indices start at r0)
+        ma.redo_list = m->redo_list;
+        ma.redo_count = m->redo_count;
+        ma.redo_cap = list_cap;
+        launch_mlp(m, m->kcfg, ma, st, 0);
+        HrSampleArgs sa;
+        fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
+        sa.ray0 = r0;
+        sa.redo_list = m->redo_list;
+        sa.redo_count = m->redo_count;
+        sa.redo_cap = list_cap;
+        sa.redo_band = m->redo_band;
+        sa.redo_band_q = m->redo_band_q;
+        sa.redo_band_off = m->redo_band_off;
+        sa.redo_amp_cut = HR_VERIFY_AMP_CUT;
+        hr_launch_samples(m->kcfg, sa, st);
+    }
+    // second pass: the listed rays (count on the device: the launches are sized for the capacity, blocks past the count leave at once) through
+    // the f16x3 tiles, gathered from / scattered to the caller's buffers by index.  The head workspace is free again; a list longer than it is
+    // walked in slices.  The counter is cleared for the next call by the FIRST slice's sample kernel, which like every later launch of the
+    // pass reads the copy the first slice's MLP kernel made (a memset node between calls does not survive hipGraph replay)
+    for (int64_t off = 0; off < list_cap; off += m->chunk) {
+        const int64_t cap = (list_cap - off < m->chunk) ? (list_cap - off) : m->chunk;
+        HrMlpArgs ma;
+        fill_mlp_args(m, ma, rays_dev, cap, 1);
+        ma.ray_index = m->redo_list + off;
+        ma.list_off = off;
+        ma.n_rays_dev = off == 0 ? m->redo_count : m->redo_count + 1;
+        ma.n_rays_copy = off == 0 ? m->redo_count + 1 : nullptr;
+        ma.redo_list = m->wide_list;                   // a tile of THIS pass in which an activation leaves the half range goes on to the third
+        ma.redo_count = m->redo_count + 2;
+        ma.redo_cap = m->wide_cap;
+        launch_mlp(m, m->kcfg, ma, st, 1);
+        HrSampleArgs sa;
+        fill_sample_args(m, sa, rays_dev, cap, rgb_dev);
+        sa.ray_index = m->redo_list + off;
+        sa.list_off = off;
+        sa.n_rays_dev = m->redo_count + 1;
+        sa.zero_word = off == 0 ? m->redo_count : nullptr;
+        hr_launch_samples(m->kcfg, sa, st);
+    }
+    // third pass: those tiles' rays with the bf16x3 tiles -- halves with the fp32 exponent range, nothing to overflow.  What a captured
+    // viewer loop gets where the host's guard (models.py: a sticky bit read between calls) cannot reach
+    HrMlpArgs ma;
+    fill_mlp_args(m, ma, rays_dev, m->wide_cap, 2);
+    ma.ray_index = m->wide_list;
+    ma.n_rays_dev = m->redo_count + 2;
+    ma.n_rays_copy = m->redo_count + 3;
+    launch_mlp(m, m->kcfg, ma, st, 2);
+    HrSampleArgs sa;
+    fill_sample_args(m, sa, rays_dev, m->wide_cap, rgb_dev);
+    sa.ray_index = m->wide_list;
+    sa.n_rays_dev = m->redo_count + 3;
+    sa.zero_word = m->redo_count + 2;
+    hr_launch_samples(m->kcfg, sa, st);
+}
+
+// entries of the ray list one hr_render call may fill: an eighth of its rays, at least 65 536 (never more than the rays there are, or the buffer)
+static int redo_list_cap(const hr_model* m, int64_t n_rays)
+{
+    int64_t cap = n_rays / 8 > 65536 ? n_rays / 8 : 65536;
+    cap = (cap + 63) & ~(int64_t)63;
+    if (cap > n_rays) cap = (n_rays + 63) & ~(int64_t)63;
+    return (int)(cap < m->redo_cap ? cap : m->redo_cap);
+}
+
+// The margins of the verified fast path for THIS model: both arithmetics' heads on the calibration rays, pushed through the
+// model's own activations, anchors, contraction and intersection by the probe kernel (band_kernel.hip) in the normalisation the sample
+// stage's per-sample margins use (hr_math.h, HrRisk); margin = 4 x the largest difference, never below HR_BAND_FLOOR.  Then the
+// well-conditioned calibration rays once through the verified path and once through the f16x3 tiles: the fraction listed, and how far the
+// two images are apart.  HR_MLP_AUTO gives the fast path up (f16x3 throughout) above 10 % / 6e-5.  Synchronises `st`.
+static int calibrate_band(hr_model* m, hipStream_t st)
+{
+    m->band_stale = false;
+    hr_verify_info& vi = m->vinfo;
+    const int fallback_before = vi.fallback;
+    vi = hr_verify_info();
+    vi.verified = m->verified;
+    vi.band_floor = HR_BAND_FLOOR;
+    vi.fallback = (fallback_before && !m->verified) ? fallback_before : 0;
+    if (!m->verified || m->coarse || m->is_coarse) return HR_OK;
+    if (!m->calib_rays || m->calib_n <= 0 || !m->head) return fail(HR_E_STATE, "verified fast path without calibration rays / workspace");
+    const hr_config& c = m->cfg;
+    const int Z = c.z_channels, P = c.preds_per_z;
+    const int64_t N = m->calib_n, nc_max = N < m->chunk ? N : m->chunk;
+    float *ha = nullptr, *hb = nullptr, *rgb = nullptr, *rgb2 = nullptr, *sel = nullptr;
+    unsigned* stats = nullptr;
+    unsigned char* ok_dev = nullptr;
+    hr_config* pcfg = nullptr;
+    auto cleanup = [&]() {
+        if (ha) (void)hipFree(ha);
+        if (hb) (void)hipFree(hb);
+        if (rgb) (void)hipFree(rgb);
+        if (rgb2) (void)hipFree(rgb2);
+        if (sel) (void)hipFree(sel);
+        if (stats) (void)hipFree(stats);
+        if (ok_dev) (void)hipFree(ok_dev);
+        if (pcfg) (void)hipFree(pcfg);
+    };
+#define HR_BAND_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(HR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); } } while (0)
+    HR_BAND_HIP(hipMalloc((void**)&ha, sizeof(float) * nc_max * Z * P));
+    HR_BAND_HIP(hipMalloc((void**)&hb, sizeof(float) * nc_max * Z * P));
+    HR_BAND_HIP(hipMalloc((void**)&stats, sizeof(unsigned) * HR_BAND_WORDS));
+    HR_BAND_HIP(hipMalloc((void**)&ok_dev, (size_t)N));
+    HR_BAND_HIP(hipMalloc((void**)&pcfg, sizeof(hr_config)));
+    HR_BAND_HIP(hipMemsetAsync(stats, 0, sizeof(unsigned) * HR_BAND_WORDS, st));
+    HR_BAND_HIP(hipMemsetAsync(ok_dev, 1, (size_t)N, st));
+    hr_config probe_cfg = c;                       // user column order; the probe applies the near / far mask itself
+    probe_cfg.isect_mask_off = 1;
+    HR_BAND_HIP(hipMemcpyAsync(pcfg, &probe_cfg, sizeof(hr_config), hipMemcpyHostToDevice, st));
+    HR_BAND_HIP(hipStreamSynchronize(st));          // (probe_cfg is a local)
+    for (int64_t r0 = 0; r0 < N; r0 += nc_max) {
+        const int64_t n = (N - r0 < nc_max) ? (N - r0) : nc_max;
+        const float* rays = m->calib_rays + r0 * c.ray_dim;
+        for (int tier = 0; tier < 2; ++tier) {
+            HrMlpArgs ma;
+            fill_mlp_args(m, ma, rays, n, tier);
+            launch_mlp(m, m->kcfg, ma, st, tier);
+            hr_launch_head_export(m->head, tier == 0 ? ha : hb, n, Z, P, m->p_live, (m->n_out + 3) / 4, rows_per_ray(c), m->col_map, st);
+        }
+        HrBandArgs ba;
+        ba.cfg_dev = pcfg;
+        ba.rays = rays;
+        ba.head_a = ha;
+        ba.head_b = hb;
+        ba.n_rays = n;
+        ba.mask_on = c.isect_mask_off ? 0 : 1;
+        ba.flip_cut = 1e-3f;
+        ba.stats = stats;
+        ba.ray_ok = ok_dev + r0;
+        ba.amp_cut = HR_VERIFY_AMP_CUT;
+        ba.phase = 0;                              // which rays are well conditioned ...
+        hr_launch_band_probe(ba, Z, st);
+        ba.phase = 1;                              // ... and the statistics over those
+        hr_launch_band_probe(ba, Z, st);
+    }
+    unsigned hs[HR_BAND_WORDS];
+    std::vector<unsigned char> ok((size_t)N);
+    std::vector<float> rays_h((size_t)N * c.ray_dim);
+    HR_BAND_HIP(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HR_BAND_HIP(hipMemcpyAsync(ok.data(), ok_dev, (size_t)N, hipMemcpyDeviceToHost, st));
+    HR_BAND_HIP(hipMemcpyAsync(rays_h.data(), m->calib_rays, sizeof(float) * rays_h.size(), hipMemcpyDeviceToHost, st));
+    HR_BAND_HIP(hipStreamSynchronize(st));
+    auto f = [&](int i) { float v; memcpy(&v, &hs[i], sizeof(v)); return v; };
+    vi.max_d_zc = f(HR_BAND_ZC);
+    vi.max_d_dist_n = f(HR_BAND_DIST_N);
+    vi.max_d_geo_n = f(HR_BAND_GEO_N);
+    vi.max_d_off = f(HR_BAND_OFF);
+    vi.max_d_dist = f(HR_BAND_DIST);
+    for (int i = 0; i < 64; ++i) vi.max_d_head = fmaxf(vi.max_d_head, f(HR_BAND_HEAD0 + i));
+    vi.n_rays = N;
+    vi.n_samples = hs[HR_BAND_COUNTED];
+    vi.n_flipped = hs[HR_BAND_FLIPPED];
+    vi.n_shaky = hs[HR_BAND_SHAKY];
+    m->redo_band = fmaxf(HR_BAND_FLOOR, 4.0f * fmaxf(vi.max_d_zc, vi.max_d_dist_n));
+    m->redo_band_q = fmaxf(HR_BAND_FLOOR, 4.0f * vi.max_d_geo_n);
+    m->redo_band_off = 4.0f * vi.max_d_off;
+    vi.band = m->redo_band;
+    vi.band_q = m->redo_band_q;
+    vi.band_off = m->redo_band_off;
+    // the well-conditioned rays, compacted on the host (<= 65 536 rays: not worth a kernel)
+    int64_t nu = 0;
+    for (int64_t i = 0; i < N; ++i)
+        if (ok[(size_t)i]) {
+            if (nu != i) memcpy(&rays_h[(size_t)nu * c.ray_dim], &rays_h[(size_t)i * c.ray_dim], sizeof(float) * c.ray_dim);
+            ++nu;
+        }
+    vi.n_rays_used = nu;
+    // (fewer than 64 well-conditioned rays -- a caller calibrating on a handful: the margins stand, there is no image to judge by)
+    bool too_many = false, too_far = false;
+    if (nu >= 64) {
+        // through the verified path as a render call takes it, and through the f16x3 tiles throughout: what fraction the first pass lists with
+        // these margins, and how far the two IMAGES are apart -- f16f8's continuous error (every pixel that is not listed keeps it) grows with
+        // the weights like the margins do, and no margin repairs it
+        HR_BAND_HIP(hipMalloc((void**)&sel, sizeof(float) * nu * c.ray_dim));
+        HR_BAND_HIP(hipMalloc((void**)&rgb, sizeof(float) * nu * 3));
+        HR_BAND_HIP(hipMalloc((void**)&rgb2, sizeof(float) * nu * 3));
+        HR_BAND_HIP(hipMemcpyAsync(sel, rays_h.data(), sizeof(float) * nu * c.ray_dim, hipMemcpyHostToDevice, st));
+        HR_BAND_HIP(hipMemsetAsync(m->redo_count, 0, 4 * sizeof(unsigned), st));
+        render_verified(m, sel, nu, rgb, redo_list_cap(m, nu), st);
+        unsigned listed = 0;
+        HR_BAND_HIP(hipMemcpyAsync(&listed, m->redo_count + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        for (int64_t r0 = 0; r0 < nu; r0 += m->chunk) {
+            const int64_t n = (nu - r0 < m->chunk) ? (nu - r0) : m->chunk;
+            const float* rays = sel + r0 * c.ray_dim;
+            launch_front(m, rays, n, st, -1, 1);
+            HrSampleArgs sa;
+            fill_sample_args(m, sa, rays, n, rgb2 + r0 * 3);
+            hr_launch_samples(m->kcfg, sa, st);
+        }
+        std::vector<float> ia((size_t)nu * 3), ib((size_t)nu * 3);
+        HR_BAND_HIP(hipMemcpyAsync(ia.data(), rgb, sizeof(float) * ia.size(), hipMemcpyDeviceToHost, st));
+        HR_BAND_HIP(hipMemcpyAsync(ib.data(), rgb2, sizeof(float) * ib.size(), hipMemcpyDeviceToHost, st));
+        HR_BAND_HIP(hipStreamSynchronize(st));
+        for (size_t i = 0; i < ia.size(); ++i) {
+            const float d = fabsf(ia[i] - ib[i]);
+            vi.max_d_rgb = (d > vi.max_d_rgb || d != d) ? d : vi.max_d_rgb;
+        }
+        vi.listed_frac = (float)((double)listed / (double)nu);
+        too_far = !(vi.max_d_rgb <= HR_VERIFY_RGB_LIMIT);
+    }
+    // the CALLER's rays are what will be rendered: the ill-conditioned ones among them are listed too (synthetic rays point anywhere;
+    // half of them graze a z-plane net's planes, which says nothing about its cameras)
+    if (m->calibrated == 2) vi.listed_frac = (float)(((double)(N - nu) + (double)vi.listed_frac * (double)nu) / (double)N);
+    too_many = vi.listed_frac > 0.10f;
+    HR_BAND_HIP(hipMemsetAsync(m->redo_count, 0, 4 * sizeof(unsigned), st));
+    HR_BAND_HIP(hipMemsetAsync(m->flags, 0, sizeof(unsigned), st));        // range bits the calibration rays raised are not the caller's
+    HR_BAND_HIP(hipStreamSynchronize(st));
+#undef HR_BAND_HIP
+    cleanup();
+    if ((too_many || too_far) && m->cfg.mlp_precision == HR_MLP_AUTO) {
+        // more than a tenth of the rays would be rendered twice (a call's list holds an eighth), or the cheap arithmetic's own error is
+        // too large a share of the 1e-4 budget on this model: plain f16x3 lists nothing and has neither problem
+        m->verified = 0;
+        m->active_precision = HR_MLP_F16X3;
+        m->packed_bytes -= m->mlp_bytes;
+        const int rc = pack_mlp(m);
+        if (rc != HR_OK) return rc;
+        m->packed_bytes += m->mlp_bytes;
+        HR_HIP(hipDeviceSynchronize());
+        m->band_stale = false;
+        vi.verified = 0;
+        vi.fallback = too_far ? 2 : 1;
+    }
+    return HR_OK;
+}
+
+int hr_model_verify_info(hr_model* m, hr_verify_info* out)
+{
+    if (!m || !out) return fail(HR_E_INVALID, "null argument");
+    if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");
+    *out = m->vinfo;
+    out->verified = m->verified;
+    return HR_OK;
+}
+
 int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, const hr_fields* fields, void* stream)
 {
     int rc = check_render(m, rays_dev, n_rays, rgb_dev);
@@ -1219,23 +1512,33 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
     //  measured twice -- plain, and with the MLP limited to one workgroup per CU so that sample
     //  blocks could co-reside -- and is slower than back-to-back launches: 3.0-3.9 vs 2.79 ms per
     //  800x800 frame; the two kernels do not interleave on the CUs.)
-    // verified fast path: first pass in f16f8 with the rays at risk listed on the device, second pass over the list in f16x3.
-    // With diagnostics requested every output comes from ONE arithmetic: the f16x3 tiles throughout.
-    const bool verify = m->verified && !fields && n_rays < ((int64_t)1 << 31);
-    const bool safe_all = m->verified && !verify;
+    // verified fast path.  With diagnostics requested every output comes from ONE arithmetic: the f16x3 tiles throughout.
+    // So does a model with an occupancy volume (hr_occupancy_test decides per cell from a head-dependent point; the band does not cover it),
+    // and a render inside a stream capture whose band is out of date (hr_model_update_config since the last measurement: measuring synchronises).
+    bool verify = m->verified && !fields && !m->occ && n_rays < ((int64_t)1 << 31);
+    if (verify && m->band_stale) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            rc = calibrate_band(m, st);
+            if (rc != HR_OK) return rc;
+            verify = verify && m->verified;            // HR_MLP_AUTO may just have given the fast path up
+        } else {
+            verify = false;
+        }
+    }
+    if (verify && n_rays > 0) {
+        render_verified(m, rays_dev, n_rays, rgb_dev, redo_list_cap(m, n_rays), st);
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
+    const bool safe_all = m->verified != 0;
     for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
         const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
         const float* rays = rays_dev + r0 * c.ray_dim;
-        launch_front(m, rays, n, st, verify ? r0 : -1, safe_all ? 1 : 0);
+        launch_front(m, rays, n, st, -1, safe_all ? 1 : 0);
         HrSampleArgs sa;
         fill_sample_args(m, sa, rays, n, rgb_dev + r0 * 3);
-        if (verify) {
-            sa.ray0 = r0;
-            sa.redo_list = m->redo_list;
-            sa.redo_count = m->redo_count;
-            sa.redo_cap = m->redo_cap;
-            sa.redo_band = m->redo_band;
-        }
         if (fields) {
             if (fields->distances_dev) sa.fields.distances_dev = fields->distances_dev + r0 * Z;
             if (fields->points_dev) sa.fields.points_dev = fields->points_dev + r0 * Z * 3;
@@ -1245,38 +1548,6 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
                 hr_launch_head_export(m->head, fields->head_dev + r0 * (int64_t)Z * c.preds_per_z, n, Z, c.preds_per_z, m->p_live,
                                       (m->n_out + 3) / 4, rows_per_ray(c), m->col_map, st);
         }
-        hr_launch_samples(m->kcfg, sa, st);
-    }
-    if (verify && n_rays > 0) {
-        // second pass: the listed rays (count on the device: the launches are sized for the list's capacity, blocks past the count leave at
-        // once) through the f16x3 tiles, gathered from / scattered to the caller's buffers by index.  The head workspace is free again.
-        HrMlpArgs ma;
-        fill_mlp_args(m, ma, rays_dev, m->redo_cap, 1);
-        // (the counter is cleared for the next call by the last launch of this pass, which reads the copy the launch before it made)
-        ma.ray_index = m->redo_list;
-        ma.n_rays_dev = m->redo_count;
-        ma.n_rays_copy = m->redo_count + 1;
-        ma.redo_list = m->wide_list;               // a tile of THIS pass in which an activation leaves the half range goes on to the third
-        ma.redo_count = m->redo_count + 2;
-        ma.redo_cap = m->wide_cap;
-        launch_mlp(m, m->kcfg, ma, st, 1);
-        HrSampleArgs sa;
-        fill_sample_args(m, sa, rays_dev, m->redo_cap, rgb_dev);
-        sa.ray_index = m->redo_list;
-        sa.n_rays_dev = m->redo_count + 1;
-        sa.zero_word = m->redo_count;
-        hr_launch_samples(m->kcfg, sa, st);
-        // third pass: those tiles' rays with the bf16x3 tiles -- halves with the fp32 exponent range, nothing to overflow.  What a captured
-        // viewer loop gets where the host's guard (models.py: a sticky bit read between calls) cannot reach
-        fill_mlp_args(m, ma, rays_dev, m->wide_cap, 2);
-        ma.ray_index = m->wide_list;
-        ma.n_rays_dev = m->redo_count + 2;
-        ma.n_rays_copy = m->redo_count + 3;
-        launch_mlp(m, m->kcfg, ma, st, 2);
-        fill_sample_args(m, sa, rays_dev, m->wide_cap, rgb_dev);
-        sa.ray_index = m->wide_list;
-        sa.n_rays_dev = m->redo_count + 3;
-        sa.zero_word = m->redo_count + 2;
         hr_launch_samples(m->kcfg, sa, st);
     }
     HR_HIP(hipGetLastError());

@@ -88,6 +88,7 @@ struct HrMlpArgs {
     int64_t ray0;
     const int* ray_index;
     const unsigned* n_rays_dev;
+    int64_t list_off;            // second pass in slices of the workspace's capacity: ray_index starts at entry list_off of the list, *n_rays_dev - list_off remain
     unsigned* n_rays_copy;       // second pass: workgroup 0 copies *n_rays_dev here (what the second pass's sample kernel reads, so that IT can clear the
                                  //   counter for the next call -- a memset node between the calls does not survive hipGraph replay: the second
                                  //   replay found 0x40404040 there)
@@ -137,11 +138,15 @@ struct HrSampleArgs {
     int64_t ray0;
     const int* ray_index;
     const unsigned* n_rays_dev;
+    int64_t list_off;       // second pass in slices: ray_index starts at entry list_off of the list, *n_rays_dev - list_off remain
     unsigned* zero_word;    // second pass: cleared by workgroup 0 (the list's counter, for the next call; this launch reads its copy)
     int* redo_list;
     unsigned* redo_count;
     int redo_cap;
-    float redo_band;
+    float redo_band;        // HrRisk::band_zc: the model's calibrated margin of  z * scale + anchor  (hr_math.h)
+    float redo_band_q;      // HrRisk::band_q: margin of a point coordinate per unit of amplification
+    float redo_band_off;    // HrRisk::band_off: margin of the point-offset / flow heads
+    float redo_amp_cut;     // HrRisk::amp_cut: a live sample conditioned worse than the calibration's rays lists its ray
     unsigned* flags;        // the model's sticky status word (bit 2: the redo list overflowed)
 #ifdef HR_DEBUG_HSUM        // measurement builds (tools/hsum_bisect.py): per ray, the XOR of the bits of every head value the sample stage read, and of its sorted distances
     unsigned* dbg_hsum;     // [n_rays][2]
@@ -202,6 +207,31 @@ struct HrRangeArgs {
 void hr_launch_mlp_range(const hr_config& cfg, const HrRangeArgs& a, hipStream_t stream);
 bool hr_mlp_range_supported(const hr_config& cfg);
 void hr_launch_synthetic_rays(float* rays, int64_t n, int ray_dim, const float lo[3], const float hi[3], unsigned seed, hipStream_t stream);
+
+// band probe of the verified fast path (band_kernel.hip): f16f8 vs f16x3 heads of the same rays in the user's (n, Z, P) layout ->
+// the largest differences of what the sample stage compares.  stats: HR_BAND_WORDS unsigned words, zeroed by the caller
+// (non-negative floats as their bit patterns, atomically maximised; counters)
+enum { HR_BAND_ZC = 0,        // max |zc(a) - zc(b)|: the length before the inverse contraction
+       HR_BAND_DIST_N = 1,    // max |distance(a) - distance(b)| / (dlen amp): the same thing seen through the intersection (the margins' model, checked)
+       HR_BAND_GEO_N = 2,     // max |point(dist a, head b) - point(dist b, head b)| / amp: the points' share of a distance error, per unit of amplification
+       HR_BAND_OFF = 3,       // max |point(dist a, head a) - point(dist a, head b)|: offset + flow heads
+       HR_BAND_COUNTED = 4, HR_BAND_FLIPPED = 5, HR_BAND_SHAKY = 6,
+       HR_BAND_DIST = 7,      // max |distance(a) - distance(b)| as it is (reported)
+       HR_BAND_HEAD0 = 8, HR_BAND_WORDS = 72 };
+struct HrBandArgs {
+    const hr_config* cfg_dev;    // the caller's configuration (user column order) with isect_mask_off = 1
+    const float* rays;
+    const float* head_a;         // (n, Z, P) raw head, cheap arithmetic
+    const float* head_b;         // the same rays, reference-grade arithmetic
+    int64_t n_rays;
+    int mask_on;                 // the model masks distances outside (near, far): only samples alive under both heads count
+    float flip_cut;              // a normalised distance difference beyond this is a decision that fell the other way, not arithmetic error
+    unsigned* stats;
+    unsigned char* ray_ok;       // one byte per ray: 1 = every live sample of the ray has amp <= amp_cut (a well-conditioned ray: every statistic
+    float amp_cut;               //   is taken over these).  phase 0: cleared by the samples that say otherwise; phase 1: read
+    int phase;                   // 0: only ray_ok; 1: the statistics, over the rays phase 0 left marked
+};
+void hr_launch_band_probe(const HrBandArgs& a, int z_channels, hipStream_t stream);
 
 void hr_launch_generate_rays(const hr_camera& cam, int ray_dim, int64_t first_pixel, int64_t n_pixels, float* rays, hipStream_t stream);
 

@@ -70,6 +70,13 @@ HR_FN float hr_tanh(float x) { return tanhf(x); }
 #define HR_SINCOS(x, s, c) sincosf((x), (s), (c))
 #endif
 
+// reciprocal for MARGINS only (1 ulp is nothing against their factor 4)
+#if defined(__HIPCC__)
+#define HR_RCP_BAND(x) __builtin_amdgcn_rcpf(x)
+#else
+#define HR_RCP_BAND(x) (1.0f / (x))
+#endif
+
 // ---------------------------------------------------------------- activations
 // y = act(x*inner + shift)*outer   (nlf/activations.py:53-69,121-137,163-178)
 HR_FN float hr_apply_act(const hr_act& a, float x)
@@ -109,6 +116,12 @@ HR_FN float hr_axis_plane_t(float val, float o, float d)
 {
     float dd = (fabsf(d) < 1e-5f) ? 1e12f : d;
     return HR_DIV(val - o, dd);
+}
+
+// |d hr_axis_plane_t / d val| -- margins only (HrRisk)
+HR_FN float hr_axis_plane_amp(float d)
+{
+    return (fabsf(d) < 1e-5f) ? 1e-12f : HR_RCP_BAND(fabsf(d));
 }
 
 // nlf/param.py:244-253 (pluecker), :87-115 (two_plane), :20-24 (identity) followed by
@@ -254,23 +267,38 @@ HR_FN void hr_contract_point(const hr_config& c, float px, float py, float pz, f
     }
 }
 
-// ---------------------------------------------------------------- decisions at risk (the verified fast path, DESIGN 3i)
-// The per-sample stage is continuous in the MLP's head EXCEPT at a handful of comparisons (near / far mask, the quadratic's discriminant and root
-// choice, the new primitives' recycling test, the bounding box, a positive weight threshold).  A cheaper MLP arithmetic moves the head by
-// ~1e-5 of its range and every continuous quantity by < 1e-6 of the scene's size -- invisible at the 1e-4 bar -- but a comparison whose two
-// sides are closer than that error may fall the other way and change a pixel by 1e-2.  With a non-NULL HrRisk the functions below also report
-// whether any comparison they made was within `band` (a length: ~4e-6 of the scene's extent, six times the largest distance error
-// measured on 160 M samples, tools/band_probe.py) or `rel` (relative, for products) of flipping; the sample kernel collects the
-// rays that have such a sample and hr_render renders them again with the reference-grade arithmetic.  NULL (the default): nothing is computed.
+// ---------------------------------------------------------------- decisions at risk (the verified fast path, DESIGN 3c)
+// The per-sample stage is continuous in the MLP's head EXCEPT at a handful of comparisons (near / far mask, the quadratic's discriminant and
+// root choice, the bounding box, a positive weight threshold).  A cheaper MLP arithmetic moves the head a little and every continuous
+// quantity with it -- invisible at the 1e-4 bar -- but a comparison whose two sides are closer than that error may fall the other way and
+// change a pixel by 1e-2.  With a non-NULL HrRisk the functions below also report whether any comparison they made was inside its margin;
+// the sample kernel collects the rays that have such a sample and hr_render renders them again with the reference-grade arithmetic.
+//
+// The margins are derived per SAMPLE from one number the model is calibrated for (api.hip: calibrate_band; band_kernel.hip):
+//   band_zc  how far the two arithmetics' values of  z * scale + anchor  (process_z_vals before the inverse contraction: a smooth, bounded-
+//            slope function of one head column) may differ -- 4 x the largest difference measured on the calibration rays;
+// pushed through the derivatives of what follows it:
+//   dlen = |d length / d zc|      of the inverse contraction (1 for none; c_aff_fac; c_d0 r^2 / c_d_scale beyond the unit ball),
+//   amp  = |d distance / d length| of the intersection (1 / |d_axis| for a plane; 2 |r| / sqrt(discriminant) for sphere and cylinder),
+// so that a length is at risk within band_zc dlen and a distance within band_zc dlen amp.  Points are compared (bounding box) after the
+// point contraction, which undoes dlen: their margin is band_q x the largest amp among the ray's samples (+ band_off for the offset and
+// flow heads), both measured the same way.  The measurement is taken over rays whose live samples all have amp <= amp_cut (a ray grazing a
+// plane or tangent to a sphere conditions everything badly, the MLP's input features included, under any arithmetic); a ray with a live
+// sample beyond amp_cut is therefore at risk by that alone.  NULL (the default): nothing is computed.
 struct HrRisk {
-    float band;     // lengths: distances, radii, coordinates
-    float rel;      // relative margin for compound quantities (the discriminant)
+    float band_zc;
+    float band_q;
+    float band_off;
+    float amp_cut;  // a live sample with amp beyond this is at risk by itself: the margins were measured on rays without such samples (0: no such rule)
     bool hit;
+    // out: this sample's zc, dlen and amp (0 where the intersection misses) -- what the margins were built from, and what the band probe reads
+    float zc, dlen, amp;
 #ifdef HR_DEBUG_HSUM
     float dbg[8];   // measurement builds: intermediates of the sphere intersection (tools/hsum_bisect.py)
 #endif
 };
-#define HR_RISK_ABS(risk, x, y) do { if (risk) (risk)->hit = (risk)->hit || (fabsf((x) - (y)) <= (risk)->band); } while (0)
+#define HR_RISK_INIT(zc_, q_, off_, cut_) HrRisk{(zc_), (q_), (off_), (cut_), false, 0.0f, 1.0f, 0.0f}
+#define HR_RISK_ABS(risk, x, y) do { if (risk) (risk)->hit = (risk)->hit || (fabsf((x) - (y)) <= (risk)->band_zc * (risk)->dlen); } while (0)
 
 // ---------------------------------------------------------------- ray / primitive intersection
 // utils/intersect_utils.py:45-84 (sphere) and :86-125 (cylinder: the xz components)
@@ -280,8 +308,12 @@ HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius, HrRisk* r
     float b = 2.0f * od;
     float cc = oo - radius * radius;
     float disc = b * b - 4.0f * a * cc;
-    // at risk: the discriminant's sign (relative to the two terms it is the difference of) and the radius' sign
-    if (risk) risk->hit = risk->hit || (fabsf(disc) <= risk->rel * (b * b + fabsf(4.0f * a * cc))) || (fabsf(radius) <= risk->band);
+    // at risk: the discriminant's sign -- only the radius depends on the head, d disc = 8 a r d r -- and the radius' sign
+    float band_r = 0.0f;
+    if (risk) {
+        band_r = risk->band_zc * risk->dlen;
+        risk->hit = risk->hit || (fabsf(disc) <= 8.0f * a * fabsf(radius) * band_r) || (fabsf(radius) <= band_r);
+    }
 #if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
     if (risk) risk->dbg[4] = disc;
 #endif
@@ -292,7 +324,11 @@ HR_FN float hr_quadratic_t(float oo, float dd, float od, float radius, HrRisk* r
 #if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
     if (risk) { risk->dbg[5] = sq; risk->dbg[6] = t1; risk->dbg[7] = t2; }
 #endif
-    if (risk) risk->hit = risk->hit || (fabsf(t2) <= risk->band);        // ... and the sign of the near root (which root is returned)
+    if (risk) {
+        // d t / d r = +- 2 r / sq for both roots (a cancels); ... and the sign of the near root (which root is returned)
+        risk->amp = (disc <= 0.0f) ? 0.0f : 2.0f * fabsf(radius) * HR_RCP_BAND(sq);
+        risk->hit = risk->hit || (disc > 0.0f && fabsf(t2) <= band_r * risk->amp);
+    }
     t1 = (disc <= 0.0f) ? 0.0f : t1;
     t2 = (disc <= 0.0f) ? 0.0f : t2;
     return ((t2 < 0.0f) || (radius < 0.0f)) ? t1 : t2;
@@ -338,11 +374,26 @@ HR_FN float hr_zval(const hr_config& c, const float* hk, int ch, float one_m)
     return hr_apply_act(c.z_act, hr_apply_act(c.f_z_vals.act, hk[c.f_z_vals.offset + ch])) * one_m;
 }
 
+// |d hr_inverse_contract_distance / d distance| at `zc` (r: the value it returned) -- margins only
+HR_FN float hr_inverse_contract_slope(const hr_config& c, float zc, float r)
+{
+    if (c.contract_type == HR_CONTRACT_AFFINE) return fabsf(c.c_aff_fac);
+    if (c.contract_type == HR_CONTRACT_DONERF) return 1.0f;       // (not derived: such models are not verified, api.hip can_verify)
+    if (fabsf(zc) < 1.0f) return fabsf(c.c_d0);
+    const float ru = r * HR_RCP_BAND(c.c_d0);                      // 1 / inv
+    return fabsf(c.c_d0 * ru * ru * HR_RCP_BAND(c.c_d_scale));
+}
+
 // process_z_vals (base.py:128-140): anchor + scale, then back from the contracted sample space
-HR_FN float hr_process_z(const hr_config& c, float z, float scale, float anchor)
+HR_FN float hr_process_z(const hr_config& c, float z, float scale, float anchor, HrRisk* risk = nullptr)
 {
     z = z * scale + anchor;
+    const float zc = z;
     if (c.contract_samples) z = hr_inverse_contract_distance(c, z);
+    if (risk) {
+        risk->zc = zc;
+        risk->dlen = c.contract_samples ? hr_inverse_contract_slope(c, zc, z) : 1.0f;
+    }
     return z;
 }
 
@@ -360,7 +411,7 @@ HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m
         HR_UNROLL
         for (int i = 0; i < 3; ++i) rs[i] = hr_zval(c, hk, 3 + i, one_m) * c.resize_scale + c.resize_initial[i];
     const float raw = hr_process_z(c, hr_zval(c, hk, 6, one_m), c.z_scale, c.samples[k]);
-    const float radius = hr_process_z(c, hr_zval(c, hk, 7, one_m), c.z_scale, c.samples[k]);
+    const float radius = hr_process_z(c, hr_zval(c, hk, 7, one_m), c.z_scale, c.samples[k], risk);
     float o[3], d[3];
     HR_UNROLL
     for (int i = 0; i < 3; ++i) { o[i] = (ro[i] - org[i]) * rs[i]; d[i] = rd[i] * rs[i]; }
@@ -400,9 +451,11 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
     if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
     float one_m = 1.0f - sigma;
     float dist;
+    if (risk) risk->amp = 1.0f;
     if (c.isect_type == HR_ISECT_Z_PLANE) {
-        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);   // base.py:129
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k], risk);   // base.py:129
         dist = hr_axis_plane_t(z, ro[2], rd[2]);                     // z.py:88-95
+        if (risk) risk->amp = hr_axis_plane_amp(rd[2]);
     } else if (c.isect_type == HR_ISECT_SPHERE || c.isect_type == HR_ISECT_CYLINDER) {
         // origins = z[:3] * origin_scale_factor + origin_initial (primitive.py:410-412).  With the
         // shipped origin_scale_factor of 0 the three channels are multiplied by zero; they are then
@@ -413,7 +466,7 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
             sy = hr_zval(c, hk, 1, one_m) * c.origin_scale + c.origin_initial[1];
             sz = hr_zval(c, hk, 2, one_m) * c.origin_scale + c.origin_initial[2];
         }
-        float radius = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
+        float radius = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k], risk);
 #if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
         if (risk) { risk->dbg[0] = hr_zval(c, hk, 3, one_m); risk->dbg[1] = radius; }
 #endif
@@ -443,11 +496,12 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
     } else if (c.isect_type == HR_ISECT_VOXEL_GRID) {
         // voxel.py:72-112: samples are (Z/3, 3) axis planes; sample k is a plane orthogonal to axis k % 3
         const int axis = k % 3;
-        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.voxel_scale[axis], c.samples[k]);
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.voxel_scale[axis], c.samples[k], risk);
         const float o = (axis == 0) ? ro[0] : (axis == 1) ? ro[1] : ro[2];
         const float d = (axis == 0) ? rd[0] : (axis == 1) ? rd[1] : rd[2];
         if (c.isect_outward) z = z * hr_sign(d);
         dist = hr_axis_plane_t(z, o, d);                             // intersect_utils.py:152-179
+        if (risk) risk->amp = hr_axis_plane_amp(d);
     } else if (c.isect_type == HR_ISECT_DEFORMABLE_VOXEL_GRID) {
         // voxel.py:184-213: a plane per sample, normal = normalize(z[:3]*scale + start_normal[k % axes]),
         // offset = processed z[3]; intersect_plane (intersect_utils.py:210-236)
@@ -459,24 +513,29 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
             HR_UNROLL
             for (int i = 0; i < 3; ++i) n[i] = hr_zval(c, hk, i, one_m) * c.dvg_normal_scale + c.dvg_normals[3 * axis + i];
         hr_normalize3(n);
-        const float dplane = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k]);
+        const float dplane = hr_process_z(c, hr_zval(c, hk, 3, one_m), c.z_scale, c.samples[k], risk);
         const float o_n = (ro[0] * n[0] + ro[1] * n[1]) + ro[2] * n[2];
         float d_n = (rd[0] * n[0] + rd[1] * n[1]) + rd[2] * n[2];
         HR_RISK_ABS(risk, fabsf(d_n), 1e-5f);
         d_n = (fabsf(d_n) < 1e-5f) ? 1e12f : d_n;
         dist = HR_DIV(dplane - o_n, d_n);
+        if (risk) risk->amp = HR_RCP_BAND(fabsf(d_n));
     } else {                                                         // euclidean_distance_unified, primitive.py:162-176
-        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k]);
+        float z = hr_process_z(c, hr_zval(c, hk, 0, one_m), c.z_scale, c.samples[k], risk);
         float pos[3];
         hr_pluecker_pos(ro, rd, pos);
         const float diff[3] = {pos[0] - ro[0], pos[1] - ro[1], pos[2] - ro[2]};
         dist = z + hr_signed_base_distance(rd, diff);
     }
     if (!c.isect_mask_off) {
-        if (risk) risk->hit = risk->hit || (fabsf(dist - c.near) <= risk->band) || (fabsf(dist - c.far) <= risk->band);
+        if (risk) {
+            const float band_d = risk->band_zc * risk->dlen * risk->amp;
+            risk->hit = risk->hit || (fabsf(dist - c.near) <= band_d) || (fabsf(dist - c.far) <= band_d);
+        }
         bool mask = (dist <= c.near) || (dist >= c.far);             // base.py:194
         dist = mask ? 0.0f : dist;
     }
+    if (risk) risk->hit = risk->hit || (dist != 0.0f && risk->amp_cut > 0.0f && risk->amp > risk->amp_cut);
     return dist;
 }
 
@@ -533,13 +592,13 @@ HR_FN void hr_sample_point(const hr_config& c, const float* hk, float dist_sorte
 }
 
 // valid_mask (tensorf_base.py:349-353) & (distances > 0) (tensorf_no_sample.py:156)
-HR_FN bool hr_sample_valid(const hr_config& c, const float* p, float dist, HrRisk* risk = nullptr)
+HR_FN bool hr_sample_valid(const hr_config& c, const float* p, float dist, HrRisk* risk = nullptr, float band_p = 0.0f)
 {
-    if (risk && dist > 0.0f) {                  // a live sample within `band` of a face of the box
+    if (risk && dist > 0.0f) {                  // a live sample within the points' margin of a face of the box (band_p: the caller's, from the ray's largest amp)
         float m = fminf(fabsf(p[0] - c.aabb[0]), fabsf(p[0] - c.aabb[3]));
         m = fminf(m, fminf(fabsf(p[1] - c.aabb[1]), fabsf(p[1] - c.aabb[4])));
         m = fminf(m, fminf(fabsf(p[2] - c.aabb[2]), fabsf(p[2] - c.aabb[5])));
-        risk->hit = risk->hit || (m <= risk->band);
+        risk->hit = risk->hit || (m <= band_p);
     }
     bool out = (c.aabb[0] > p[0]) || (p[0] > c.aabb[3]) || (c.aabb[1] > p[1]) || (p[1] > c.aabb[4]) ||
                (c.aabb[2] > p[2]) || (p[2] > c.aabb[5]);

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     int64_t n_rays = a.n_rays;
     if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     if (a.n_rays_dev) {
-        const int64_t nd = (int64_t)*a.n_rays_dev;
+        const int64_t nd_raw = (int64_t)*a.n_rays_dev;
+        const int64_t nd = nd_raw > a.list_off ? nd_raw - a.list_off : 0;
         n_rays = nd < n_rays ? nd : n_rays;
     }
     if (ray_base >= n_rays) return;                // (block-uniform, before any barrier)

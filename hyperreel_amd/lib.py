@@ -11,7 +11,7 @@ from .plan import hr_camera, hr_config, hr_fields
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libhyperreel_hip.so')
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 
@@ -28,6 +28,14 @@ class hr_train_tensors(C.Structure):
                 ('basis', C.c_void_p), ('color_table', C.c_void_p)]
 
 
+class hr_verify_info(C.Structure):
+    """What the verified fast path rests on for one model (include/hyperreel_hip.h)."""
+    _fields_ = [('verified', C.c_int32), ('fallback', C.c_int32), ('band', C.c_float), ('band_q', C.c_float), ('band_off', C.c_float),
+                ('band_floor', C.c_float), ('max_d_zc', C.c_float), ('max_d_dist_n', C.c_float), ('max_d_geo_n', C.c_float), ('max_d_off', C.c_float),
+                ('max_d_dist', C.c_float), ('max_d_head', C.c_float), ('listed_frac', C.c_float), ('max_d_rgb', C.c_float),
+                ('n_rays', C.c_int64), ('n_rays_used', C.c_int64), ('n_samples', C.c_int64), ('n_flipped', C.c_int64), ('n_shaky', C.c_int64)]
+
+
 # every symbol include/hyperreel_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ('hr_abi_version', C.c_int, []),
@@ -42,6 +50,7 @@ SYMBOLS = [
     ('hr_model_reserve', C.c_int, [C.c_void_p, C.c_int64]),
     ('hr_model_set_option', C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ('hr_model_get_option', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ('hr_model_verify_info', C.c_int, [C.c_void_p, C.POINTER(hr_verify_info)]),
     ('hr_model_set_occupancy', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_void_p]),
     ('hr_render', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ('hr_render_frame', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),

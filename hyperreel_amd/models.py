@@ -613,13 +613,19 @@ class HipLightfieldModel(nn.Module):
     def set_execution(self, frame_kernel=None, sample_waves=None):
         """Chooses how render() is laid out on the device (images are bit-identical under every setting):
         frame_kernel False = the two-kernel path through the HBM workspace (default), True = the persistent frame kernel for the static
-        nets (64-ray tiles), 2 = wherever the model fits it; sample_waves 4 | 8."""
+        nets (64-ray tiles), 2 = wherever the model fits it; sample_waves 4 | 8.
+        The frame kernel is a one-pass plan: a model on the verified fast path (mlp_precision 'auto' / 'f16f8v', two passes over the HBM
+        workspace) keeps the two-kernel path whatever is asked for here -- choose mlp_precision 'f16x3' (or plain 'f16f8') with it."""
         if frame_kernel is not None:
             self.frame_kernel = self._frame_mode(frame_kernel)
         if sample_waves is not None:
             self.sample_waves = int(sample_waves)
         if self._native is not None:
             self._apply_options()
+            if self.frame_kernel and self.mlp_verified():
+                import warnings
+                warnings.warn("hyperreel_amd: frame_kernel was requested for a model on the verified fast path (mlp_precision 'auto' resolved to "
+                              "f16f8 + verification), which is a two-pass plan: the request has no effect; use mlp_precision='f16x3' with it")
 
     def frame_kernel_active(self):
         """True when render() of this model runs as the single persistent frame kernel (head tile in LDS)."""
@@ -652,8 +658,17 @@ class HipLightfieldModel(nn.Module):
         return self._get_option(_lib.HR_OPT_WIDE_COUNT)
 
     def redo_overflowed(self):
-        """Sticky: a render() listed more rays than the list holds (min(chunk, 65536)); the excess kept their first-pass pixels."""
+        """Sticky: a render() listed more rays than a call's list holds (max(65536, B / 8)); the excess kept their first-pass pixels
+        (_overflow_guard then re-decides the arithmetic on those rays and renders the batch again)."""
         return bool(self._get_option(_lib.HR_OPT_REDO_OVERFLOW))
+
+    def verify_info(self):
+        """hr_model_verify_info as a dict: the band of the verified fast path for THIS model and the f16f8-vs-f16x3 measurement on the
+        calibration rays it was derived from (band = max(floor, 4 x the largest difference of a distance / length / point))."""
+        import ctypes as C
+        v = _lib.hr_verify_info()
+        _lib.check(_lib.load().hr_model_verify_info(self.native(), C.byref(v)), 'hr_model_verify_info')
+        return {k: getattr(v, k) for k, _ in v._fields_}
 
     def mlp_overflowed(self):
         """True when an fp16-split kernel saw an activation at the IEEE-half range on a rendered ray (sticky; synchronises)."""
@@ -772,6 +787,17 @@ class HipLightfieldModel(nn.Module):
                     raise _lib.HipRangeError(f'mlp_precision {self.mlp_precision!r} overflowed the IEEE-half range on rendered rays of a point_prediction '
                                              'cascade; use mlp_precision="auto" or "bf16x3"') from e
                 self.mlp_precision = 'bf16x3'
+                self._native_key = None
+                self.native()
+            return True
+        if active == 5 and self.mlp_verified() and self.redo_overflowed():
+            # verified fast path: more than an eighth of the batch had a comparison inside the band -- rays unlike the calibration's (which
+            # gives the fast path up above a tenth).  The excess kept their unverified pixels: measure the band on THESE rays (the library
+            # falls back to f16x3 when they list too many) and render again; a model that still overflows leaves the fast path for good
+            warnings.warn('hyperreel_amd: the verified fast path listed more rays than a call holds; re-calibrating on these rays and rendering the batch again')
+            self.calibrate(rays)
+            if self.mlp_verified() and self.verify_info()['listed_frac'] > 0.10:
+                self.mlp_precision = 'f16x3'
                 self._native_key = None
                 self.native()
             return True

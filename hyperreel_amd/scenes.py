@@ -87,13 +87,49 @@ def _uniform(rng, shape, bound):
     return ((rng.random(shape, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)) * np.float32(bound)).astype(np.float32)
 
 
-def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_scale=0.1):
+# mlp variants of make_state_dict: (factor of every hidden Linear's weight and bias, factor of the last Linear, bias shift of the last Linear)
+#   'hostile'  head x 128 next to the initialiser's (2^5 x 4), biases shifted by -2 / 0 / +2 from one head column to the next
+#   'stiff'    head x 15 (1.5^5 x 2), shift 1
+# The recipe VERDICT r5 names (hidden x 3, last x 8: head x 1944) is beyond what fp32 ITSELF reproduces on the full-size grids: two correct
+# fp32 evaluations of the reference's algorithm (numpy's BLAS order vs torch's) then differ by more than 1e-4 RGB on 29 of 8 448 Neural-3D
+# rays (1.7e-4 max), 3 of 8 448 at (2, 8, 3); (2, 4, 2) stays at 4e-5 -- the largest of the scan that leaves the 1e-4 bar meaningful.
+MLP_VARIANTS = {'hostile': (2.0, 4.0, 2.0), 'stiff': (1.5, 2.0, 1.0)}
+
+
+def _hostile_layer(w, b, last, colour_cols=None, variant='hostile'):
+    """What a trained sample-prediction MLP can look like next to its initialiser: hidden weights and biases scaled (activations grow
+    layer by layer), the last Linear scaled again with its bias shifted from one head column to the next, so that the head's sigmoids and
+    tanhs run into saturation on one side and through their steep middle on the other.  The colour scale / shift columns (identity
+    activations straight into the pixel) are scaled back to the initialiser's magnitude instead: blown-out colours would be clamped to
+    0 / 1 and hide every error of the geometry behind them."""
+    hid, fin, sh = MLP_VARIANTS[variant]
+    if not last:
+        return (w * np.float32(hid)).astype(np.float32), (b * np.float32(hid)).astype(np.float32)
+    n = b.shape[0]
+    fac = np.full(n, fin, np.float32)
+    shift = (np.arange(n) % 3 - 1).astype(np.float32) * np.float32(sh)
+    if colour_cols is not None:
+        fac[colour_cols] = np.float32(1.0 / hid ** 5)
+        shift[colour_cols] = np.float32(0.0)
+    return (w * fac[:, None]).astype(np.float32), (b * fac + shift).astype(np.float32)
+
+
+def _colour_columns(pred):
+    """Boolean mask over the last Linear's outputs (sample-major: index = k * P + column) of the color_* heads."""
+    per = []
+    for name, o in pred['outputs'].items():
+        per += [name.startswith('color')] * int(o['channels'])
+    return np.tile(np.asarray(per, bool), int(pred['z_channels']))
+
+
+def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_scale=0.1, mlp='default'):
     """{reference state_dict key: float32 ndarray} for a random-weight scene.
 
     grid_size: [Nx, Ny, Nz]; defaults to the config's final resolution.
     density: 'dense' | 'default' (the reference initialiser).
     app_scale: std of the appearance planes/lines (reference: 0.1; tests use 1.0 so
-    that decoded colours span the whole [0,1] range instead of hugging 0.5)."""
+    that decoded colours span the whole [0,1] range instead of hugging 0.5).
+    mlp: 'default' (the reference initialiser) | 'hostile' | 'stiff' (MLP_VARIANTS: the same draws, scaled and shifted)."""
     rng = np.random.default_rng(seed)
     net = cfg['color']['net']
     if grid_size is None:
@@ -108,6 +144,10 @@ def make_state_dict(cfg, dataset, grid_size=None, seed=0, density='dense', app_s
         b = 1.0 / math.sqrt(n_in)
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.weight'] = _uniform(rng, (o, n_in), b)
         sd[f'{EMB}{pred_idx}.net.layers.{i}{mid}.bias'] = _uniform(rng, (o,), b)
+        if mlp != 'default':
+            kw, kb = f'{EMB}{pred_idx}.net.layers.{i}{mid}.weight', f'{EMB}{pred_idx}.net.layers.{i}{mid}.bias'
+            pred = next(e for e in emb.values() if e['type'] == 'ray_prediction')
+            sd[kw], sd[kb] = _hostile_layer(sd[kw], sd[kb], i == len(shapes) - 1, _colour_columns(pred), mlp)
 
     for pi, e in enumerate(emb.values()):        # point_prediction cascades: a second MLP, one row per coarse sample
         if e['type'] != 'point_prediction':

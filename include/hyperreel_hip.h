@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HR_ABI_VERSION 25
+#define HR_ABI_VERSION 26
 
 #define HR_MAX_Z 256         /* samples per ray (z_channels) supported by the sample kernel */
 #define HR_MAX_P 64          /* per-sample head columns (preds_per_z) */
@@ -116,11 +116,16 @@ enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
         * comparisons -- `dist <= near` / `>= far` (nlf/intersect/base.py:194), the quadratic's discriminant and root choice
         * (utils/intersect_utils.py:45-125), the bounding box (nlf/nets/tensorf_base.py:349-353), a positive weight threshold -- and F16F8's head
         * error (2e-5 of the head's range; distances move by < 1e-6 of the scene's extent) only shows when one of them falls the other way.  The
-        * sample kernel therefore lists, on the device, every ray with a comparison inside a band of 2.5e-6 of the scene's extent (and the MLP
-        * kernel every tile that raised a range bit), and hr_render / hr_render_frame end with a second, list-driven pass that renders exactly
-        * those rays (0.05 - 1.5 % of a frame) again with F16X3's tiles.  Both passes are ordinary launches on the caller's stream: capturable.
-        * hr_render_fields with diagnostics renders everything with the F16X3 tiles (one arithmetic for every output).  HR_OPT_MLP_PRECISION_ACTIVE
-        * reports HR_MLP_F16F8, HR_OPT_MLP_VERIFIED 1. */
+        * sample kernel therefore lists, on the device, every ray with a comparison inside a BAND of flipping (and the MLP kernel every tile that
+        * raised a range bit), and hr_render / hr_render_frame end with a second, list-driven pass that renders exactly those rays (0.05 - 3 %
+        * of a frame) again with F16X3's tiles.  The band is PER MODEL and PER SAMPLE: hr_model_finalize / hr_model_calibrate run the MLP in both
+        * arithmetics on the calibration rays and measure how far the length fed to the intersection moves; the sample kernel pushes 4x that through
+        * the derivatives of the inverse contraction and of the intersection of each sample (hr_verify_info below; csrc/hr_math.h, HrRisk).
+        * Under HR_MLP_AUTO a model whose margins would list more than 10 % of the calibration rays, or whose calibration image differs from
+        * F16X3's by more than 6e-5 anywhere, is rendered with F16X3 throughout instead; so are intersections the margins are not derived for
+        * (the `_new` primitives, the deformable grid, learned sphere origins, DoNeRFContract).  Both passes are ordinary launches on the caller's stream: capturable.  hr_render_fields with diagnostics,
+        * and models with an occupancy volume set (its cell test is a head-dependent decision the band does not cover), render everything with the
+        * F16X3 tiles.  HR_OPT_MLP_PRECISION_ACTIVE reports HR_MLP_F16F8, HR_OPT_MLP_VERIFIED 1. */
        HR_MLP_F16F8V = 6 };
 /* storage of the feature grids on the device: the reference's float32, or float16 texels (viewer
  * path, BASELINE config 5: half the gather bytes; values are rounded once at finalize, all arithmetic
@@ -324,7 +329,9 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit.
  * HR_OPT_MLP_VERIFIED 1 when hr_render runs the verified fast path (HR_MLP_F16F8V); HR_OPT_REDO_COUNT the number of rays the last hr_render listed
  * for its second pass (reading it synchronises the device); HR_OPT_REDO_OVERFLOW the sticky bit raised when a call listed more rays than the
- * list holds (min(chunk, 65 536)): the excess rays keep their first-pass pixels -- re-create the model with HR_MLP_F16X3 for such scenes.
+ * list holds -- max(65 536, n_rays / 8) per call, i.e. more than 12.5 % of a large call's rays at risk, which the calibration's 10 % rule
+ * makes a property of rays unlike the calibration's: the excess rays keep their first-pass pixels.  A caller that renders without
+ * hyperreel_amd's host guard polls this bit (hr_model_calibrate on such rays re-decides; HR_MLP_F16X3 never lists).
  * HR_OPT_WIDE_COUNT: rays the last hr_render passed on to the THIRD pass (bf16x3 tiles: halves with the fp32 exponent range) because an activation of
  * theirs left the IEEE-half range in the second -- the device-side form of the overflow fallback, inside a captured graph too.  In the verified
  * mode HR_OPT_MLP_OVERFLOW / HR_OPT_MLP_F8_SATURATED are raised only for rays that could not be listed (a full list). */
@@ -333,6 +340,40 @@ enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACT
        HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10, HR_OPT_WIDE_COUNT = 11 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
+
+/* What the verified fast path (HR_MLP_F16F8V) rests on for THIS model: the margins inside which a comparison counts as "at risk" and the
+ * measurement they were derived from (hr_model_finalize on 4096 synthetic rays, hr_model_calibrate on the caller's, again after
+ * hr_model_update_config).  The reference needs none of this: its MLP is fp32 (nlf/nets/mlp.py:159-172) and its decisions are exact
+ * comparisons (nlf/intersect/base.py:194, utils/intersect_utils.py:45-150).
+ * The margins are per SAMPLE (csrc/hr_math.h, HrRisk): with zc = z * scale + anchor (process_z_vals, nlf/intersect/base.py:128-140, before
+ * the inverse contraction), dlen = |d length / d zc| of the inverse contraction and amp = |d distance / d length| of the intersection
+ * (1 / |d_axis| for a plane, 2 |r| / sqrt(discriminant) for sphere and cylinder), a length is at risk within band * dlen, a distance within
+ * band * dlen * amp, a point coordinate within band_q * (largest amp of the ray) + band_off. */
+typedef struct hr_verify_info {
+    int32_t verified;            /* 1: hr_render runs the verified fast path */
+    int32_t fallback;            /* HR_MLP_AUTO gave the fast path up for this model (it renders F16X3): 1 = `listed_frac` exceeded 0.10,
+                                  * 2 = `max_d_rgb` exceeded 6e-5 (the cheap arithmetic's own error is too large on these weights) */
+    float band;                  /* margin of zc: max(band_floor, 4 * max(max_d_zc, max_d_dist_n)) */
+    float band_q;                /* margin of a point coordinate per unit of amplification: max(band_floor, 4 * max_d_geo_n) */
+    float band_off;              /* margin of the point-offset / flow heads: 4 * max_d_off */
+    float band_floor;            /* 1e-6: four float32 ulps of the largest |zc| (2) */
+    float max_d_zc;              /* largest |zc(f16f8) - zc(f16x3)| over all calibration samples */
+    float max_d_dist_n;          /* largest |distance(f16f8) - distance(f16x3)| / (dlen * amp) over the samples alive under both: the margins' model, checked */
+    float max_d_geo_n;           /* largest point difference caused by the distance difference, / amp */
+    float max_d_off;             /* largest point difference caused by the offset / flow heads */
+    float max_d_dist;            /* largest |distance difference| as it is (scene units; reported) */
+    float max_d_head;            /* largest difference of a raw head column (reported) */
+    float listed_frac;           /* fraction of the well-conditioned calibration rays the first pass lists with these margins (hr_model_calibrate: of
+                                  * all the caller's rays, the ill-conditioned ones -- always listed -- included) */
+    float max_d_rgb;             /* largest |rgb(verified path) - rgb(F16X3)| over the well-conditioned calibration rays: f16f8's continuous error on THIS model */
+    int64_t n_rays;              /* calibration rays */
+    int64_t n_rays_used;         /* ... of which well-conditioned (no live sample with amp > 2): every figure above is taken over these; at render time a ray
+                                  * with a live sample beyond that is listed by that alone.  Fewer than 64: listed_frac and max_d_rgb are not measured */
+    int64_t n_samples;           /* samples alive under both arithmetics */
+    int64_t n_flipped;           /* samples left out because their normalised distance moved by more than 1e-3 (a decision fell the other way) */
+    int64_t n_shaky;             /* samples left out because a radius, root or discriminant was exactly 0 */
+} hr_verify_info;
+int hr_model_verify_info(hr_model* m, hr_verify_info* out);
 
 /* Opt-in occupancy early-reject of the render path.  The reference builds an AlphaGridMask while training
  * (TensorBase.updateAlphaMask) and carries the test in its forward -- `alphas = self.alphaMask.sample_alpha(xyz_sampled[ray_valid]);

@@ -45,7 +45,26 @@ CASES = [
     # sit inside the frame whose >1e-4 rays the GPU test counts
     dict(case='neural_3d_full', model='neural_3d_z_plane', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=7, rgb_only=True),
     dict(case='immersive_full', model='immersive_sphere', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=7, rgb_only=True),
+    # HOSTILE sample-prediction MLPs (scenes.MLP_VARIANTS: every hidden Linear x 2, the last x 4, its bias shifted so
+    # that the head's activations saturate -- a head 128 times the initialiser's; the comment there says why not more) for the four families
+    # at the shipped grid, 32 768 rays of the benchmark frame each: what the verified fast path's per-model band and its fall-back rule
+    # (hr_model_finalize) have to hold on -- the f16f8 head error grows with the weights.  `stiff`: the milder variant (head x 15)
+    dict(case='donerf_sphere_hostile', model='donerf_sphere', z=None, grid=None, n_random=256, pin=None, frame=(0, 32768), density='dense', seed=31, mlp='hostile', rgb_only=True),
+    dict(case='technicolor_hostile', model='technicolor_z_plane', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=32, mlp='hostile', rgb_only=True),
+    dict(case='neural_3d_hostile', model='neural_3d_z_plane', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=33, mlp='hostile', rgb_only=True),
+    dict(case='immersive_hostile', model='immersive_sphere', z=None, grid=None, n_random=256, pin=None, frame=(7, 32768), density='dense', seed=34, mlp='hostile', rgb_only=True),
+    dict(case='donerf_sphere_stiff', model='donerf_sphere', z=None, grid=None, n_random=128, pin=None, frame=(0, 16384), density='dense', seed=35, mlp='stiff', rgb_only=True),
+    dict(case='technicolor_stiff', model='technicolor_z_plane', z=None, grid=None, n_random=128, pin=None, frame=(7, 16384), density='dense', seed=36, mlp='stiff', rgb_only=True),
+    dict(case='neural_3d_stiff', model='neural_3d_z_plane', z=None, grid=None, n_random=128, pin=None, frame=(7, 16384), density='dense', seed=37, mlp='stiff', rgb_only=True),
+    dict(case='immersive_stiff', model='immersive_sphere', z=None, grid=None, n_random=128, pin=None, frame=(7, 16384), density='dense', seed=38, mlp='stiff', rgb_only=True),
 ]
+
+# POST-FIT weights: the reference's own 200-step Adam run of tests/golden/fit/<case>.npz (make_fit_golden.py, same recipe, same seeds) --
+# the trained tensors are stored IN the fixture ('sd/<key>': they are what was trained, not a seed) next to the reference's render of them
+POSTFIT = {
+    'donerf_sphere_postfit': ('donerf_sphere_fit', 4096, 51),
+    'technicolor_postfit': ('technicolor_z_plane_fit', 4096, 52),
+}
 
 
 def special_rays(video, z_plane):
@@ -99,7 +118,8 @@ def build(c):
     model_cfg = C.model_config(c['model'], z_channels=c['z'])
     ds = C.dataset_scalars(c['model'])
     if c['grid'] is None:        # the shipped final grid (what make_state_dict builds without a size)
-        c['grid'] = [int(v) for v in scenes.make_state_dict(model_cfg, ds, None, c['seed'], c['density'], c.get('app_scale', 1.0))['model.color_model.net.gridSize']]
+        from hyperreel_amd.config import n_to_reso
+        c['grid'] = [int(v) for v in n_to_reso(model_cfg['color']['net']['N_voxel_final'], model_cfg['color']['net']['aabb'])]
     # reference side: the shipped YAML, plus the same overrides
     def overrides(cfg):
         if c['z'] is not None:
@@ -108,7 +128,7 @@ def build(c):
         cfg.color.net.grid_size = ref_shim.to_attr({'start': list(c['grid']), 'end': list(c['grid'])})
     ref_cfg = ref_shim.load_model_cfg(c['model'], overrides)
     fn = ref_shim.build_reference(ref_cfg, ds)
-    sd = scenes.make_state_dict(model_cfg, ds, c['grid'], c['seed'], c['density'], c.get('app_scale', 1.0))
+    sd = scenes.make_state_dict(model_cfg, ds, c['grid'], c['seed'], c['density'], c.get('app_scale', 1.0), c.get('mlp', 'default'))
     own = dict(fn.state_dict())
     with torch.no_grad():
         for k, v in sd.items():
@@ -137,7 +157,7 @@ def main(only=None):
             'recipe': np.frombuffer(json.dumps({
                 'case': c['case'], 'model': c['model'], 'z_channels': c['z'], 'grid': c['grid'],
                 'seed': c['seed'], 'density': c['density'], 'app_scale': c.get('app_scale', 1.0), 'dataset': ds,
-                'checksum': scenes.state_dict_checksum(sd)}).encode(), dtype=np.uint8),
+                'mlp': c.get('mlp', 'default'), 'checksum': scenes.state_dict_checksum(sd)}).encode(), dtype=np.uint8),
         }
         if c.get('frame') is not None:
             # the frame's rays are a pure function of (model, frame): the fixture keeps their pixel indices only and
@@ -163,5 +183,56 @@ def main(only=None):
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_postfit(only=None):
+    """The reference trained by the reference (make_fit_golden.fit: 200 Adam steps), then rendered by the reference on fresh rays."""
+    import make_fit_golden as F
+    for case, (fit_case, n_rays, ray_seed) in POSTFIT.items():
+        if only and case not in only:
+            continue
+        model, grid, s_seed, t_seed, (H, W, frame), lr = F.CASES[fit_case]
+        F.LR = lr
+        cfg, ds = C.model_config(model), C.dataset_scalars(model)
+        fit_rays = torch.from_numpy(np.ascontiguousarray(scenes.benchmark_rays(model, H, W, frame=frame), np.float32))
+        teacher = F.build(model, grid, ds, scenes.make_state_dict(cfg, ds, grid, t_seed, 'dense', 1.0))
+        target = ref_shim.run_reference(teacher, fit_rays)['rgb'].detach().clone()
+        student_sd = scenes.make_state_dict(cfg, ds, grid, s_seed, 'dense', 1.0)
+        fn = F.build(model, grid, ds, student_sd)
+        fn.train()
+        params = [p for n, p in fn.named_parameters() if 'dummy' not in n]
+        opt = torch.optim.Adam(params, lr=lr)
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: torch.full((1,), 0.9)
+        try:
+            for step in range(F.N_STEPS):
+                opt.zero_grad(set_to_none=True)
+                with ref_shim.cpu_mode():
+                    loss = ((fn(fit_rays)['rgb'] - target) ** 2).mean()
+                loss.backward()
+                opt.step()
+        finally:
+            torch.rand = real_rand
+        fn.eval()
+        trained = {k: v.detach().numpy().astype(np.float32) for k, v in fn.state_dict().items() if k in student_sd and not k.endswith('gridSize')}
+        video = not model.startswith('donerf')
+        full = scenes.benchmark_rays(model, 800, 800, frame=frame)
+        idx = np.sort(np.random.default_rng(ray_seed).choice(full.shape[0], n_rays, replace=False))
+        rays = np.ascontiguousarray(np.concatenate([full[idx], special_rays(video, 'z_plane' in model)], 0), np.float32)
+        out = ref_shim.run_reference(fn, torch.from_numpy(rays))
+        payload = {'rays': rays, 'rgb': out['rgb'].numpy().astype(np.float32),
+                   'recipe': np.frombuffer(json.dumps({
+                       'case': case, 'model': model, 'z_channels': None, 'grid': grid, 'seed': s_seed, 'density': 'dense', 'app_scale': 1.0,
+                       'dataset': ds, 'mlp': 'default', 'postfit_of': fit_case, 'final_loss': float(loss.detach()),
+                       'checksum': scenes.state_dict_checksum(student_sd)}).encode(), dtype=np.uint8)}
+        for k, v in trained.items():
+            payload['sd/' + k] = v
+        path = os.path.join(OUT, case + '.npz')
+        np.savez_compressed(path, **payload)
+        moved = max(float(np.abs(trained[k] - student_sd[k]).max()) for k in trained if trained[k].size)
+        print(f"{case}: {rays.shape[0]} rays, final loss {float(loss.detach()):.5f}, largest weight change {moved:.3f}, rgb mean {payload['rgb'].mean():.4f}, "
+              f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == '__main__':
-    main(sys.argv[1:] or None)
+    only = sys.argv[1:] or None
+    main(only)
+    main_postfit(only)

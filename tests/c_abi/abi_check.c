@@ -48,6 +48,7 @@ int main(void)
         if (hr_model_set_occupancy(NULL, NULL, n3, box, NULL) != HR_E_INVALID) return 23;
         { int32_t v = 0; if (hr_model_get_option(NULL, HR_OPT_SAMPLE_WAVES, &v) != HR_E_INVALID) return 19; }
         if (hr_model_calibrate(NULL, &x, 1, NULL, NULL) != HR_E_INVALID) return 24;
+        { hr_verify_info vi; if (hr_model_verify_info(NULL, &vi) != HR_E_INVALID || sizeof(hr_verify_info) != 96) return 32; }
         if (hr_allgather_tiles(NULL, &x, &x, 3, NULL) != HR_E_INVALID) return 25;
         {   /* hr_adam_step: NULL arrays refused; a negative size and a step count of 0 refused before anything is launched; zero tensors is a no-op */
             float* pp[1] = {&x}; const float* gp[1] = {&x}; int64_t nn[1] = {-1}; double hp[6] = {1e-3, 0.9, 0.99, 1e-8, 0.0, 1.0};

@@ -5,13 +5,13 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, golden_cases, linf, sweep_cases
+from helpers import Golden, golden_cases, initialiser_golden_cases, linf, sweep_cases
 
 pytestmark = pytest.mark.gpu
 RGB_TOL = 1e-4
 
 
-@pytest.mark.parametrize('case', golden_cases())
+@pytest.mark.parametrize('case', initialiser_golden_cases())
 def test_f16f8_matches_every_reference_golden(case):
     from gpu_common import make_render_fn, render_np
     g = Golden(case)

@@ -1,7 +1,7 @@
 """`-m gpu`: the verified fast path (HR_MLP_F16F8V; what mlp_precision='auto' resolves to for a plain ray MLP with <= 64 samples per ray).
 
 First pass: the MLP in f16 + fp8 (two thirds of f16x3's matrix-pipe time); the sample kernel lists, on the device, every ray with a
-comparison within 2.5e-6 of the scene's extent of flipping -- `dist <= near` (nlf/intersect/base.py:194), the quadratic's discriminant and
+comparison inside its margin of flipping (per model and per sample: csrc/hr_math.h HrRisk, hr_model_verify_info) -- `dist <= near` (nlf/intersect/base.py:194), the quadratic's discriminant and
 root choice (utils/intersect_utils.py:45-125), the box test (nlf/nets/tensorf_base.py:349-353).  Second pass: exactly those rays again with
 the f16x3 tiles.  What is held here:
   * every pixel is, bit for bit, either the plain f16f8 pixel or the plain f16x3 pixel of that ray, and at most `redo_count` are the latter;
@@ -178,3 +178,174 @@ def test_rays_outside_the_half_range_are_repaired_on_the_device_inside_a_hipgrap
         near_tile = torch.arange(lo, hi, device='cuda')
         assert float((out[near_tile] - torch.where(torch.isin(near_tile, far)[:, None], ref_far[near_tile], clean[near_tile])).abs().max()) <= 1e-4
     assert 700 <= auto.wide_count() <= 13 * 64 and not auto.mlp_overflowed() and not auto.redo_overflowed()
+
+
+# ---- the band is the MODEL's: measured at finalize / calibrate, proven on hostile weights
+HOSTILE = ['donerf_sphere_hostile', 'technicolor_hostile', 'neural_3d_hostile', 'immersive_hostile',
+           'donerf_sphere_stiff', 'technicolor_stiff', 'neural_3d_stiff', 'immersive_stiff', 'donerf_sphere_postfit', 'technicolor_postfit']
+
+
+def _check_info(vi):
+    floor = vi['band_floor']
+    assert floor == pytest.approx(1e-6)
+    if vi['verified']:
+        assert vi['band'] >= floor and vi['band'] >= 4.0 * max(vi['max_d_zc'], vi['max_d_dist_n']) * (1.0 - 1e-6), vi
+        assert vi['band_q'] >= floor and vi['band_q'] >= 4.0 * vi['max_d_geo_n'] * (1.0 - 1e-6), vi
+        assert vi['band_off'] >= 4.0 * vi['max_d_off'] * (1.0 - 1e-6), vi
+        assert vi['listed_frac'] <= 0.10 and vi['max_d_rgb'] <= 6e-5, vi
+        assert vi['n_samples'] > 0 and vi['fallback'] == 0
+    else:
+        assert vi['fallback'] in (1, 2), vi
+        assert {1: vi['listed_frac'] > 0.10, 2: vi['max_d_rgb'] > 6e-5}[vi['fallback']], vi
+
+
+def _fmt(vi):
+    return (f"verified {vi['verified']} fallback {vi['fallback']} band {vi['band']:.2e} q {vi['band_q']:.2e} off {vi['band_off']:.2e} | d_zc {vi['max_d_zc']:.2e} "
+            f"d_dist_n {vi['max_d_dist_n']:.2e} d_geo_n {vi['max_d_geo_n']:.2e} d_off {vi['max_d_off']:.2e} d_dist {vi['max_d_dist']:.2e} d_head {vi['max_d_head']:.2e} "
+            f"d_rgb {vi['max_d_rgb']:.2e} listed {vi['listed_frac']:.4f} | rays {vi['n_rays_used']}/{vi['n_rays']} samples {vi['n_samples']} flipped {vi['n_flipped']} "
+            f"shaky {vi['n_shaky']}")
+
+
+@pytest.mark.parametrize('case', HOSTILE)
+def test_auto_holds_the_bar_on_hostile_and_trained_weights(case):
+    """Reference-rendered fixtures whose sample-prediction MLP is NOT the initialiser's: weights scaled and heads driven into saturation
+    (scenes.MLP_VARIANTS), and the reference's own post-fit weights.  f16f8's head error grows with the weights; 'auto' either keeps the
+    verified path with a band measured on this model (>= 4 x the largest f16f8-vs-f16x3 difference of a compared quantity) or gives it up
+    for f16x3 -- and in both cases no ray is further than 1e-4 from the REFERENCE's pixel."""
+    from gpu_common import make_render_fn, render_np
+    g = Golden(case)
+    fn = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    out = render_np(fn, g.rays)['rgb']
+    m = fn.model
+    vi = m.verify_info()
+    _check_info(vi)
+    err = np.abs(out - g.rgb).max(-1)
+    n_redo = m.redo_count() if m.mlp_verified() else 0
+    print(f"{case}: {_fmt(vi)}; frame: {n_redo} listed, worst {err.max():.2e}")
+    assert np.isfinite(out).all()
+    assert int((err > 1e-4).sum()) == 0, f'{case}: {int((err > 1e-4).sum())} rays over 1e-4, worst {err.max():.3e} at ray {int(err.argmax())}'
+    assert not m.redo_overflowed()
+
+
+@pytest.mark.parametrize('case', ['donerf_sphere_hostile', 'neural_3d_hostile', 'immersive_stiff'])
+def test_forced_verified_path_on_hostile_weights_against_plain_f16x3(case):
+    """mlp_precision='f16f8v' keeps the two-pass plan whatever the calibration says: the band alone has to repair every flipped decision.
+    Counted against the f16x3 image of the same model (the continuous error of f16f8 on these weights is what `max_d_rgb` reports and what
+    makes 'auto' fall back; a flipped decision is 1e-2)."""
+    from gpu_common import make_render_fn
+    g = Golden(case)
+    rays = torch.from_numpy(g.rays).cuda()
+    v = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16f8v', iteration=g.iteration).model
+    s = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3', iteration=g.iteration).model
+    p = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16f8', iteration=g.iteration).model
+    iv, is_, ip = v.render(rays)['rgb'], s.render(rays)['rgb'], p.render(rays)['rgb']
+    torch.cuda.synchronize()
+    assert v.mlp_verified()
+    vi = v.verify_info()
+    d_v = (iv - is_).abs().amax(-1)
+    d_p = (ip - is_).abs().amax(-1)
+    # a flipped decision moves a pixel by orders of magnitude more than the continuous error: count rays beyond 20 x the calibration's image error
+    cut = max(1e-4, 20.0 * vi['max_d_rgb'])
+    print(f"{case}: {_fmt(vi)}; listed {v.redo_count()} of {rays.shape[0]}; rays beyond {cut:.1e}: plain f16f8 {int((d_p > cut).sum())}, "
+          f"verified {int((d_v > cut).sum())}; worst {float(d_p.max()):.2e} -> {float(d_v.max()):.2e}")
+    assert int((d_v > cut).sum()) == 0
+    fast = (iv == ip).all(-1)
+    safe = (iv == is_).all(-1)
+    assert bool((fast | safe).all())
+
+
+def test_default_families_keep_the_fast_path_with_a_measured_band():
+    for model in ('donerf_sphere', 'technicolor_z_plane', 'immersive_sphere', 'neural_3d_z_plane'):
+        from gpu_common import make_render_fn
+        cfg, ds = C.model_config(model), C.dataset_scalars(model)
+        sd = scenes.make_state_dict(cfg, ds, [64, 64, 64], seed=7, density='dense', app_scale=1.0)
+        m = make_render_fn(cfg, ds, sd).model
+        m.native()
+        vi = m.verify_info()
+        _check_info(vi)
+        assert vi['verified'] == 1, (model, vi)
+        assert vi['n_rays'] == 4096
+        # calibrate on the caller's rays: the measurement is taken again on (a strided sample of) them
+        rays = torch.from_numpy(scenes.benchmark_rays(model, 400, 400, frame=3)).cuda()
+        m.calibrate(rays)
+        v2 = m.verify_info()
+        _check_info(v2)
+        assert v2['n_rays'] == 160000 // 3 + 1 and v2['verified'] == 1, v2
+        print(f"{model}: synthetic rays: {_fmt(vi)}")
+        print(f"{model}: camera rays:    {_fmt(v2)}")
+
+
+def test_the_list_is_walked_in_slices_of_the_workspace():
+    """A call whose list is longer than the chunk's head workspace (the list no longer stops at min(chunk, 65 536)): a chunk of
+    4 096 rays and 20 000 rays of which every third leans 63 degrees off the planes' normal -- conditioned worse than anything the margins
+    were measured on (amp 2.2 > 2), so listed by that alone -- rendered again in slices with the f16x3 tiles: those rays carry the f16x3
+    model's pixels, every other one the f16f8 model's or the f16x3 model's."""
+    from gpu_common import make_render_fn
+    g = Golden('technicolor_z_plane_small')
+    rays_np = np.concatenate([g.rays[:160]] * 125, 0).copy()      # the Gaussian rays about (0, 0, 1) looking down -z
+    lean = np.arange(0, 20000, 3)
+    d = np.array([0.6, 0.65, -0.4665], np.float32)
+    rays_np[lean, 3:6] = d / np.linalg.norm(d)
+    rays = torch.from_numpy(rays_np).cuda()
+    auto = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).model
+    safe = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3', iteration=g.iteration).model
+    fast = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16f8', iteration=g.iteration).model
+    auto.reserve(4096)
+    auto._render_calls = 1000                                   # past the calls on which render() polls the sticky bits itself
+    out, ref, cheap = auto.render(rays)['rgb'], safe.render(rays)['rgb'], fast.render(rays)['rgb']
+    torch.cuda.synchronize()
+    assert auto.mlp_verified(), auto.verify_info()
+    n = auto.redo_count()
+    assert n > 4096, n                                          # more than one slice
+    lean_t = torch.from_numpy(lean).cuda()
+    assert torch.equal(out[lean_t], ref[lean_t]), f'{int((out[lean_t] != ref[lean_t]).any(-1).sum())} leaning rays differ from the f16x3 image'
+    is_safe, is_fast = (out == ref).all(-1), (out == cheap).all(-1)
+    assert bool((is_safe | is_fast).all()) and int((is_safe & ~is_fast).sum()) <= n
+    assert not auto.redo_overflowed()
+    # and the next call starts from a clean list
+    few = torch.from_numpy(np.concatenate([g.rays[:160]] * 4, 0)).cuda()
+    a2, s2 = auto.render(few)['rgb'], safe.render(few)['rgb']
+    torch.cuda.synchronize()
+    assert auto.redo_count() < few.shape[0] // 4 and float((a2 - s2).abs().max()) <= 1e-4
+
+
+def test_an_occupancy_volume_takes_the_fast_path_off():
+    """hr_occupancy_test decides per cell from a head-dependent point, which the band does not cover -- with a volume set, 'auto'
+    renders with the f16x3 tiles throughout."""
+    from gpu_common import make_render_fn
+    g = Golden('donerf_sphere_small')
+    sd = scenes.carve_density(g.state_dict)
+    a = make_render_fn(g.cfg, g.dataset, sd).model
+    b = make_render_fn(g.cfg, g.dataset, sd, mlp_precision='f16x3').model
+    for m in (a, b):
+        m.color_model.net.updateAlphaMask((24, 24, 24))
+        m.set_occupancy(True)
+    rays = torch.from_numpy(np.concatenate([g.rays] * 4, 0)).cuda()
+    ia, ib = a.render(rays)['rgb'], b.render(rays)['rgb']
+    torch.cuda.synchronize()
+    assert a.mlp_verified() and torch.equal(ia, ib)
+
+
+def test_a_batch_that_overflows_the_list_is_rendered_again_by_the_host_guard():
+    """a call may list max(65 536, B / 8) rays.  100 000 rays that ALL lean 63 degrees off the planes' normal (every one listed by
+    its conditioning alone) overflow it; the excess would keep unverified pixels.  render() reads the sticky bit on its first calls,
+    re-calibrates on the batch -- the caller's rays: the ill-conditioned ones count as listed, so 'auto' gives the fast path up -- and
+    renders again: the f16x3 model's image, with a warning."""
+    from gpu_common import make_render_fn
+    g = Golden('technicolor_z_plane_small')
+    rays_np = np.concatenate([g.rays[:160]] * 625, 0).copy()
+    d = np.array([0.6, 0.65, -0.4665], np.float32)
+    rays_np[:, 3:6] = d / np.linalg.norm(d)
+    rays = torch.from_numpy(rays_np).cuda()
+    auto = make_render_fn(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).model
+    safe = make_render_fn(g.cfg, g.dataset, g.state_dict, mlp_precision='f16x3', iteration=g.iteration).model
+    auto.native()
+    assert auto.mlp_verified()
+    with pytest.warns(UserWarning, match='listed more rays than a call holds'):
+        out = auto.render(rays)['rgb']
+    ref = safe.render(rays)['rgb']
+    torch.cuda.synchronize()
+    vi = auto.verify_info()
+    assert not auto.mlp_verified() and vi['fallback'] == 1 and vi['listed_frac'] > 0.10 and auto.mlp_precision_active() == 'f16x3', vi
+    assert torch.equal(out, ref)
+    assert not auto.redo_overflowed()

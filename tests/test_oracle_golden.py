@@ -15,10 +15,12 @@ def test_oracle_matches_reference_golden(case):
     # fp32 on both sides; only BLAS summation order / libm ulps differ.  On the 33 000-ray subsets of the full-size
     # white-noise grids (`*_full`: 640^3 / 823x617x514 texels of unit-variance noise) the last bits of a sample position
     # move the bilinear taps more than anywhere else: the tail of 33 000 rays reaches 3e-5 where 500 rays stay below 2e-5
-    tol = 5e-5 if case in ('neural_3d_full', 'immersive_full') else 2e-5
+    # `*_hostile`: MLP weights scaled x3 / x8 (scenes._hostile_layer) amplify the fp32 rounding of the matrix chain itself -- two correct
+    # fp32 evaluations (numpy's BLAS order vs torch's) sit up to 4e-5 apart in RGB
+    tol = 5e-5 if case in ('neural_3d_full', 'immersive_full') or case.endswith(('_hostile', '_stiff')) else 2e-5
     err = np.abs(out['rgb'] - g.rgb).max(-1)
     assert err.max() <= tol, f'{err.max():.3e}'
-    assert (err > 2e-5).mean() <= 1e-3
+    assert (err > 2e-5).mean() <= (1e-2 if case.endswith(('_hostile', '_stiff')) else 1e-3)
     if 'distances' in g.arrays:
         n, Z = g.arrays['distances'].shape
         d_ref = g.arrays['distances']
@@ -46,7 +48,7 @@ def test_torch_port_matches_reference_golden(case):
     from torch_port import TorchPort
     g = Golden(case)
     out = TorchPort(g.cfg, g.dataset, g.state_dict, iteration=g.iteration).render(g.rays)
-    assert linf(out['rgb'], g.rgb) <= 2e-5
+    assert linf(out['rgb'], g.rgb) <= (5e-5 if case.endswith(('_hostile', '_stiff')) else 2e-5)
 
 
 @pytest.mark.parametrize('case', sweep_cases())
