@@ -1,18 +1,24 @@
 #!/usr/bin/env python
 """Benchmark of the HyperReel forward-render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 without a launcher around it (no WORLD_SIZE in the environment): the script starts its N ranks itself -- torch.distributed.run,
+one process per GPU, rendezvous on 127.0.0.1 -- and passes their one JSON line through.
 
 Workload (BASELINE.json configs[1]): DoNeRF static scene, `donerf_sphere` model group, 800x800 pinhole frame = 640 000
 rays, 32 samples/ray, shipped final grid 600^3, synthetic random-weight scene ('dense' density variant so alpha spans
 (0,1)).  One step = one full forward render of a frame with rays and rgb resident in HBM.
 
-Multi-GPU: `--scaling weak` (default): every rank renders its own 800x800 tile of an (800*N)x800 panorama and the tiles are
-all-gathered over RCCL/xGMI inside the timed step.  `--scaling strong`: ONE 800x800 frame per step, split into N contiguous
-pixel ranges (rays generated on each GPU from the camera), the all-gather of frame i double-buffered under the render of
-frame i+1 (hyperreel_amd.parallel.ShardedFramePipeline) -- BASELINE's "800x800 frame ms at 1/2/4/8".  value = rays of all
-ranks per second either way.
+Multi-GPU, both in every N > 1 line:
+  `value` (scaling "weak", the driver's contract): every rank renders its own 800x800 frame (the same camera, panned by the rank) and the
+      tiles are all-gathered over RCCL/xGMI inside the timed step; value = rays of all ranks per second.
+  `strong` (BASELINE's "800x800 frame ms at 1/2/4/8", the north star's ">= 6x image-parallel scaling at 8 GPUs"): ONE 800x800 frame per
+      step, split into N contiguous pixel ranges, the all-gather of frame i double-buffered under the render of frame i + 1
+      (hyperreel_amd.parallel.ShardedFramePipeline).  frame_ms is the answer to "frame ms at N"; speedup_vs_n1_frame_ms prices it against
+      a whole frame on one rank of the same job; tile_render_ms / gather_alone_ms / gather_overlap say where the rest went.
+  `--scaling strong` makes the strong window `value` as well.
 
 The JSON line also carries
   roofline        the dominant kernel of the step, its launches timed live with HIP events on the launch stream, against the
@@ -41,6 +47,17 @@ sys.path.insert(0, ROOT)
 
 from hyperreel_amd import config as C  # noqa: E402
 from hyperreel_amd import scenes  # noqa: E402
+
+# HR_BENCH_FAKE_RENDERER=1 (tests/test_bench_launch.py only): the launch / rank / window / JSON plumbing of a multi-rank run on CPU over gloo
+# with a stand-in renderer -- no figure of such a run means anything, and its line says so in `data`
+FAKE = os.environ.get('HR_BENCH_FAKE_RENDERER') == '1'
+DEV = 'cpu' if FAKE else 'cuda'
+
+
+def sync():
+    if not FAKE:
+        torch.cuda.synchronize()
+
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (= fp32 vector) peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (measured 2495)
@@ -172,20 +189,20 @@ def family_figures(names=('technicolor_z_plane', 'neural_3d_z_plane', 'immersive
 def timed_frames(step, steps, warmup, multi, dist):
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if multi:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if multi:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -196,22 +213,22 @@ def prewarm(step, seconds, multi, dist):
     manager takes ~15 frames (30-40 ms) to reach the steady clock (profiles/r05_headline_diag_*.json: 2.35 -> 1.98 ms per frame over the
     first 15 replays of a process, again after 0.5 s of idling); 5 warm-up steps end inside that ramp.  Multi-rank: every rank runs the
     SAME number of steps (the step holds a collective)."""
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(8):
         step()
-    torch.cuda.synchronize()
+    sync()
     per = max((time.perf_counter() - t0) / 8, 1e-5)
     n = int(min(max(seconds / per, 8), 4000))
     if multi:
-        t = torch.tensor([n], dtype=torch.int64, device='cuda')
+        t = torch.tensor([n], dtype=torch.int64, device=DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = int(t.item())
     for i in range(n):
         step()
         if i % 32 == 31:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
+            sync()
+    sync()
     return n + 8
 
 
@@ -297,6 +314,108 @@ def viewer_figures(sizes=((512, 512), (800, 800)), model_name='immersive_sphere'
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
+    `torch.distributed.run`, rendezvous on 127.0.0.1) with the same arguments, pass their output through, return their exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class _FakeModel:
+    """HR_BENCH_FAKE_RENDERER: render(rays, out=None) -> {'rgb'} on the CPU, a pure function of the rays (so that gathered frames can be checked)."""
+
+    def render(self, rays, out=None, **_):
+        rgb = torch.sigmoid(rays[:, :3] * 3.0 + rays[:, 3:6])
+        if out is not None:
+            out.copy_(rgb)
+            rgb = out
+        return {'rgb': rgb}
+
+    def mlp_overflowed(self): return False
+    def mlp_precision_active(self): return 'fp32'
+    def frame_kernel_active(self): return False
+    def mlp_verified(self): return False
+
+
+def local_frames(step, steps, warmup):
+    """Seconds per step of `step` on THIS rank alone (no barrier, no reduction)."""
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def max_over_ranks(x, dist):
+    t = torch.tensor([x], dtype=torch.float64, device=DEV)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def strong_window(model, args, dist, local_rank, headline, n1_frame_s):
+    """ONE frame per step, split into contiguous pixel ranges (north star: "800x800 frame ms at 1/2/4/8", ">= 6x image-parallel scaling"):
+    this rank renders its range into the pipeline's tile buffer, the all-gather of frame i runs on a side stream under the render of
+    frame i + 1 (hyperreel_amd.parallel.ShardedFramePipeline).  Returns (dt, windows, n_pre, full frame, this rank's rays, info)."""
+    from hyperreel_amd.parallel import ShardedFramePipeline
+    rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7)
+    n_pix = args.height * args.width
+    pipe = ShardedFramePipeline(n_pix, torch.device(DEV, local_rank) if not FAKE else torch.device('cpu'), always_gather=True)
+    rays = torch.from_numpy(np.ascontiguousarray(rays_np[pipe.lo:pipe.hi])).to(DEV)     # the rays generate_rays would produce
+    model.render(rays)
+    sync()
+    if args.no_graph or FAKE:
+        def step():
+            tile = pipe.begin()
+            model.render(rays, out=tile)
+            return pipe.submit()
+        tile_only = lambda: model.render(rays, out=pipe.tiles[0][:pipe.hi - pipe.lo])
+    else:       # one hipGraph per tile buffer: a step is a graph launch + the all-gather enqueue
+        step = pipe.capture(lambda tile: model.render(rays, out=tile))
+        g_tile, _ = capture(model, rays)
+        tile_only = g_tile.replay
+    dt, windows, n_pre = headline(step)
+    # host time per frame: how long the CPU needs to enqueue a step (no synchronisation inside the loop) -- the floor a rank's
+    # frame time cannot go below however little of the frame it renders
+    sync()
+    t_h = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    host_us = (time.perf_counter() - t_h) / args.steps * 1e6
+    sync()
+    rgb_full = pipe.flush()
+    sync()
+    # what the pieces cost alone: this rank's tile without any collective, and the all-gather without any render
+    tile_s = max_over_ranks(local_frames(tile_only, args.steps, args.warmup), dist)
+
+    def gather_only():
+        dist.all_gather_into_tensor(pipe.full[0], pipe.tiles[0])
+    gather_s = max_over_ranks(local_frames(gather_only, args.steps, args.warmup), dist)
+    frame_s = dt / args.steps
+    exposed = max(0.0, frame_s - tile_s)
+    info = {'what': f'ONE {args.height}x{args.width} frame per step split into {pipe.world} contiguous pixel ranges, all-gather of frame i under the render of frame i + 1',
+            'frame_ms': round(frame_s * 1e3, 4), 'mrays_s': round(n_pix / frame_s / 1e6, 3),
+            'n1_frame_ms': round(n1_frame_s * 1e3, 4),
+            'speedup_vs_n1_frame_ms': round(n1_frame_s / frame_s, 3),
+            'tile_render_ms': round(tile_s * 1e3, 4), 'gather_alone_ms': round(gather_s * 1e3, 4),
+            'gather_overlap': round(min(1.0, max(0.0, 1.0 - exposed / gather_s)), 3) if gather_s > 0 else None,
+            'host_us_per_frame': round(host_us, 1), 'ranks': pipe.world, 'rays_per_rank': int(pipe.hi - pipe.lo),
+            'windows_ms_per_frame': [round(w / args.steps * 1e3, 4) for w in windows],
+            'answers': 'BASELINE metric "800x800 frame ms at N GPUs" = frame_ms; north star ">= 6x image-parallel scaling at 8 GPUs" = speedup_vs_n1_frame_ms'}
+    return dt, windows, n_pre, rgb_full, rays, pipe, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -313,7 +432,8 @@ def main():
     ap.add_argument('--no-stage-timing', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16f8', 'f16x2', 'fp32'],
-                    help="arithmetic of the MLP GEMMs: auto = 3-product fp16 split on MFMA (fp32-grade), or exact fp32 MFMA")
+                    help="arithmetic of the MLP GEMMs: auto = the library's choice (f16 + fp8 first pass with its discrete decisions verified by an f16x3 "
+                         "second pass where that applies, DESIGN 3c; f16x3 / bf16x3 otherwise), or one arithmetic by name (fp32 = the exact fp32 MFMA)")
     ap.add_argument('--no-graph', action='store_true', help='enqueue every frame eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--grid-dtype', default='fp32', choices=['fp32', 'fp16'],
                     help='texel storage: float32 (the reference; headline) or float16 (viewer path, BASELINE config 5)')
@@ -327,18 +447,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: be the launcher (the driver's own multi-GPU command comes in through torch.distributed.run with WORLD_SIZE set)
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with torch.distributed.run (one process per GPU)')
-    torch.cuda.set_device(local_rank)
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: one process per GPU, launched as torch.distributed.run --nproc-per-node {args.gpus}')
+    if not FAKE:
+        torch.cuda.set_device(local_rank)
     dist = None
-    # HR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-gather, barrier, max-reduce) with a single
+    # HR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-gather, barrier, max-reduce, the strong window) with a single
     # rank -- the only way to exercise it on a one-GPU box
     multi = world > 1 or os.environ.get('HR_BENCH_FORCE_DIST') == '1'
     if multi:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if FAKE:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     if args.lib:
         from hyperreel_amd import lib as _hl
@@ -347,7 +473,7 @@ def main():
     cfg = C.model_config(args.model)
     ds = C.dataset_scalars(args.model)
     video = cfg['color']['net']['type'] == 'tensor_vm_split_time'
-    sd = scenes.make_state_dict(cfg, ds, None, seed=7, density='dense', app_scale=1.0)
+    sd = scenes.make_state_dict(cfg, ds, [16, 16, 16] if FAKE else None, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
     texel_bytes = 2 if args.grid_dtype == 'fp16' else 4
     # checker-side weights: with float16 texels the reference algorithm is run on the same rounded grids
@@ -371,82 +497,63 @@ def main():
         return sorted(wins)[(len(wins) - 1) // 2], wins, n_pre
 
     use_frame = (2 if args.frame_mode == 2 else True) if (args.frame_kernel and not args.no_frame_kernel) else False
-    fn = make(args.mlp_precision, use_frame)
-    model = fn.model
-    strong = args.scaling == 'strong' and multi
+    model = _FakeModel() if FAKE else make(args.mlp_precision, use_frame).model
+    want_strong_value = args.scaling == 'strong' and multi
     Z = cfg['embedding']['embeddings']['ray_prediction_0']['z_channels']
 
+    # ---- the weak window: every rank renders its own frame (the same camera, panned by the rank), the tiles all-gathered inside the step
     graph = None
-    if not strong:
-        # tile of this rank: the same camera, panned by the tile index (weak scaling)
-        rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
-        if world > 1:
-            pose_shift = np.zeros_like(rays_np)
-            pose_shift[:, 1] = 0.01 * rank
-            rays_np = rays_np + pose_shift
-        rays = torch.from_numpy(rays_np).cuda()
-        B = rays.shape[0]
-        gathered = torch.empty((world, B, 3), dtype=torch.float32, device='cuda') if multi else None
-        if not args.no_graph:
-            graph, rgb_static = capture(model, rays)
+    rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7 + rank)
+    if world > 1:
+        pose_shift = np.zeros_like(rays_np)
+        pose_shift[:, 1] = 0.01 * rank
+        rays_np = rays_np + pose_shift
+    rays = torch.from_numpy(rays_np).to(DEV)
+    B = rays.shape[0]
+    gathered = torch.empty((world, B, 3), dtype=torch.float32, device=DEV) if multi else None
+    if not args.no_graph and not FAKE:
+        graph, rgb_static = capture(model, rays)
 
-        def step():
-            if graph is not None:
-                graph.replay()
-                out = rgb_static
-            else:
-                out = model.render(rays)['rgb']
-            if multi:
-                dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))
-            return out
+    def render_frame():
+        if graph is not None:
+            graph.replay()
+            return rgb_static
+        return model.render(rays)['rgb']
 
+    def step():
+        out = render_frame()
+        if multi:
+            dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))
+        return out
+
+    strong_info = None
+    if not want_strong_value:
         dt, windows, n_pre = headline(step)
         rgb = step()
-        torch.cuda.synchronize()
+        sync()
         total_rays = B * world
         rays_per_gpu = B
         parallelism = f'image tiles x{world}, RCCL all_gather of rgb' if world > 1 else 'single GPU'
-    else:
-        # strong scaling: ONE frame per step, split into contiguous pixel ranges; this rank's rays come from the camera on
-        # the device (hr_generate_rays), the tile is rendered into the pipeline's buffer, its all-gather runs on a side
-        # stream under the next frame's render
-        from hyperreel_amd.parallel import ShardedFramePipeline
-        rays_np = scenes.benchmark_rays(args.model, args.height, args.width, frame=7)
-        n_pix = args.height * args.width
-        pipe = ShardedFramePipeline(n_pix, torch.device('cuda', local_rank))
-        rays = torch.from_numpy(np.ascontiguousarray(rays_np[pipe.lo:pipe.hi])).cuda()     # the rays generate_rays would produce
-        B = rays.shape[0]
-        model.render(rays)
-        torch.cuda.synchronize()
-
-        if args.no_graph:
-            def step():
-                tile = pipe.begin()
-                model.render(rays, out=tile)
-                return pipe.submit()
-        else:       # one hipGraph per tile buffer: a step is a graph launch + the all-gather enqueue
-            step = pipe.capture(lambda tile: model.render(rays, out=tile))
-
-        dt, windows, n_pre = headline(step)
-        # host time per frame: how long the CPU needs to enqueue a step (no synchronisation inside the loop) -- the floor a rank's
-        # frame time cannot go below however little of the frame it renders
-        torch.cuda.synchronize()
-        t_h = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        host_us = (time.perf_counter() - t_h) / args.steps * 1e6
-        torch.cuda.synchronize()
-        rgb_full = pipe.flush()
-        torch.cuda.synchronize()
-        rgb = rgb_full[pipe.lo:pipe.hi]
-        total_rays = n_pix
-        rays_per_gpu = B
-        parallelism = f'ONE {args.height}x{args.width} frame split into {world} pixel ranges, double-buffered RCCL all_gather'
+    if multi:
+        # ---- the strong window (north star's frame-ms metric): one frame split N ways.  Its yardstick is THIS job's single-GPU frame: a whole
+        # frame on one rank without any collective (every rank times its own; the slowest counts)
+        n1 = max_over_ranks(local_frames(render_frame, args.steps, args.warmup), dist)
+        s_dt, s_windows, s_pre, rgb_full, s_rays, pipe, strong_info = strong_window(model, args, dist, local_rank, headline, n1)
+        if want_strong_value:
+            dt, windows, n_pre = s_dt, s_windows, s_pre
+            rays, B = s_rays, s_rays.shape[0]
+            rgb = rgb_full[pipe.lo:pipe.hi]
+            total_rays = args.height * args.width
+            rays_per_gpu = B
+            parallelism = f'ONE {args.height}x{args.width} frame split into {world} pixel ranges, double-buffered RCCL all_gather'
+            host_us = strong_info['host_us_per_frame']
+            graph = None
+    strong = want_strong_value
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rays / (dt / args.steps) / 1e6
     # every step of one more window with its own event pair: a stall (clock dip, a neighbour's SMI poll) shows as max >> p50 in the line itself
-    series = step_series({'value_path': step}, max(args.steps, 20))
+    series = step_series({'value_path': step}, max(args.steps, 20)) if not FAKE else None
     # the fp16 split arithmetic was chosen on calibration rays: the kernels' sticky overflow bit must be clear on the rays that were timed
     # (render() checks it on the first batches and falls back to bf16x3, models.py _overflow_guard; a replayed graph cannot)
     if model.mlp_overflowed():
@@ -456,7 +563,8 @@ def main():
         'metric': 'Mrays/s (32 samples/ray), forward render of 800x800 frames',
         'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-        'dtype': 'f32 storage / accumulate; MLP GEMM operands: see mlp_gemm', 'mlp_gemm': None, 'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)',
+        'dtype': 'f32 storage / accumulate; MLP GEMM operands: see mlp_gemm', 'mlp_gemm': None,
+        'data': 'synthetic (seeded random-weight scene, dense density variant; pinhole rays)' if not FAKE else 'NONE: HR_BENCH_FAKE_RENDERER (CPU stand-in renderer over gloo; launch plumbing test, no figure means anything)',
         'windows_ms_per_step': [round(w / args.steps * 1e3, 4) for w in windows],
         'value_rule': f'median of {len(windows)} consecutive windows of exactly {args.steps} steps (each after {args.warmup} warm-up steps), wall clock, max over ranks',
         'step_ms': series,
@@ -467,8 +575,12 @@ def main():
                                 'two kernels per workspace chunk (MLP -> HBM workspace -> sample stage)'},
     }
 
+    if strong_info is not None:
+        strong_info['rccl_ranks'] = int(dist.get_world_size())
+        strong_info['backend'] = str(dist.get_backend())
+        result['strong'] = strong_info
     # ---- per-kernel timing + roofline (rank 0): the two kernels of the default path through hr_stage_*
-    if rank == 0 and not args.no_stage_timing:
+    if rank == 0 and not args.no_stage_timing and not FAKE:
         import ctypes
         from hyperreel_amd import lib as hlib
         L = hlib.load()
@@ -588,7 +700,7 @@ def main():
             result['roofline'] = dom
             result['roofline_other'] = oth
 
-    extras = rank == 0 and world == 1 and not args.no_extras
+    extras = rank == 0 and world == 1 and not args.no_extras and not FAKE and not multi
     # ---- the same frame through the other execution plan, and with the exact fp32-MFMA MLP
     if extras:
         def quick(f):
@@ -603,7 +715,10 @@ def main():
             n_redo = model.redo_count()
             result['verified_fast_path'] = {'first_pass': 'f16f8', 'second_pass': 'f16x3 over the rays listed on the device', 'rays_listed': int(n_redo),
                                             'fraction_of_frame': round(n_redo / B, 6), 'list_overflowed': bool(model.redo_overflowed()),
-                                            'band': '2.5e-6 of the scene extent (profiles/r05_band_probe.json: largest |d distance| f16f8 vs f16x3 7e-7 at extent 2)'}
+                                            'margins': {k: (round(v, 9) if isinstance(v, float) else v) for k, v in model.verify_info().items()},
+                                            'margins_what': 'hr_model_verify_info: per-model margins measured at hr_model_finalize on 4096 synthetic rays (f16f8 vs f16x3 heads through the '
+                                                            'model\'s own activations, contraction and intersection); per sample a length is at risk within band * dlen, a distance within '
+                                                            'band * dlen * amp, a point within band_q * max amp + band_off (csrc/hr_math.h HrRisk; DESIGN 3c)'}
             base3 = make('f16x3', False)
             v, ms = quick(base3)
             rgb3 = base3.model.render(rays)['rgb'].clone()
@@ -691,7 +806,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- CPU baseline (rank 0, N = 1)
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not FAKE:
         v, secs, idx, ref_rgb = cpu_baseline(cfg, ds, sd_ref, rays_np, min(args.cpu_sample, B))
         got = rgb[torch.from_numpy(idx).cuda()].cpu().numpy()
         sample = (f'{len(idx)} rays of the same frame through oracle/torch_port.py (the reference\'s algorithm on PyTorch CPU ops, fp32, '
@@ -719,6 +834,10 @@ def main():
 
     if strong:
         result['host_us_per_frame'] = round(host_us, 1)
+    if FAKE:
+        print(json.dumps(result), flush=True) if rank == 0 else None
+        dist.destroy_process_group() if multi else None
+        return
     result['grid_dtype'] = args.grid_dtype
     result['config']['launch'] = 'eager (Python -> hr_render per frame)' if args.no_graph else \
         ('hipGraph replay of this rank\'s captured render + all-gather enqueued from Python on the side stream' if strong else 'hipGraph replay of one captured frame')
@@ -732,8 +851,8 @@ def main():
                           'f16f8': 'f16 + fp8 on MFMA: x_hi*w_hi as f16, x*w_lo + x_lo*w_hi as one block-scaled fp8 K=64 product, fp32 accumulate (raw head within 2e-5 of the fp32 chain)',
                           'fp32': 'fp32 MFMA'}[prec_name]
     if model.mlp_verified():
-        result['mlp_gemm'] += ('; VERIFIED (HR_MLP_F16F8V, what auto resolves to): rays with a comparison within 2.5e-6 of the scene extent of flipping are listed on the device '
-                               'and rendered again with the f16x3 tiles by a second pass inside the same captured frame')
+        result['mlp_gemm'] += ('; VERIFIED (HR_MLP_F16F8V, what auto resolves to): rays with a comparison inside its per-model, per-sample margin of flipping (verified_fast_path.margins) '
+                               'are listed on the device and rendered again with the f16x3 tiles by a second pass inside the same captured frame')
         result['dtype'] += '; second pass f16x3'
     # ---- comparator for the north star's ">= 10x the reference PyTorch single-GPU rays/s": the same algorithm as stock
     #      PyTorch-ROCm ops on this GPU (oracle/torch_port.py on device 'cuda'; the reference itself cannot travel to the GPU

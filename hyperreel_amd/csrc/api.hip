@@ -125,6 +125,7 @@ struct hr_model {
     int n_tiles_t[HR_MAX_LAYERS] = {};
     long long* grad_fx = nullptr;        // deterministic training (HR_OPT_TRAIN_DETERMINISTIC): ONE 64-bit fixed-point buffer for every accumulator of a step
     size_t grad_fx_elems = 0;
+    HrFxUnit* fx_unit = nullptr;         // ... and THIS model's fixed-point unit of the step (hr_train.h)
     int opt_train_det = 0;
     float* tape = nullptr;               // per-sample values between the backward's phases: 8 words x tape_samples
     int64_t tape_samples = 0;
@@ -1995,6 +1996,7 @@ int hr_mlp_train_forward(hr_model* m, const float* const* weights_dev, const flo
 static void fill_train_args(const hr_model* m, HrTrainArgs& a, const float* rays, const float* head, int64_t n, int white_bg)
 {
     a.f_dist = a.f_points = a.f_weights = nullptr;
+    a.fx = nullptr;
     a = HrTrainArgs();
     a.cfg_dev = m->ucfg_dev;
     a.rays = rays;
@@ -2147,12 +2149,15 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         if (need > m->grad_fx_elems) {
             HR_HIP(hipStreamSynchronize(st));
             if (m->grad_fx) (void)hipFree(m->grad_fx);
+    if (m->fx_unit) (void)hipFree(m->fx_unit);
             m->grad_fx = nullptr; m->grad_fx_elems = 0;
             HR_HIP(hipMalloc((void**)&m->grad_fx, sizeof(long long) * need));
             m->grad_fx_elems = need;
         }
         HR_HIP(hipMemsetAsync(m->grad_fx, 0, sizeof(long long) * need, st));
+        if (!m->fx_unit) HR_HIP(hipMalloc((void**)&m->fx_unit, sizeof(HrFxUnit)));
         HrTrainArgs ad = a;
+        ad.fx = m->fx_unit;
         for (int j = 0; j < 3; ++j) {
             ad.g_a[j] = n_a[j] ? reinterpret_cast<float*>(m->grad_fx + off_a[j]) : nullptr;
             ad.g_b[j] = n_b[j] ? reinterpret_cast<float*>(m->grad_fx + off_b[j]) : nullptr;
@@ -2160,10 +2165,8 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         ad.d_basis = reinterpret_cast<float*>(m->grad_fx + off_basis);
         ad.d_color_table = n_ct ? reinterpret_cast<float*>(m->grad_fx + off_ct) : nullptr;
         hr_launch_train_det(m->cfg, &ad, sizeof(ad), st);
-        const float* fx_inv = nullptr;
-        const unsigned* fx_bad = nullptr;
-        hr_train_det_scale(&fx_inv, &fx_bad);
-        if (!fx_inv || !fx_bad) return fail(HR_E_HIP, "deterministic training: the fixed-point unit's device symbols are not available");
+        const float* fx_inv = &m->fx_unit->inv;
+        const unsigned* fx_bad = &m->fx_unit->bad;
         for (int j = 0; j < 3; ++j) {
             if (n_a[j]) hr_launch_fixed_to_float(m->grad_fx + off_a[j], m->grad_a[j], (int64_t)n_a[j], fx_inv, fx_bad, st);
             if (n_b[j]) hr_launch_fixed_to_float(m->grad_fx + off_b[j], m->grad_b[j], (int64_t)n_b[j], fx_inv, fx_bad, st);

@@ -284,9 +284,9 @@ void hr_launch_rows(const hr_config& cfg, const HrRowsArgs& args, hipStream_t st
 void hr_launch_dense_alpha(const HrMaskArgs& args, hipStream_t stream);
 void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args, hipStream_t stream);
 // the deterministic build (train_det_kernel.hip): `args_flt` is the default build's HrTrainArgs whose accumulator pointers (g_a, g_b,
-// d_basis, d_color_table) point to 64-bit fixed-point buffers of the same element counts (hr_train.h: hr_acc_t, 2^-40 units)
+// d_basis, d_color_table) point to 64-bit fixed-point buffers of the same element counts (hr_train.h: hr_acc_t; the unit is chosen per step and
+// kept in args.fx, the model's own)
 void hr_launch_train_det(const hr_config& cfg, const void* args_flt, size_t args_bytes, hipStream_t stream);
-void hr_train_det_scale(const float** inv_dev, const unsigned** bad_dev);      // device addresses of the step's unit (1 / units per 1.0) and its non-finite flag
 void hr_launch_fixed_to_float(const long long* src, float* dst, int64_t n, const float* inv_dev, const unsigned* bad_dev, hipStream_t stream);   // dst[i] = src[i] * *inv_dev (NaN if *bad_dev)
 void hr_launch_features(const hr_config* cfg_dev, const float* rays, int64_t n, float* out, hipStream_t stream);
 // training GEMMs of the MLP (train_gemm_kernel.hip)

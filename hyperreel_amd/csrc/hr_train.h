@@ -32,17 +32,28 @@
 // are converted to float once, after the last add.  The unit is a power of two chosen PER STEP from the step's largest |dL/d rgb|
 // (hr_fx_scale_kernel: max |d_rgb| = 2^32 units): every gradient is linear in d_rgb, so a contribution 2^-32 of the largest still has its
 // leading bit and a sum may reach 2^31 times the largest -- a fixed 2^-40 unit (round 4) dropped most bits of late-training gradients
-// (d_rgb = 2 err / 3B ~ 1e-10).  A non-finite contribution raises hr_fx_bad and the step's totals convert to NaN (the fp32 path
-// would have produced inf / NaN there; __float2ll_rn alone turns NaN into 0).
+// (d_rgb = 2 err / 3B ~ 1e-10).  A non-finite contribution, or one beyond 2^62 units, raises the unit's `bad` word and the step's
+// totals convert to NaN (the fp32 path would have produced inf / NaN or a huge value there; __float2ll_rn alone turns NaN into 0 and
+// saturates silently).
+// The unit {units per 1.0, its inverse, the step's non-finite flag} lives in a small PER-MODEL device buffer (HrTrainArgs::fx, allocated next
+// to the model's fixed-point accumulators; ADVICE r5: module-global __device__ variables were shared by every model and stream of the
+// process -- two models training deterministically at once converted with each other's units).  hr_fx_scale_kernel writes it at the start
+// of every step; every accumulating kernel copies it into the workgroup's LDS on entry (HR_FX_ENTER), where the macros below find it.
+struct HrFxUnit { float one, inv; unsigned bad, pad_; };
 #if defined(__HIPCC__) && defined(HR_TRAIN_DET)
 typedef long long hr_acc_t;
-__device__ float hr_fx_one = 1099511627776.0f;      // units per 1.0, a power of two (set per step)
-__device__ float hr_fx_inv = 1.0f / 1099511627776.0f;
-__device__ unsigned hr_fx_bad = 0u;
+__shared__ float hr_fx_one;            // units per 1.0, a power of two (this step's, this model's)
+__shared__ float hr_fx_inv;
+__shared__ unsigned* hr_fx_bad_p;
+#define HR_FX_ENTER(a) do { if (threadIdx.x == 0) { hr_fx_one = (a).fx->one; hr_fx_inv = (a).fx->inv; hr_fx_bad_p = &(a).fx->bad; } __syncthreads(); } while (0)
 __device__ __forceinline__ long long hr_to_fixed(float v)
 {
-    if (!(fabsf(v) <= 3.0e38f)) hr_fx_bad = 1u;     // NaN or infinity (a plain store of the same value from any lane: no atomic needed)
-    return __float2ll_rn(v * hr_fx_one);
+    const float u = v * hr_fx_one;
+    // NaN, infinity, or a contribution beyond the accumulator's range (a pathological Jacobian: __float2ll_rn would saturate silently and the
+    // integer sum could wrap) -- the fp32 path would hold inf / NaN or a huge value there: the step's totals convert to NaN.  (A plain store of
+    // the same value from any lane: no atomic needed.)
+    if (!(fabsf(u) < 4.6e18f)) *hr_fx_bad_p = 1u;                 // 2^62
+    return __float2ll_rn(u);
 }
 #define HR_ACC_VALUE(x) ((float)((double)(x) * (double)hr_fx_inv))
 #define HR_ATOMIC_ADD(p, v) (void)atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)hr_to_fixed(v))
@@ -51,6 +62,7 @@ __device__ __forceinline__ long long hr_to_fixed(float v)
 #define HR_ACC_ZERO 0ll
 #elif defined(__HIPCC__)
 typedef float hr_acc_t;
+#define HR_FX_ENTER(a) do {} while (0)
 #define HR_ACC_VALUE(x) (x)
 #define HR_ACC_ZERO 0.0f
 #define HR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
@@ -60,6 +72,7 @@ typedef float hr_acc_t;
 #define HR_ATOMIC_ADD_RAY(p, v) (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #else
 typedef float hr_acc_t;
+#define HR_FX_ENTER(a) do {} while (0)
 #define HR_ACC_VALUE(x) (x)
 #define HR_ACC_ZERO 0.0f
 #define HR_ATOMIC_ADD(p, v) (*(p) += (v))
@@ -135,6 +148,7 @@ struct HrTrainArgs {
     float* f_dist;              // (n, Z) final (contracted) distances
     float* f_points;            // (n, Z, 3)
     float* f_weights;           // (n, Z) render weights
+    HrFxUnit* fx;               // deterministic build: this model's fixed-point unit for the step (NULL in the default build)
 };
 
 // d/dx of hr_apply_act

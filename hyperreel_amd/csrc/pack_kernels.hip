@@ -343,7 +343,7 @@ void hr_launch_blend_rows(const float* b, float* line, int row_floats, int i0, i
     hipLaunchKernelGGL(hr_blend_rows_kernel, dim3((unsigned)((row_floats + 255) / 256)), dim3(256), 0, stream, b, line, row_floats, i0, i1, w0, w1);
 }
 
-// 64-bit fixed-point gradient totals of the deterministic training build (hr_train.h: 2^-40 units) -> float, once, after the last add
+// 64-bit fixed-point gradient totals of the deterministic training build (hr_train.h: the step's unit, kept per model) -> float, once, after the last add
 __global__ __launch_bounds__(256) void hr_fixed_to_float_kernel(const long long* __restrict__ src, float* __restrict__ dst, int64_t n,
                                                                  const float* __restrict__ inv_dev, const unsigned* __restrict__ bad_dev)
 {

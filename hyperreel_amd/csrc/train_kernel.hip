@@ -33,6 +33,7 @@ namespace hr_det {
 template <int ZP>
 __global__ __launch_bounds__(64) void hr_train_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
+    HR_FX_ENTER(a);
     if (threadIdx.x >= HR_TRAIN_RPW) return;
     const int64_t ray = (int64_t)blockIdx.x * HR_TRAIN_RPW + threadIdx.x;
     if (ray >= a.n_rays) return;
@@ -67,6 +68,7 @@ template <int ZP, int NB, int PC>
 __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
     static_assert(ZP <= 64, "a ray inside one wavefront");
+    HR_FX_ENTER(a);
     const hr_config& c = *cfgp;
     constexpr int RPB = 256 / ZP;
     extern __shared__ float lds[];                 // [RPB][3 * CA] decode matrices
@@ -344,6 +346,7 @@ __device__ __forceinline__ int hr_train_basis_rows(const hr_config& c) { return 
 template <int ZP>
 __global__ __launch_bounds__(256, 4) void hr_train_gather_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
+    HR_FX_ENTER(a);
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 256 / HR_TRAIN_LPS;
     constexpr int RPB = (ZP >= GROUPS) ? 1 : GROUPS / ZP;
@@ -522,6 +525,7 @@ __device__ __forceinline__ void hr_bwd_class_sample(const hr_config& c, const Hr
 template <int ZP, bool KEYED, int PC>
 __global__ __launch_bounds__(1024) void hr_train_gather_bwd_lines_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a, const unsigned pairs, const int add_dp)
 {
+    HR_FX_ENTER(a);
     const hr_config& c = *cfgp;
     constexpr int GROUPS = 1024 / HR_TRAIN_LPS;
     constexpr int RPB = HR_TRAIN_LINES_RPB(ZP);
@@ -766,6 +770,7 @@ static bool hr_launch_gather_bwd_lines(const hr_config& cfg, const HrTrainArgs& 
 // Tail of phase B (taps path): one thread per sorted sample
 __global__ __launch_bounds__(256) void hr_train_point_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
+    HR_FX_ENTER(a);
     const hr_config& c = *cfgp;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= a.n_rays * c.z_channels) return;
@@ -775,6 +780,7 @@ __global__ __launch_bounds__(256) void hr_train_point_bwd_kernel(const hr_config
 // Phase C
 __global__ __launch_bounds__(256) void hr_train_dist_bwd_kernel(const hr_config* __restrict__ cfgp, const HrTrainArgs a)
 {
+    HR_FX_ENTER(a);
     const hr_config& c = *cfgp;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= a.n_rays * c.z_channels) return;
@@ -834,8 +840,9 @@ void hr_launch_train(const hr_config& cfg, const HrTrainArgs& args_in, hipStream
 }
 
 #ifdef HR_TRAIN_DET
-// the step's fixed-point unit: max |d_rgb| -> 2^32 units (hr_train.h); one workgroup, before the step's first accumulating kernel
-__global__ __launch_bounds__(1024) void hr_fx_scale_kernel(const float* __restrict__ d_rgb, int64_t n)
+// the step's fixed-point unit: max |d_rgb| -> 2^32 units (hr_train.h); one workgroup, before the step's first accumulating kernel.  ALWAYS
+// run (n = 0 without a d_rgb): the flag of the step before must not leak into this one
+__global__ __launch_bounds__(1024) void hr_fx_scale_kernel(const float* __restrict__ d_rgb, int64_t n, HrFxUnit* __restrict__ fx)
 {
     __shared__ float s_max[16];
     __shared__ unsigned s_bad;
@@ -857,9 +864,9 @@ __global__ __launch_bounds__(1024) void hr_fx_scale_kernel(const float* __restri
         if (mx > 0.0f) (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
         int sh = 32 - e;                                // mx * 2^sh in [2^31, 2^32)
         sh = sh < -60 ? -60 : (sh > 120 ? 120 : sh);
-        hr_fx_one = ldexpf(1.0f, sh);
-        hr_fx_inv = ldexpf(1.0f, -sh);
-        hr_fx_bad = s_bad;
+        fx->one = ldexpf(1.0f, sh);
+        fx->inv = ldexpf(1.0f, -sh);
+        fx->bad = s_bad;
     }
 }
 }   // namespace hr_det
@@ -867,17 +874,11 @@ __global__ __launch_bounds__(1024) void hr_fx_scale_kernel(const float* __restri
 void hr_launch_train_det(const hr_config& cfg, const void* args_flt, size_t args_bytes, hipStream_t stream)
 {
     hr_det::HrTrainArgs a;
-    if (args_bytes != sizeof(a)) return;
+    if (args_bytes != sizeof(a) || !reinterpret_cast<const hr_det::HrTrainArgs*>(args_flt)->fx) return;
     memcpy(&a, args_flt, sizeof(a));
-    if (a.d_rgb && a.n_rays > 0) hipLaunchKernelGGL(hr_det::hr_fx_scale_kernel, dim3(1), dim3(1024), 0, stream, a.d_rgb, a.n_rays * 3);
+    const bool have = a.d_rgb && a.n_rays > 0;
+    hipLaunchKernelGGL(hr_det::hr_fx_scale_kernel, dim3(1), dim3(1024), 0, stream, have ? a.d_rgb : nullptr, have ? a.n_rays * 3 : 0, a.fx);
     hr_det::hr_launch_train_impl(cfg, a, stream);
-}
-// where the step's unit and its non-finite flag live (device addresses): hr_launch_fixed_to_float reads them
-void hr_train_det_scale(const float** inv_dev, const unsigned** bad_dev)
-{
-    void* p = nullptr;
-    *inv_dev = (hipGetSymbolAddress(&p, HIP_SYMBOL(hr_det::hr_fx_inv)) == hipSuccess) ? static_cast<const float*>(p) : nullptr;
-    *bad_dev = (hipGetSymbolAddress(&p, HIP_SYMBOL(hr_det::hr_fx_bad)) == hipSuccess) ? static_cast<const unsigned*>(p) : nullptr;
 }
 #else
 // Coarse level of a point_prediction cascade (hr_ray_rows ... in hr_train.h): rows forward per ray, then per sample the

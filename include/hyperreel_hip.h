@@ -315,7 +315,9 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  *                         head workspace traffic, measured as fast as or slower than two kernels (hence not part of 1).
  *   HR_OPT_SAMPLE_WAVES   sample wavefronts per workgroup of the frame kernel: 4 or 8 (0: the plan's default, 8).
  *   HR_OPT_TRAIN_DETERMINISTIC  1: hr_train_backward accumulates every gradient that many samples add to -- texel gradients, basis_mat's,
- *                         the colour table's -- as 64-bit fixed point (2^-40 units) with integer atomics instead of fp32 atomics: the
+ *                         the colour table's -- as 64-bit fixed point with integer atomics instead of fp32 atomics (the unit is a power of two
+ *                         chosen per step: the step's largest |dL/d rgb| = 2^32 units; a non-finite contribution, or one beyond 2^62 units,
+ *                         turns the step's totals into NaN, as the fp32 path would hold inf / NaN there): the
  *                         result does not depend on the order of the adds, so two runs of the same step agree bit for bit (the
  *                         reference's loop, nlf/__init__.py:634-709, is deterministic for a given thread count).  The values agree
  *                         with the default mode's to fp32 rounding of the sums; slower (no LDS staging of the contended lines).

@@ -644,3 +644,55 @@ def test_backward_writes_every_gradient_element(case):
         assert (ga is None) == (gb is None)
         if ga is not None:
             assert torch.isfinite(gb).all() and torch.equal(ga, gb)
+
+
+def test_two_models_training_deterministically_on_two_streams_keep_their_own_units():
+    """the per-step fixed-point unit used to live in module-global device variables -- two models (or two streams) in the
+    deterministic mode converted with each other's units.  Now it is the model's own buffer: model A with |dL/d rgb| ~ 1e-7 and model B with
+    ~ 3e4, stepping at the same time on two streams, get the gradients each gets alone, bit for bit; and a non-finite step of B does not
+    turn A's totals into NaN."""
+    from gpu_common import make_render_fn
+    g = Golden('donerf_sphere_small')
+    rays = torch.from_numpy(np.ascontiguousarray(np.concatenate([g.rays] * 8, 0), np.float32)).cuda()
+    rng = np.random.default_rng(5)
+    GA = torch.from_numpy((rng.standard_normal((rays.shape[0], 3)) * 1e-7).astype(np.float32)).cuda()
+    GB = torch.from_numpy((rng.standard_normal((rays.shape[0], 3)) * 3e4).astype(np.float32)).cuda()
+    GBad = GB.clone()
+    GBad[3, 0] = float('nan')
+
+    def make():
+        fn = make_render_fn(g.cfg, g.dataset, g.state_dict)
+        fn.model.set_train_deterministic(True)
+        fn.train()
+        return fn
+
+    def step(fn, G):
+        fn.zero_grad()
+        (fn.model.forward_train(rays, white_bg=False) * G).sum().backward()
+
+    def grads(fn):
+        return {n: p.grad.detach().clone() for n, p in fn.named_parameters() if p.grad is not None and p.grad.numel()}
+
+    a, b = make(), make()
+    step(a, GA); step(b, GB)
+    torch.cuda.synchronize()
+    alone_a, alone_b = grads(a), grads(b)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rnd in range(12):
+        for s in (sa, sb):
+            s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sa):
+            step(a, GA)
+        with torch.cuda.stream(sb):
+            step(b, GBad if rnd % 3 == 2 else GB)
+        torch.cuda.current_stream().wait_stream(sa)
+        torch.cuda.current_stream().wait_stream(sb)
+        torch.cuda.synchronize()
+        ga, gb = grads(a), grads(b)
+        for n in alone_a:
+            assert torch.equal(ga[n], alone_a[n]), (rnd, n)
+        if rnd % 3 == 2:
+            assert all(bool(torch.isnan(gb[n]).all()) for n in gb if 'plane' in n or 'line' in n)
+        else:
+            for n in alone_b:
+                assert torch.equal(gb[n], alone_b[n]), (rnd, n)
