@@ -905,7 +905,16 @@ def main():
         except Exception as e:
             result['train_step'] = {'error': repr(e)}
 
+    if multi:
+        dist.barrier()
     if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe buffers until the process exits -- i.e. AFTER this line, unless it is
+        # flushed first.  The JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
         print(json.dumps(result), flush=True)
     if multi:
         dist.destroy_process_group()

@@ -176,6 +176,9 @@ int validate(const hr_config& c, bool coarse = false)
     if (c.mlp_layers != 0) {   // 0: ZeroMLP (nlf/nets/mlp.py:14-33), the head is all zeros and samples sit on their anchors
         if (c.mlp_hidden != 64 && c.mlp_hidden != 128 && c.mlp_hidden != 256)
             return fail(HR_E_INVALID, "mlp_hidden must be 64, 128 or 256 (got %d)", c.mlp_hidden);
+        // nn.LeakyReLU(0.01) (nlf/nets/mlp.py:149-154).  The split kernels evaluate it as max(v, slope v), which is the same function for a slope in [0, 1]
+        if (!(c.leaky_slope >= 0.0f && c.leaky_slope <= 1.0f))
+            return fail(HR_E_INVALID, "leaky_slope must be in [0, 1] (got %g)", (double)c.leaky_slope);
         if (c.mlp_layers < 2 || c.mlp_layers > HR_MAX_LAYERS) return fail(HR_E_INVALID, "mlp_layers must be 0 or in [2,%d]", HR_MAX_LAYERS);
         if (c.mlp_in < 1 || c.mlp_in > HR_MAX_MLP_IN) return fail(HR_E_INVALID, "mlp_in must be in [1,%d]", HR_MAX_MLP_IN);
         if (c.mlp_skip_mask & 1) return fail(HR_E_INVALID, "layer 0 cannot be a skip layer");
@@ -650,7 +653,9 @@ static int pack_mlp_as(hr_model* m, const int precision, const HrPackOut o)
         }
         const int nb = nt * tile_n;
         std::vector<float> bp(nb, 0.0f);
-        for (int i = 0; i < N; ++i) bp[i] = b[last ? (i / P_live) * P_user + live_cols[i % P_live] : i];
+        // split kernels: the accumulators START from the bias (mlp_split_core.inc, hr_acc_init_bias), in the accumulator's unit: b * 2^s (exact;
+        // 1 for bf16 halves and for the exact-fp32 kernel, which adds its bias in the epilogue)
+        for (int i = 0; i < N; ++i) bp[i] = b[last ? (i / P_live) * P_user + live_cols[i % P_live] : i] * wmul;
         HR_HIP(hipMalloc((void**)&o.bias[l], nb * sizeof(float)));
         HR_HIP(hipMemcpy(o.bias[l], bp.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         o.n_tiles[l] = nt;
