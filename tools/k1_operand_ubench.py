@@ -28,6 +28,7 @@ def child(lib):
     from hyperreel_amd import lib as hl
     if lib != 'product':
         hl.LIB_PATH = os.path.join(ROOT, 'tools', '_bin', f'libhr_{lib}.so')
+        assert os.path.exists(hl.LIB_PATH), hl.LIB_PATH
     from hyperreel_amd import config as C, scenes
     from hyperreel_amd.render import build_render_fn
     cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf_sphere')
