@@ -84,7 +84,7 @@ struct hr_model {
     int* redo_list = nullptr;            // the second pass's rays
     int* wide_list = nullptr;            // the third pass's rays
     unsigned* redo_count = nullptr;      // [0] second-pass counter, [1] its copy, [2] third-pass counter, [3] its copy
-    int redo_cap = 0;                    // entries the list holds (hr_model_reserve); a call uses max(65 536, n_rays / 8) of them
+    int redo_cap = 0;                    // entries the list holds (hr_model_reserve); a call uses max(32 768, n_rays / 16) of them
     int wide_cap = 0;
     float redo_band = 0.0f;              // the margins of THIS model (calibrate_band; hr_math.h HrRisk): of zc,
     float redo_band_q = 0.0f;            //   of a point coordinate per unit of amplification,
@@ -676,6 +676,7 @@ static void free_safe_pack(hr_model* m)
 }
 
 static const float HR_BAND_FLOOR = 1e-6f;
+static const float HR_VERIFY_LISTED_LIMIT = 0.05f; // fraction of the calibration rays the first pass may list (a call's list holds a sixteenth of its rays)
 static const float HR_VERIFY_RGB_LIMIT = 6e-5f;   // on <= 65 536 calibration rays; the shipped families measure 1.5e-5 - 5e-5 here and 2.3e-5 - 5.4e-5 on their 640 000-ray frames
 static const float HR_VERIFY_AMP_CUT = 2.0f;      // a ray with a live sample beyond it (60 degrees off a plane's normal; a sphere nearly tangent) is not what the margins
                                                   // are measured on -- its errors are the geometry's, the MLP's two-plane / Pluecker inputs included -- and is always listed
@@ -1064,7 +1065,7 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk)
     }
     m->chunk = rays_per_chunk;
     // verified fast path: the list of rays the second pass renders again.  The buffer holds 4 M entries (16 MB); a call uses
-    // max(65 536, n_rays / 8) of them (measured: 0.05 - 3 % of a frame's rays are listed; the calibration gives the fast path up above 10 %)
+    // max(32 768, n_rays / 16) of them (measured: 0.01 - 2.5 % of a frame's rays are listed; the calibration gives the fast path up above 5 %)
     // and walks them in slices of the chunk's head workspace.  Beyond that the kernels raise bit 2 of the status word (HR_OPT_REDO_OVERFLOW)
     free_dev(reinterpret_cast<float*&>(m->redo_list));
     free_dev(reinterpret_cast<float*&>(m->wide_list));
@@ -1324,10 +1325,12 @@ static void render_verified(hr_model* m, const float* rays_dev, int64_t n_rays, 
     hr_launch_samples(m->kcfg, sa, st);
 }
 
-// entries of the ray list one hr_render call may fill: an eighth of its rays, at least 65 536 (never more than the rays there are, or the buffer)
+// entries of the ray list one hr_render call may fill: a sixteenth of its rays, at least 32 768 (never more than the rays there are, or the buffer).
+// The second pass's launches are sized for it -- ~1.7 ns per workgroup that finds nothing to do -- and the calibration gives the fast path up
+// above a twentieth (HR_VERIFY_LISTED_LIMIT)
 static int redo_list_cap(const hr_model* m, int64_t n_rays)
 {
-    int64_t cap = n_rays / 8 > 65536 ? n_rays / 8 : 65536;
+    int64_t cap = n_rays / 16 > 32768 ? n_rays / 16 : 32768;
     cap = (cap + 63) & ~(int64_t)63;
     if (cap > n_rays) cap = (n_rays + 63) & ~(int64_t)63;
     return (int)(cap < m->redo_cap ? cap : m->redo_cap);
@@ -1337,7 +1340,7 @@ static int redo_list_cap(const hr_model* m, int64_t n_rays)
 // model's own activations, anchors, contraction and intersection by the probe kernel (band_kernel.hip) in the normalisation the sample
 // stage's per-sample margins use (hr_math.h, HrRisk); margin = 4 x the largest difference, never below HR_BAND_FLOOR.  Then the
 // well-conditioned calibration rays once through the verified path and once through the f16x3 tiles: the fraction listed, and how far the
-// two images are apart.  HR_MLP_AUTO gives the fast path up (f16x3 throughout) above 10 % / 6e-5.  Synchronises `st`.
+// two images are apart.  HR_MLP_AUTO gives the fast path up (f16x3 throughout) above 5 % / 6e-5.  Synchronises `st`.
 static int calibrate_band(hr_model* m, hipStream_t st)
 {
     m->band_stale = false;
@@ -1471,14 +1474,14 @@ static int calibrate_band(hr_model* m, hipStream_t st)
     // the CALLER's rays are what will be rendered: the ill-conditioned ones among them are listed too (synthetic rays point anywhere;
     // half of them graze a z-plane net's planes, which says nothing about its cameras)
     if (m->calibrated == 2) vi.listed_frac = (float)(((double)(N - nu) + (double)vi.listed_frac * (double)nu) / (double)N);
-    too_many = vi.listed_frac > 0.10f;
+    too_many = vi.listed_frac > HR_VERIFY_LISTED_LIMIT;
     HR_BAND_HIP(hipMemsetAsync(m->redo_count, 0, 4 * sizeof(unsigned), st));
     HR_BAND_HIP(hipMemsetAsync(m->flags, 0, sizeof(unsigned), st));        // range bits the calibration rays raised are not the caller's
     HR_BAND_HIP(hipStreamSynchronize(st));
 #undef HR_BAND_HIP
     cleanup();
     if ((too_many || too_far) && m->cfg.mlp_precision == HR_MLP_AUTO) {
-        // more than a tenth of the rays would be rendered twice (a call's list holds an eighth), or the cheap arithmetic's own error is
+        // more than a twentieth of the rays would be rendered twice (a call's list holds a sixteenth), or the cheap arithmetic's own error is
         // too large a share of the 1e-4 budget on this model: plain f16x3 lists nothing and has neither problem
         m->verified = 0;
         m->active_precision = HR_MLP_F16X3;

@@ -658,7 +658,7 @@ class HipLightfieldModel(nn.Module):
         return self._get_option(_lib.HR_OPT_WIDE_COUNT)
 
     def redo_overflowed(self):
-        """Sticky: a render() listed more rays than a call's list holds (max(65536, B / 8)); the excess kept their first-pass pixels
+        """Sticky: a render() listed more rays than a call's list holds (max(32768, B / 16)); the excess kept their first-pass pixels
         (_overflow_guard then re-decides the arithmetic on those rays and renders the batch again)."""
         return bool(self._get_option(_lib.HR_OPT_REDO_OVERFLOW))
 
@@ -791,12 +791,12 @@ class HipLightfieldModel(nn.Module):
                 self.native()
             return True
         if active == 5 and self.mlp_verified() and self.redo_overflowed():
-            # verified fast path: more than an eighth of the batch had a comparison inside the band -- rays unlike the calibration's (which
-            # gives the fast path up above a tenth).  The excess kept their unverified pixels: measure the band on THESE rays (the library
+            # verified fast path: more than a sixteenth of the batch had a comparison inside its margin -- rays unlike the calibration's (which
+            # gives the fast path up above a twentieth).  The excess kept their unverified pixels: measure the band on THESE rays (the library
             # falls back to f16x3 when they list too many) and render again; a model that still overflows leaves the fast path for good
             warnings.warn('hyperreel_amd: the verified fast path listed more rays than a call holds; re-calibrating on these rays and rendering the batch again')
             self.calibrate(rays)
-            if self.mlp_verified() and self.verify_info()['listed_frac'] > 0.10:
+            if self.mlp_verified() and self.verify_info()['listed_frac'] > 0.05:
                 self.mlp_precision = 'f16x3'
                 self._native_key = None
                 self.native()

@@ -121,7 +121,7 @@ enum { HR_MLP_FP32 = 0, HR_MLP_BF16X3 = 1, HR_MLP_F16X3 = 2, HR_MLP_F16X2 = 3,
         * of a frame) again with F16X3's tiles.  The band is PER MODEL and PER SAMPLE: hr_model_finalize / hr_model_calibrate run the MLP in both
         * arithmetics on the calibration rays and measure how far the length fed to the intersection moves; the sample kernel pushes 4x that through
         * the derivatives of the inverse contraction and of the intersection of each sample (hr_verify_info below; csrc/hr_math.h, HrRisk).
-        * Under HR_MLP_AUTO a model whose margins would list more than 10 % of the calibration rays, or whose calibration image differs from
+        * Under HR_MLP_AUTO a model whose margins would list more than 5 % of the calibration rays, or whose calibration image differs from
         * F16X3's by more than 6e-5 anywhere, is rendered with F16X3 throughout instead; so are intersections the margins are not derived for
         * (the `_new` primitives, the deformable grid, learned sphere origins, DoNeRFContract).  Both passes are ordinary launches on the caller's stream: capturable.  hr_render_fields with diagnostics,
         * and models with an occupancy volume set (its cell test is a head-dependent decision the band does not cover), render everything with the
@@ -331,7 +331,7 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * overflows -- hr_model_calibrate on such rays moves the exponents and clears the bit.
  * HR_OPT_MLP_VERIFIED 1 when hr_render runs the verified fast path (HR_MLP_F16F8V); HR_OPT_REDO_COUNT the number of rays the last hr_render listed
  * for its second pass (reading it synchronises the device); HR_OPT_REDO_OVERFLOW the sticky bit raised when a call listed more rays than the
- * list holds -- max(65 536, n_rays / 8) per call, i.e. more than 12.5 % of a large call's rays at risk, which the calibration's 10 % rule
+ * list holds -- max(32 768, n_rays / 16) per call, i.e. more than 6.25 % of a large call's rays at risk, which the calibration's 5 % rule
  * makes a property of rays unlike the calibration's: the excess rays keep their first-pass pixels.  A caller that renders without
  * hyperreel_amd's host guard polls this bit (hr_model_calibrate on such rays re-decides; HR_MLP_F16X3 never lists).
  * HR_OPT_WIDE_COUNT: rays the last hr_render passed on to the THIRD pass (bf16x3 tiles: halves with the fp32 exponent range) because an activation of
@@ -353,7 +353,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
  * band * dlen * amp, a point coordinate within band_q * (largest amp of the ray) + band_off. */
 typedef struct hr_verify_info {
     int32_t verified;            /* 1: hr_render runs the verified fast path */
-    int32_t fallback;            /* HR_MLP_AUTO gave the fast path up for this model (it renders F16X3): 1 = `listed_frac` exceeded 0.10,
+    int32_t fallback;            /* HR_MLP_AUTO gave the fast path up for this model (it renders F16X3): 1 = `listed_frac` exceeded 0.05,
                                   * 2 = `max_d_rgb` exceeded 6e-5 (the cheap arithmetic's own error is too large on these weights) */
     float band;                  /* margin of zc: max(band_floor, 4 * max(max_d_zc, max_d_dist_n)) */
     float band_q;                /* margin of a point coordinate per unit of amplification: max(band_floor, 4 * max_d_geo_n) */
