@@ -974,7 +974,9 @@ int hr_model_finalize(hr_model* m)
         const int64_t nq = ((int64_t)m->n_out + 3) / 4;
         int64_t rays = (256ll << 20) / (nq * 16 * rows_per_ray(m->cfg));
         if (rays >= 16384) rays &= ~(int64_t)16383;
-        rays = rays > 131072 ? 131072 : (rays < 4096 ? 4096 : rays);
+        // (163 840 = 231 MB of DoNeRF head: the largest that still sits in the cache next to the grids' hot lines -- and with hr_render's even split
+        //  an 800x800 frame is 4 launches of 160 000 rays instead of 4 x 131 072 + 115 712: 1.717 vs 1.729 ms, profiles/r06_chunk_sweep.txt; 213 376: 1.824)
+        rays = rays > 163840 ? 163840 : (rays < 4096 ? 4096 : rays);
         const int rc = hr_model_reserve(m, rays);
         if (rc != HR_OK) return rc;
     }
@@ -1257,14 +1259,25 @@ static int check_render(const hr_model* m, const float* rays, int64_t n, const f
     return HR_OK;
 }
 
+// rays per launch of a call of n rays: as many launches as the workspace demands, of equal size (a short last launch leaves the chip half empty
+// for a whole kernel)
+static int64_t even_chunk(const hr_model* m, int64_t n)
+{
+    if (n <= m->chunk) return m->chunk;
+    const int64_t k = (n + m->chunk - 1) / m->chunk;
+    const int64_t per = (((n + k - 1) / k) + 63) & ~(int64_t)63;
+    return per < m->chunk ? per : m->chunk;
+}
+
 // The verified fast path over one call's rays: first pass in f16f8 with the rays at risk listed on the device, then the list
 // again with the f16x3 tiles (in slices of the chunk's head workspace), then whatever left the half range there with the bf16x3 tiles.
 // list_cap: entries of the list this call may use.
 static void render_verified(hr_model* m, const float* rays_dev, int64_t n_rays, float* rgb_dev, int list_cap, hipStream_t st)
 {
     const hr_config& c = m->cfg;
-    for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
-        const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
+    const int64_t per = even_chunk(m, n_rays);
+    for (int64_t r0 = 0; r0 < n_rays; r0 += per) {
+        const int64_t n = (n_rays - r0 < per) ? (n_rays - r0) : per;
         const float* rays = rays_dev + r0 * c.ray_dim;
         HrMlpArgs ma;
         fill_mlp_args(m, ma, rays, n, 0);
@@ -1542,8 +1555,9 @@ int hr_render_fields(hr_model* m, const float* rays_dev, int64_t n_rays, float* 
         return HR_OK;
     }
     const bool safe_all = m->verified != 0;
-    for (int64_t r0 = 0; r0 < n_rays; r0 += m->chunk) {
-        const int64_t n = (n_rays - r0 < m->chunk) ? (n_rays - r0) : m->chunk;
+    const int64_t per = even_chunk(m, n_rays);
+    for (int64_t r0 = 0; r0 < n_rays; r0 += per) {
+        const int64_t n = (n_rays - r0 < per) ? (n_rays - r0) : per;
         const float* rays = rays_dev + r0 * c.ray_dim;
         launch_front(m, rays, n, st, -1, safe_all ? 1 : 0);
         HrSampleArgs sa;
@@ -2157,7 +2171,6 @@ int hr_train_backward(hr_model* m, const float* rays_dev, const float* head_dev,
         if (need > m->grad_fx_elems) {
             HR_HIP(hipStreamSynchronize(st));
             if (m->grad_fx) (void)hipFree(m->grad_fx);
-    if (m->fx_unit) (void)hipFree(m->fx_unit);
             m->grad_fx = nullptr; m->grad_fx_elems = 0;
             HR_HIP(hipMalloc((void**)&m->grad_fx, sizeof(long long) * need));
             m->grad_fx_elems = need;
@@ -2307,6 +2320,7 @@ void hr_model_destroy(hr_model* m)
         free_dev(m->bias[l]);
     }
     free_safe_pack(m);
+    free_dev(m->calib_rays);
     free_dev(reinterpret_cast<float*&>(m->redo_list));
     free_dev(reinterpret_cast<float*&>(m->wide_list));
     free_dev(reinterpret_cast<float*&>(m->redo_count));
@@ -2328,6 +2342,7 @@ void hr_model_destroy(hr_model* m)
     for (int j = 0; j < 3; ++j) { m->grad_a[j] = m->grad_b[j] = nullptr; free_dev(m->frame_line[j]); }
     free_dev(m->tape);
     if (m->grad_fx) (void)hipFree(m->grad_fx);
+    if (m->fx_unit) (void)hipFree(m->fx_unit);
     for (int l = 0; l < HR_MAX_LAYERS; ++l) {          // the training forward's per-step weight tiles (hr_mlp_train_forward)
         if (m->wsplit_t[l]) (void)hipFree(m->wsplit_t[l]);
         m->wsplit_t[l] = nullptr;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence on the GPU box (-> gpurun_out/r06_*; the summaries are then copied to profiles/):
 #   PMC passes of the two kernels of the default plan (plain f16f8: the verified path's first pass without its list-driven launches, so that
-#   per-dispatch averages are per 131 072-ray launch), the counters JSON bench.py quotes, rocprofv3 kernel-trace stats of the driver's command,
+#   per-dispatch averages are per 160 000-ray launch), the counters JSON bench.py quotes, rocprofv3 kernel-trace stats of the driver's command,
 #   the bench line itself (driver command, three times), Neural-3D's counters.
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
@@ -10,9 +10,9 @@ export TMPDIR=/tmp PYTHONUNBUFFERED=1
 mkdir -p gpurun_out
 P="--prewarm 0 --windows 1"
 bash tools/pmc.sh ${T}_f16f8 $P --mlp-precision f16f8 > /dev/null 2>&1
-python tools/make_counters.py ${T}_f16f8 gpurun_out/r06_counters.json donerf_sphere f16f8 fp32 131072 600 600 600 > gpurun_out/r06_${T}_counters_summary.txt
+python tools/make_counters.py ${T}_f16f8 gpurun_out/r06_counters.json donerf_sphere f16f8 fp32 160000 600 600 600 > gpurun_out/r06_${T}_counters_summary.txt
 bash tools/pmc.sh ${T}_neural3d $P --mlp-precision f16f8 --model neural_3d_z_plane > /dev/null 2>&1
-python tools/make_counters.py ${T}_neural3d gpurun_out/r06_counters_neural_3d_z_plane.json neural_3d_z_plane f16f8 fp32 65536 823 617 514 >> gpurun_out/r06_${T}_counters_summary.txt
+python tools/make_counters.py ${T}_neural3d gpurun_out/r06_counters_neural_3d_z_plane.json neural_3d_z_plane f16f8 fp32 64000 823 617 514 >> gpurun_out/r06_${T}_counters_summary.txt
 for i in 1 2 3 4 5; do for c in f16f8 neural3d; do [ -f gpurun_out/pmc_${T}_${c}_$i.txt ] && cp gpurun_out/pmc_${T}_${c}_$i.txt gpurun_out/r06_${T}_${c}_pmc_pass$i.txt; done; done
 cp gpurun_out/r06_counters.json profiles/r06_counters.json      # so that this run's bench line quotes them
 for i in 1 2 3; do timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r06_${T}_bench_$i.json; done
