@@ -1,0 +1,8 @@
+#!/bin/bash
+# same-lease A/B of whole-library builds on the headline frame: tools/ab_lib.sh <lib or "product"> ...   (three interleaved rounds)
+for r in 1 2 3; do for l in "$@"; do
+  if [ "$l" = product ]; then a=""; else a="--lib $l"; fi
+  python bench.py --steps 20 --warmup 5 --no-extras --cpu-sample 0 $a 2>/dev/null | grep "^{" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$l', d['value'], d['ms_per_step'], d['stage_ms'])"
+done; done
