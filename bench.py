@@ -586,7 +586,7 @@ def main():
         L = hlib.load()
         h = model.native()
         # rays per launch, as hr_render splits a call: as many launches as the workspace (163 840 rays by default) demands, of equal size
-        cap = args.chunk or 163840
+        cap = model.chunk_rays()
         n_launch = -(-B // cap)
         chunk = min(cap, (-(-B // n_launch) + 63) & ~63)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -410,7 +410,7 @@ static int create_level(const hr_config* cfg, bool coarse, hr_model** out)
         size_t ca = 0;
         for (int j = 0; j < 3; ++j) ca += 4 * (size_t)((c.n_app[j] + 3) / 4);
         const size_t lds = 4 * (rpb * rows_per_ray(c) * (nq * 4 + 4) + rpb * 3 * ca + 256);
-        if (lds > 160 * 1024) {
+        if (lds > 160 * 1024 - 4096) {             // (- the static words of the sample kernel: the ray records, hr_gather_ones)
             const int z = c.z_channels, pl = m->p_live;
             hr_model_destroy(m);                      // also releases the device configuration
             return fail(HR_E_INVALID, "z_channels %d x %d head columns need %zu bytes of LDS per workgroup (160 KiB available)", z, pl, lds);
@@ -1689,6 +1689,7 @@ int hr_model_get_option(hr_model* m, int32_t option, int32_t* value)
     if (option == HR_OPT_FRAME_KERNEL) *value = m->opt_frame_kernel;
     else if (option == HR_OPT_SAMPLE_WAVES) *value = m->opt_sample_waves;
     else if (option == HR_OPT_TRAIN_DETERMINISTIC) *value = m->opt_train_det;
+    else if (option == HR_OPT_CHUNK_RAYS) *value = (int32_t)m->chunk;
     else if (option == HR_OPT_MLP_PRECISION_ACTIVE || option == HR_OPT_MLP_CALIBRATED || option == HR_OPT_MLP_OVERFLOW || option == HR_OPT_MLP_F8_SATURATED ||
              option == HR_OPT_MLP_VERIFIED || option == HR_OPT_REDO_OVERFLOW || option == HR_OPT_REDO_COUNT || option == HR_OPT_WIDE_COUNT) {
         if (!m->finalized) return fail(HR_E_STATE, "hr_model_finalize has not been called");

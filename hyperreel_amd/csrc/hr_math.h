@@ -97,7 +97,11 @@ HR_FN float hr_apply_act(const hr_act& a, float x)
 HR_FN float hr_apply_act_post(const hr_act& a, float x)
 {
 #if defined(__HIPCC__) && defined(HR_FAST_POST)
-    float y = x * a.inner + a.shift;
+    // the shipped colour scale / shift heads and the outer offset / flow activations are the identity with unit parameters: x itself (three
+    // instructions per value otherwise; the parameters are uniform, their bit patterns compare on the scalar unit).  Only -0 -> +0 is lost.
+    if (a.type == HR_ACT_IDENTITY && __builtin_bit_cast(unsigned, a.inner) == 0x3f800000u && __builtin_bit_cast(unsigned, a.shift) == 0u &&
+        __builtin_bit_cast(unsigned, a.outer) == 0x3f800000u && __builtin_bit_cast(unsigned, a.add) == 0u) return x;
+    float y = __builtin_fmaf(x, a.inner, a.shift);          // (one rounding instead of two: these heads feed continuous quantities only)
     if (a.type == HR_ACT_SIGMOID) {
         y = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
     } else if (a.type == HR_ACT_TANH) {
@@ -445,7 +449,28 @@ HR_FN float hr_isect_new(const hr_config& c, const float* hk, int k, float one_m
 // head activation -> z activation * (1 - sigma) -> anchors/scale -> inverse contraction
 // -> closed-form intersection -> near/far mask.  `hk` points at the P raw head values of
 // sample k; `ro`/`rd` are the ray origin (minus intersect origin) and direction.
-HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const float* ro, const float* rd, HrRisk* risk = nullptr)
+// The ray's terms of the sphere / cylinder quadratic (primitive.py:425-431, intersect_utils.py:45-125) for a primitive of centre-scale
+// (sx, sy, sz): q = {o.o, d.d, o.d} of the scaled origin and direction.  With the shipped origin_scale_factor of 0 the scale is a constant of
+// the model and q a constant of the RAY: the sample kernel computes it once per ray (sample_core.inc, hr_ray_constants) and hands it to
+// hr_sample_distance, which otherwise calls this per sample -- the same operations in the same order either way.
+HR_FN void hr_quadratic_ray_terms(const hr_config& c, const float* ro, const float* rd, float sx, float sy, float sz, float* q)
+{
+    float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
+    float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
+    if (c.isect_type == HR_ISECT_SPHERE) {
+        q[0] = ox * ox + oy * oy + oz * oz;
+        q[1] = dx * dx + dy * dy + dz * dz;
+        q[2] = ox * dx + oy * dy + oz * dz;
+    } else {
+        q[0] = ox * ox + oz * oz;
+        q[1] = dx * dx + dz * dz;
+        q[2] = ox * dx + oz * dz;
+    }
+}
+
+// quad: hr_quadratic_ray_terms of this ray for the model's constant centre-scale, or NULL (read only where origin_scale == 0)
+HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const float* ro, const float* rd, HrRisk* risk = nullptr,
+                               const float* quad = nullptr)
 {
     float sigma = 0.0f;
     if (c.f_isect_sigma.offset >= 0) sigma = hr_apply_act(c.f_isect_sigma.act, hk[c.f_isect_sigma.offset]);
@@ -470,27 +495,15 @@ HR_FN float hr_sample_distance(const hr_config& c, const float* hk, int k, const
 #if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
         if (risk) { risk->dbg[0] = hr_zval(c, hk, 3, one_m); risk->dbg[1] = radius; }
 #endif
-        float ox = ro[0] * sx, oy = ro[1] * sy, oz = ro[2] * sz;     // primitive.py:425-431
-        float dx = rd[0] * sx, dy = rd[1] * sy, dz = rd[2] * sz;
-#if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM == 2      // -DHR_DEBUG_HSUM=2: the six products and the two sums, per lane (tools/hsum_bisect.py --lanes)
-        if (risk) { risk->dbg[0] = ox; risk->dbg[1] = oy; risk->dbg[2] = oz; risk->dbg[3] = dx; risk->dbg[4] = dy; risk->dbg[5] = dz; }
-#endif
-        if (c.isect_type == HR_ISECT_SPHERE) {
-            float oo = ox * ox + oy * oy + oz * oz;
-            float dd = dx * dx + dy * dy + dz * dz;
-            float od = ox * dx + oy * dy + oz * dz;
+        float q_[3];
+        if (quad && c.origin_scale == 0.0f) { q_[0] = quad[0]; q_[1] = quad[1]; q_[2] = quad[2]; }
+        else hr_quadratic_ray_terms(c, ro, rd, sx, sy, sz, q_);
 #if defined(HR_DEBUG_HSUM) && HR_DEBUG_HSUM != 2
-            if (risk) { risk->dbg[2] = oo; risk->dbg[3] = od; }
+        if (risk) { risk->dbg[2] = q_[0]; risk->dbg[3] = q_[2]; }
 #elif defined(HR_DEBUG_HSUM)
-            if (risk) { risk->dbg[6] = oo; risk->dbg[7] = od; }
+        if (risk) { risk->dbg[6] = q_[0]; risk->dbg[7] = q_[2]; }
 #endif
-            dist = hr_quadratic_t(oo, dd, od, radius, risk);
-        } else {
-            float oo = ox * ox + oz * oz;
-            float dd = dx * dx + dz * dz;
-            float od = ox * dx + oz * dz;
-            dist = hr_quadratic_t(oo, dd, od, radius, risk);
-        }
+        dist = hr_quadratic_t(q_[0], q_[1], q_[2], radius, risk);
     } else if (c.isect_type == HR_ISECT_SPHERE_NEW || c.isect_type == HR_ISECT_CYLINDER_NEW) {
         dist = hr_isect_new(c, hk, k, one_m, ro, rd, risk);
     } else if (c.isect_type == HR_ISECT_VOXEL_GRID) {

@@ -1,6 +1,7 @@
 // Stand-alone sample kernel: the sample stage (sample_core.inc) over a head that the MLP kernel left in the HBM
 // workspace.  Used where the fused frame kernel (fused_impl.inc) does not apply: diagnostics (hr_render_fields),
 // point_prediction cascades, heads too wide for the LDS hand-over, the exact-fp32 MLP.
+#define HR_GATHER_FENCED 1
 #include "sample_core.inc"
 
 template <int ZP, bool HALF, int PC, int NB>
@@ -68,14 +69,36 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     // ---- per-ray quantities (computed redundantly by the ray's lanes) and the ray's decode matrix
     // RGB shading: the decode matrix is basis_mat itself, the same for every ray -- the block keeps ONE copy, filled by its
     // first ray's lanes (SH: one per ray, folded with that ray's view direction)
-    const HrRayLane L = hr_load_ray(cfg, a, ray, ray_ok);
+    // The ray record (origin, direction, time, contracted origin, keyframe time, the quadratic's ray terms: sample_core.inc, HrRayLane) is
+    // computed by ONE lane per ray -- the first RPB lanes of the workgroup, a ray each -- and read back from LDS by the ray's lanes after the
+    // barrier: in the lane-per-sample mapping every lane of the ray would otherwise repeat it.
+    __shared__ __attribute__((aligned(16))) float s_ray[RPB * HR_RAY_RECORD];
+    if (tid < RPB) {
+        const int64_t lrow_r = ray_base + tid;
+        const bool ok_r = lrow_r < n_rays;
+        const int64_t ray_r = (a.ray_index && ok_r) ? (int64_t)a.ray_index[lrow_r] : lrow_r;
+        HrRayLane R = hr_load_ray(cfg, a, ray_r, ok_r);
+        hr_ray_constants(cfg, R);
+        hr_store_ray_record(R, s_ray + tid * HR_RAY_RECORD);
+    }
     const bool per_ray_M = (cfg.shading == HR_SHADING_SH);
     float* M = s_M + (per_ray_M ? rib * 3 * CA : 0);
 #ifdef HR_TUNING
     if (!(a.dbg_mode & 4))
 #endif
-    if (per_ray_M || rib == 0) hr_fill_decode<ZP>(cfg, a, L, k, M);
+    if (per_ray_M) {                               // SH: folded with the ray's view direction, which its lanes read themselves (the record is not published yet)
+        HrRayLane V = hr_load_ray(cfg, a, 0, false);
+        if (ray_ok) {
+            const float* r = a.rays + ray * cfg.ray_dim;
+            V.vd[0] = r[3]; V.vd[1] = r[4]; V.vd[2] = r[5];
+        }
+        hr_fill_decode<ZP>(cfg, a, V, k, M);
+    } else if (rib == 0) {
+        hr_fill_decode<ZP>(cfg, a, hr_load_ray(cfg, a, 0, false), k, M);
+    }
+    hr_gather_ones_init();
     __syncthreads();
+    const HrRayLane L = hr_read_ray_record(s_ray + rib * HR_RAY_RECORD);
 
 #ifdef HR_TUNING
     unsigned long long sph__[12] = {};
@@ -86,7 +109,11 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)
 {
     const int RPB = 256 / ZP;
-    return ((size_t)RPB * rows_per_ray * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total + (ZP > 64 ? 256 : 0)) * sizeof(float);
+    size_t bytes = ((size_t)RPB * rows_per_ray * (nq * 4 + 4) + (size_t)RPB * 3 * ca_total + (ZP > 64 ? 256 : 0)) * sizeof(float);
+#ifdef HR_SAMPLE_LDS_FLOOR     // measurement builds: fewer workgroups per CU than the registers allow (profiles/r06_k2_occupancy_ab.txt)
+    if (bytes < HR_SAMPLE_LDS_FLOOR) bytes = HR_SAMPLE_LDS_FLOOR;
+#endif
+    return bytes;
 }
 
 void hr_launch_samples(const hr_config& cfg, const HrSampleArgs& args, hipStream_t stream)

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
         }
         lds[e] = v;
     }
+    hr_gather_ones_init();
     __syncthreads();
     const float* M = lds + rib * 3 * CA;
     const bool lane_ok = ray_ok && k < Z;

@@ -18,7 +18,7 @@ ABI_VERSION = 26
 HR_OPT_FRAME_KERNEL, HR_OPT_SAMPLE_WAVES, HR_OPT_FRAME_KERNEL_ACTIVE, HR_OPT_MLP_PRECISION_ACTIVE, HR_OPT_MLP_OVERFLOW, HR_OPT_MLP_CALIBRATED = 0, 1, 2, 3, 4, 5
 HR_OPT_TRAIN_DETERMINISTIC = 6
 HR_OPT_MLP_F8_SATURATED = 7
-HR_OPT_MLP_VERIFIED, HR_OPT_REDO_COUNT, HR_OPT_REDO_OVERFLOW, HR_OPT_WIDE_COUNT = 8, 9, 10, 11
+HR_OPT_MLP_VERIFIED, HR_OPT_REDO_COUNT, HR_OPT_REDO_OVERFLOW, HR_OPT_WIDE_COUNT, HR_OPT_CHUNK_RAYS = 8, 9, 10, 11, 12
 HR_E_RANGE = -5
 
 

@@ -634,6 +634,10 @@ class HipLightfieldModel(nn.Module):
         _lib.check(_lib.load().hr_model_get_option(self.native(), _lib.HR_OPT_FRAME_KERNEL_ACTIVE, C.byref(v)), 'hr_model_get_option')
         return bool(v.value)
 
+    def chunk_rays(self):
+        """Rays per launch of the head workspace (hr_model_reserve / the finalize default): the most hr_stage_* accept."""
+        return self._get_option(_lib.HR_OPT_CHUNK_RAYS)
+
     def _get_option(self, opt):
         import ctypes as C
         v = C.c_int32(0)

@@ -336,10 +336,11 @@ int hr_model_reserve(hr_model* m, int64_t rays_per_chunk);
  * hyperreel_amd's host guard polls this bit (hr_model_calibrate on such rays re-decides; HR_MLP_F16X3 never lists).
  * HR_OPT_WIDE_COUNT: rays the last hr_render passed on to the THIRD pass (bf16x3 tiles: halves with the fp32 exponent range) because an activation of
  * theirs left the IEEE-half range in the second -- the device-side form of the overflow fallback, inside a captured graph too.  In the verified
- * mode HR_OPT_MLP_OVERFLOW / HR_OPT_MLP_F8_SATURATED are raised only for rays that could not be listed (a full list). */
+ * mode HR_OPT_MLP_OVERFLOW / HR_OPT_MLP_F8_SATURATED are raised only for rays that could not be listed (a full list).
+ * HR_OPT_CHUNK_RAYS: rays per launch of the head workspace (hr_model_reserve's, or hr_model_finalize's default): what hr_stage_* accept. */
 enum { HR_OPT_FRAME_KERNEL = 0, HR_OPT_SAMPLE_WAVES = 1, HR_OPT_FRAME_KERNEL_ACTIVE = 2, HR_OPT_MLP_PRECISION_ACTIVE = 3,
        HR_OPT_MLP_OVERFLOW = 4, HR_OPT_MLP_CALIBRATED = 5, HR_OPT_TRAIN_DETERMINISTIC = 6, HR_OPT_MLP_F8_SATURATED = 7,
-       HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10, HR_OPT_WIDE_COUNT = 11 };
+       HR_OPT_MLP_VERIFIED = 8, HR_OPT_REDO_COUNT = 9, HR_OPT_REDO_OVERFLOW = 10, HR_OPT_WIDE_COUNT = 11, HR_OPT_CHUNK_RAYS = 12 };
 int hr_model_set_option(hr_model* m, int32_t option, int32_t value);
 int hr_model_get_option(hr_model* m, int32_t option, int32_t* value);
 

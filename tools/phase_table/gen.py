@@ -92,12 +92,25 @@ __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
     const int64_t ray = (int64_t)blockIdx.x * {256 // ZP} + rib;
     const bool ray_ok = ray < b.n_rays;
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 100" ::: "memory");
-    const HrRayLane L = hr_load_ray(c, b, ray, ray_ok);
+    // the ray record as the stand-alone kernel makes it (sample_kernel.hip): one lane per ray of the workgroup -- executed by wavefront 0 only
+    __shared__ __attribute__((aligned(16))) float s_ray[{256 // ZP} * HR_RAY_RECORD];
+    if (tid < {256 // ZP}) {{
+        const int64_t ray_r = (int64_t)blockIdx.x * {256 // ZP} + tid;
+        HrRayLane R = hr_load_ray(c, b, ray_r, ray_r < b.n_rays);
+        hr_ray_constants(c, R);
+        hr_store_ray_record(R, s_ray + tid * HR_RAY_RECORD);
+    }}
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 101" ::: "memory");
     float* M = lds + 4096 + rib * 3 * b.ca_total;
-    hr_fill_decode<{ZP}>(c, b, L, k, M);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {{
+        HrRayLane V = hr_load_ray(c, b, 0, false);
+        if (c.shading == HR_SHADING_SH && ray_ok) {{ const float* r = b.rays + ray * c.ray_dim; V.vd[0] = r[3]; V.vd[1] = r[4]; V.vd[2] = r[5]; }}
+        if (c.shading == HR_SHADING_SH || rib == 0) hr_fill_decode<{ZP}>(c, b, V, k, M);
+    }}
+    hr_gather_ones_init();
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 102" ::: "memory");
+    const HrRayLane L = hr_read_ray_record(s_ray + rib * HR_RAY_RECORD);
     hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB, {pclass}>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, nullptr);
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 199" ::: "memory");
 }}
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
     subprocess.run([B.hipcc(), *B.FLAGS, f'-DHR_PHASE_PIPE=1', f'-DHR_PHASE_NB={nb}', '-S', '--cuda-device-only', cu, '-o', asm], check=True)
     text = open(asm).read()
     body = text[text.index('_Z12phase_kernel12HrSampleArgs:'):text.index('.Lfunc_end0')]
-    names = {100: 'ray load', 101: 'decode matrix', 102: '(head ptr)', 0: 'distance', 1: 'sort', 2: 'point+delta', 3: 'valid+taps', 4: 'gather plane 0',
+    names = {100: 'ray record (wavefront 0)', 101: 'decode matrix (ray 0)', 102: '(record read)', 0: 'distance', 1: 'sort', 2: 'point+delta', 3: 'valid+taps', 4: 'gather plane 0',
              5: 'gather plane 1', 6: 'gather plane 2', 7: 'alpha+transmittance', 8: 'colour+sum+store', 199: 'end'}
     cur, counts = None, collections.OrderedDict()
     for ln in body.split('\n'):
