@@ -586,7 +586,10 @@ def main():
         L = hlib.load()
         h = model.native()
         # rays per launch, as hr_render splits a call: as many launches as the workspace (163 840 rays by default) demands, of equal size
-        cap = model.chunk_rays()
+        try:
+            cap = model.chunk_rays()
+        except Exception:               # (a measurement library older than HR_OPT_CHUNK_RAYS, --lib)
+            cap = args.chunk or 163840
         n_launch = -(-B // cap)
         chunk = min(cap, (-(-B // n_launch) + 63) & ~63)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -96,14 +96,15 @@ __global__ __launch_bounds__(256, (HrGatherTune<ZP, HALF>::MIN_BLOCKS)) void hr_
     } else if (rib == 0) {
         hr_fill_decode<ZP>(cfg, a, hr_load_ray(cfg, a, 0, false), k, M);
     }
-    hr_gather_ones_init();
+    __shared__ __attribute__((aligned(16))) float s_ones[HR_GATHER_ONES];
+    hr_gather_ones_init(s_ones);
     __syncthreads();
     const HrRayLane L = hr_read_ray_record(s_ray + rib * HR_RAY_RECORD);
 
 #ifdef HR_TUNING
     unsigned long long sph__[12] = {};
 #endif
-    hr_sample_body<ZP, HALF, 1, NB, PC>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_x HR_SPH_ARG);
+    hr_sample_body<ZP, HALF, 1, NB, PC>(cfg, a, L, ray, ray_ok, k, s_head + rib * RPR * HS, HS, M, s_ones, s_x HR_SPH_ARG);
 }
 
 static size_t hr_sample_lds_bytes(int nq, int ca_total, int ZP, int rows_per_ray)

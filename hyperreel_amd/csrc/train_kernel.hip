@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
         }
         lds[e] = v;
     }
-    hr_gather_ones_init();
+    __shared__ __attribute__((aligned(16))) float s_ones[HR_GATHER_ONES];
+    hr_gather_ones_init(s_ones);
     __syncthreads();
     const float* M = lds + rib * 3 * CA;
     const bool lane_ok = ray_ok && k < Z;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void hr_train_lanes_kernel(const hr_config* __
             at.ax[1] = hr_make_tap_c(pn[1], c.grid[1]);
             at.ax[2] = hr_make_tap_c(pn[2], c.grid[2]);
             at.t = hr_make_tap_c(pn[3], (NB == 4 && c.video) ? c.num_keyframes : 2);
-            hr_gather_844<NB, PC>(a.planes, at, valid, M, feat, pre0, pre1, pre2);
+            hr_gather_844<NB, PC>(a.planes, at, valid, M, s_ones, feat, pre0, pre1, pre2);
         } else {
             HrAxisTaps at;
             at.ax[0] = hr_make_tap(pn[0], c.grid[0]);

@@ -107,11 +107,12 @@ __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
         if (c.shading == HR_SHADING_SH && ray_ok) {{ const float* r = b.rays + ray * c.ray_dim; V.vd[0] = r[3]; V.vd[1] = r[4]; V.vd[2] = r[5]; }}
         if (c.shading == HR_SHADING_SH || rib == 0) hr_fill_decode<{ZP}>(c, b, V, k, M);
     }}
-    hr_gather_ones_init();
+    __shared__ __attribute__((aligned(16))) float s_ones[HR_GATHER_ONES];
+    hr_gather_ones_init(s_ones);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 102" ::: "memory");
     const HrRayLane L = hr_read_ray_record(s_ray + rib * HR_RAY_RECORD);
-    hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB, {pclass}>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, nullptr);
+    hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB, {pclass}>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, s_ones, nullptr);
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 199" ::: "memory");
 }}
 '''
