@@ -64,6 +64,7 @@ MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA p
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave-instructions per ns: 256 CUs x 4 SIMDs, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md, wave
                                      # scheduling), 2.4 GHz.  tools/valu_ilp_ubench.hip on this part: 2.6 cycles per v_fma_f32 per SIMD with four wavefronts,
                                      # 4.3-4.9 per DPP instruction, 8.3 per transcendental (profiles/r03_valu_ilp_ubench.txt)
+GATHER_UBENCH_L1_TBS, GATHER_UBENCH_L2_TBS = 30.2, 16.3      # profiles/r01_i_gather_ubench.txt (mode 1: quad-cooperative 64-byte texels)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -639,16 +640,23 @@ def main():
         if split:
             r_mlp['sustained_mfma_tflops'] = 1850.0
             r_mlp['frac_of_sustained_issued'] = round(n_prod * flops / (mlp_ms[0] * 1e-3) / 1e12 / 1850.0, 4)
-        r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'valu', 'achieved': None, 'peak': round(VALU_PEAK_GINST, 1), 'unit': 'G wave-instructions/s',
-                 'frac': None, 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
-                 'algorithmic_gather_GBs': round(byts / (smp_ms[0] * 1e-3) / 1e9, 1),
+        gather_tbs = byts / (smp_ms[0] * 1e-3) / 1e12
+        r_smp = {'kernel': 'hr_sample_kernel', 'bound': 'valu + vector-L1 load path (co-limited)', 'achieved': None, 'peak': round(VALU_PEAK_GINST, 1),
+                 'unit': 'G wave-instructions/s', 'frac': None, 'traffic': None, 'launches_per_step': nl, 'avg_launch_ms': round(smp_ms[0] / nl, 4),
+                 'algorithmic_gather_GBs': round(gather_tbs * 1e3, 1),
                  'algorithmic_per_launch': f'{algorithmic_bytes_per_ray(cfg, video, texel_bytes)} B/ray x {min(chunk, B)} rays (L2 / Infinity-Cache resident: not an HBM figure)',
-                 'note': 'the sample stage is bound by vector-ALU issue, not by bytes: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, '
-                         'the committed PMC pass) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue '
-                         'rate for plain fp32 instructions; the stage\'s mix of DPP and transcendental instructions issues slower: '
-                         'profiles/r03_valu_ilp_ubench.txt).  The library contains no packed-fp32 instructions since the end of round 5 (DESIGN.md 4): '
-                         'the same arithmetic counted 1 169 instructions per sample slot with 184 of them packed, at the same time per launch '
-                         '(a packed-fp32 instruction takes two issue passes; profiles/r05_no_packed_fp32_ab.txt)'}
+                 'load_path': {'achieved': round(gather_tbs, 2), 'peak': GATHER_UBENCH_L1_TBS, 'peak_l2_resident': GATHER_UBENCH_L2_TBS, 'unit': 'TB/s',
+                               'frac': round(gather_tbs / GATHER_UBENCH_L1_TBS, 4),
+                               'what': 'the gather\'s algorithmic bytes per second against what the SAME access shape (16-byte lane loads, the 4 lanes of a quad '
+                                       'on one 64-byte texel) reaches with nothing else in the kernel: 30.2 TB/s from an L1-resident working set, 16.3 TB/s '
+                                       'L2-resident (tools/gather_ubench.hip, profiles/r01_i_gather_ubench.txt); the stage hits L1 ~90 %, L2 ~80 % of the rest'},
+                 'note': 'after round 6\'s reductions (1 298 -> ~1 100 vector instructions per sample slot: branch-free density / appearance lanes, one ray '
+                         'record per ray, FMA-chain decode sums) the stage is co-limited: VALU ~82 % busy, address unit / L1 path ~73 % -- 13 % fewer '
+                         'instructions bought 1.5 % of time, and 5 / 4 / 7 / 8 workgroups per CU instead of 6 are all slower (profiles/r06_k2_*_ab*.txt).  '
+                         'VALU side: achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU, the committed PMC pass) / live launch time; peak = '
+                         '1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide\'s issue rate for plain fp32 instructions; the stage\'s mix of DPP '
+                         'and transcendental instructions issues slower: profiles/r03_valu_ilp_ubench.txt).  The library contains no packed-fp32 '
+                         'instructions (DESIGN.md 4)'}
         # counters measured separately with rocprofv3 --pmc (never inside a timed run) and committed under profiles/;
         # attached only when the workload matches the profiled one
         tr, state, src = load_counters('', lambda w: (w['model'] == args.model and w['rays_per_launch'] == min(chunk, B) and w['grid'] == grid

@@ -15,6 +15,7 @@
 //   phase C (intersection backward): one thread per (ray, sample), elementwise.
 #include "hr_kernels.h"
 #include "hr_mask.h"
+#define HR_GATHER_FENCED 1        // (the lane-per-sample forward: 90 registers instead of 102, sample_core.inc)
 #include "sample_core.inc"      // the render kernels' lane-per-sample building blocks (sort, cooperative gather)
 // The deterministic build of the sample-stage training kernels (train_det_kernel.hip: HR_TRAIN_DET, hr_acc_t = 64-bit fixed point, see
 // hr_train.h) compiles this file a second time: everything that depends on hr_acc_t lives in its own namespace there, the exports that

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 3) void phase_kernel(const HrSampleArgs a)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 102" ::: "memory");
     const HrRayLane L = hr_read_ray_record(s_ray + rib * HR_RAY_RECORD);
+    __builtin_assume(b.rows_per_ray == 1);
     hr_sample_body<{ZP}, {'true' if half else 'false'}, HR_PHASE_PIPE, HR_PHASE_NB, {pclass}>(c, b, L, ray, ray_ok, k, lds + rib * b.nq * 4, b.nq * 4, M, s_ones, nullptr);
     __builtin_amdgcn_sched_barrier(0); asm volatile("; HRPHASE 199" ::: "memory");
 }}
