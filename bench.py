@@ -633,10 +633,12 @@ def main():
                           '(profiles/r02_e_mfma_pipe_ubench.txt), 1.85 PFLOP/s sustained -- frac_of_sustained_issued prices the issued products against that') if split else 'exact fp32 MFMA (v_mfma_f32_16x16x4_f32)'}
         if prec_name == 'f16f8':
             r_mlp['note'] = ('fp32 GEMMs as ONE f16 MFMA product (x_hi w_hi) + one fp8 K=64 MFMA per 32 k for both correction products: the matrix cores issue the pipe time of '
-                             '2 f16 products per 16 k, so frac <= 1/2 by construction.  What co-limits it (DESIGN.md 3, K1): per k-step a workgroup loads 16 KB of weights through the '
-                             'CU\'s one 64 B/clk vector-L1 path for 8 MFMA-equivalents of 32 cycles per SIMD -- at the full matrix rate that path is 100 % busy (f16x3: 67 %); eight '
-                             'wavefronts per workgroup instead of four run at the same speed (profiles/r05_k1_nw8_ab.txt).  Under real operands the power manager holds the shader clock at '
-                             '1.6-2.0 GHz (2.44 with zero operands, profiles/r02_e_mfma_pipe_ubench.txt): frac_of_sustained_issued prices the issued products against 1.85 PFLOP/s')
+                             '2 f16 products per 16 k, so frac <= 1/2 by construction.  What bounds it (DESIGN.md 3, K1; measured in round 6): the package power limit -- the kernel '
+                             'holds the socket at its 1.4 kW cap with the shader clock at 1.91 GHz; without its matrix instructions it runs at 2.38 GHz / 1 270 W, without them and '
+                             'the weight loads at 2.39 GHz / 1 150 W (profiles/r06_k1_power_probe.txt).  In cycles the MFMAs overlap the operand stream and the epilogues; in time they '
+                             'cost the clock.  The operand stream is not the ceiling (profiles/r06_k1_operand_ubench.txt), and prefetch depth, 4 / 8 wavefronts, staggered or '
+                             'turn-taking workgroups all run level (profiles/r06_k1_ab_*.txt): only removing work pays.  frac_of_sustained_issued prices the issued products against '
+                             'the 1.85 PFLOP/s the matrix pipe sustains alone under real operands (profiles/r02_e_mfma_pipe_ubench.txt)')
         if split:
             r_mlp['sustained_mfma_tflops'] = 1850.0
             r_mlp['frac_of_sustained_issued'] = round(n_prod * flops / (mlp_ms[0] * 1e-3) / 1e12 / 1850.0, 4)

@@ -906,6 +906,9 @@ int hr_model_finalize(hr_model* m)
         const size_t esz = half ? 2 : sizeof(float);
         const size_t a_bytes = esz * (size_t)g.aw * g.ah * tex;
         const size_t b_bytes = esz * (size_t)g.bw * g.bh * tex;
+        // the gathers address texels by 32-bit BYTE offsets (and the class-specialised one marks a masked sample by the offset 0xffffffff)
+        if (a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32))
+            return fail(HR_E_INVALID, "plane pair %d: %zu / %zu bytes -- a feature plane must stay below 4 GiB (32-bit texel offsets)", j, a_bytes, b_bytes);
         HR_HIP(hipMalloc((void**)&m->grid_a[j], a_bytes));
         HR_HIP(hipMalloc((void**)&m->grid_b[j], b_bytes));
         HR_HIP(hipMemset(m->grid_a[j], 0, a_bytes));
