@@ -46,6 +46,26 @@ void hm_embed(const hr_config* c, const float* rays, const float* head, int n, f
     }
 }
 
+// hr_sample_distance with the quadratic's ray terms handed in (what the sample kernel does once per ray: sample_core.inc, hr_ray_constants)
+// and without: dist_pre / dist_own (n, Z)
+void hm_distance_both(const hr_config* c, const float* rays, const float* head, int n, float* dist_pre, float* dist_own)
+{
+    const int Z = c->z_channels, P = c->preds_per_z;
+    for (int i = 0; i < n; ++i) {
+        const float* r = rays + (size_t)i * c->ray_dim;
+        float ro[3] = {r[0] - c->isect_origin[0], r[1] - c->isect_origin[1], r[2] - c->isect_origin[2]};
+        float rd[3] = {r[3], r[4], r[5]};
+        float quad[3] = {0.0f, 0.0f, 0.0f};
+        if ((c->isect_type == HR_ISECT_SPHERE || c->isect_type == HR_ISECT_CYLINDER) && c->origin_scale == 0.0f)
+            hr_quadratic_ray_terms(*c, ro, rd, c->origin_initial[0], c->origin_initial[1], c->origin_initial[2], quad);
+        const float* h = head + (size_t)i * Z * P;
+        for (int k = 0; k < Z; ++k) {
+            dist_pre[(size_t)i * Z + k] = hr_sample_distance(*c, h + k * P, k, ro, rd, nullptr, quad);
+            dist_own[(size_t)i * Z + k] = hr_sample_distance(*c, h + k * P, k, ro, rd);
+        }
+    }
+}
+
 // one axis of grid_sample: g (n) on an axis of `size` texels -> i0,i1,w0,w1
 void hm_taps(const float* g, int n, int size, int* i0, int* i1, float* w0, float* w1)
 {

@@ -161,8 +161,10 @@ def test_internal_chunking_is_invisible(fns):
     g, fn = fns('immersive_sphere_small')
     rays = np.concatenate([g.rays] * 3, 0)
     fn.model.reserve(64)
+    assert fn.model.chunk_rays() == 64                  # HR_OPT_CHUNK_RAYS: what hr_stage_* accept (bench.py sizes its stage timing from it)
     a = render_np(fn, rays)['rgb']
     fn.model.reserve(32768)
+    assert fn.model.chunk_rays() == 32768
     b = render_np(fn, rays)['rgb']
     assert np.array_equal(a, b)
     assert np.array_equal(a[:g.rays.shape[0]], a[g.rays.shape[0]:2 * g.rays.shape[0]])

@@ -80,6 +80,26 @@ def test_features_and_embedding_match_oracle(hm, case):
     assert (valid.astype(bool) == col['valid']).mean() > 0.999
 
 
+@pytest.mark.parametrize('case', SMALL)
+def test_per_ray_quadratic_terms_give_the_same_distances_bit_for_bit(hm, case):
+    """The sample kernel computes o.o, d.d, o.d of the sphere / cylinder intersection once per ray (csrc/sample_core.inc: hr_ray_constants)
+    and hands them to hr_sample_distance, which otherwise forms them per sample (the reference's order: primitive.py:425-431,
+    intersect_utils.py:45-125): the same operations either way."""
+    g = Golden(case)
+    if plan.is_cascade(g.cfg):
+        pytest.skip('two-level models are exercised end to end on the GPU')
+    hc = plan.compile_config(g.cfg, g.dataset, g.grid, iteration=g.iteration)
+    orc = HyperReelOracle(g.cfg, g.dataset, g.state_dict, iteration=g.iteration)
+    rays = np.ascontiguousarray(g.rays[:300], np.float32)
+    n = rays.shape[0]
+    head = np.ascontiguousarray(orc.embed(rays)['_head_raw'], np.float32)
+    Z = hc.z_channels
+    a = np.zeros((n, Z), np.float32)
+    b = np.zeros((n, Z), np.float32)
+    hm.hm_distance_both(C.byref(hc), fp(rays), fp(head), n, fp(a), fp(b))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_taps_sh_density_normalize(hm):
     rng = np.random.default_rng(0)
     g = np.concatenate([rng.uniform(-1.2, 1.2, 500), [-1.0, 1.0, 0.0, 0.99999994, -0.99999994]]).astype(np.float32)
