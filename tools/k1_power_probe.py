@@ -16,13 +16,15 @@ def child(lib):
     from hyperreel_amd import config as C, scenes
     from hyperreel_amd.render import build_render_fn
     cfg, ds = C.model_config('donerf_sphere'), C.dataset_scalars('donerf_sphere')
-    grid = None if os.environ.get('HR_PROBE_STAGE') == 'samples' else [64, 64, 64]      # K2 wants the shipped 600^3 grid (its gather), K1 does not care
+    stage = os.environ.get('HR_PROBE_STAGE', 'mlp')       # mlp (K1 back to back) | samples (K2) | frame (whole 800x800 frames through hr_render, default arithmetic)
+    grid = None if stage in ('samples', 'frame') else [64, 64, 64]      # K2 wants the shipped 600^3 grid (its gather), K1 does not care
     sd = scenes.make_state_dict(cfg, ds, grid, seed=7, density='dense', app_scale=1.0)
     grid = [int(v) for v in sd['model.color_model.net.gridSize']]
-    f = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision='f16f8')
+    f = build_render_fn(cfg, dataset=ds, grid_size=grid, mlp_precision='auto' if stage == 'frame' else 'f16f8')
     f.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     h = f.model.native()
-    rays = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800, frame=7)[:131072]).cuda()
+    rays_all = torch.from_numpy(scenes.benchmark_rays('donerf_sphere', 800, 800, frame=7)).cuda()
+    rays = rays_all[:131072].contiguous()
     L = hl.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     samples, stop = [], threading.Event()
@@ -44,9 +46,12 @@ def child(lib):
     rgb = torch.empty((131072, 3), device='cuda')
     k2 = os.environ.get('HR_PROBE_STAGE') == 'samples'       # the sample stage instead (K2 reads the head K1 left in the workspace)
     hl.check(L.hr_stage_mlp(h, ctypes.c_void_p(rays.data_ptr()), 131072, st), 'hr_stage_mlp')
+    rgb_all = torch.empty((rays_all.shape[0], 3), device='cuda')
     while time.perf_counter() - t0 < 5.0:
         for _ in range(200):
-            if k2:
+            if stage == 'frame':
+                hl.check(L.hr_render(h, ctypes.c_void_p(rays_all.data_ptr()), rays_all.shape[0], ctypes.c_void_p(rgb_all.data_ptr()), st), 'hr_render')
+            elif k2:
                 hl.check(L.hr_stage_samples(h, ctypes.c_void_p(rays.data_ptr()), 131072, ctypes.c_void_p(rgb.data_ptr()), st), 'hr_stage_samples')
             else:
                 hl.check(L.hr_stage_mlp(h, ctypes.c_void_p(rays.data_ptr()), 131072, st), 'hr_stage_mlp')
@@ -54,7 +59,7 @@ def child(lib):
         n += 200
     dt = time.perf_counter() - t0
     stop.set(); th.join()
-    print(json.dumps({'variant': lib, 'stage': 'K2' if k2 else 'K1', 'ms_per_launch': round(dt / n * 1e3, 4), 'smi': samples[2:-1][:12]}))
+    print(json.dumps({'variant': lib, 'stage': 'frame (hr_render, 640 000 rays)' if stage == 'frame' else ('K2' if k2 else 'K1'), 'ms_per_launch': round(dt / n * 1e3, 4), 'smi': samples[2:-1][:12]}))
 
 
 if __name__ == '__main__':
