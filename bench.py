@@ -107,6 +107,45 @@ def mlp_flops_per_ray(cfg):
     return 2 * sum(o * i for o, i in scenes.mlp_layer_shapes(cfg))
 
 
+def power_probe(fn, seconds=1.2, period=0.2):
+    """Socket power and shader clock while `fn` (which enqueues GPU work) runs back to back: rocm-smi polled from a thread.  Returns
+    {'socket_w', 'sclk_mhz', 'samples'} (medians) or None when rocm-smi is not usable.  Outside every timed region."""
+    import json as _json, re, subprocess, threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5)
+                card = _json.loads(r.stdout)
+                card = card[sorted(card)[0]]
+                w = next((float(v) for k, v in card.items() if 'power' in k.lower() and re.match(r'^[0-9.]+$', str(v))), None)
+                c = next((float(re.sub(r'[^0-9.]', '', str(v))) for k, v in card.items() if k.lower().startswith('sclk clock speed')), None)
+                if w is not None and c is not None:
+                    samples.append((w, c))
+            except Exception:
+                return
+            stop.wait(period)
+    th = threading.Thread(target=poll, daemon=True)
+    try:
+        fn(); sync()
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                fn()
+            sync()
+    finally:
+        stop.set()
+        if th.is_alive():
+            th.join(timeout=6)
+    s_ = samples[1:] if len(samples) > 2 else samples          # (the first sample may predate the load)
+    if not s_:
+        return None
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {'socket_w': med([a for a, _ in s_]), 'sclk_mhz': med([b for _, b in s_]), 'samples': len(s_)}
+
+
 def time_stage(fn, reps):
     """Average ms of `fn()` (which enqueues on the current stream), HIP events around each call."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -431,6 +470,7 @@ def main():
     ap.add_argument('--prewarm', type=float, default=0.5, help='seconds of uncounted replays before the first warm-up step (clock ramp of an idle GPU; 0 = none)')
     ap.add_argument('--windows', type=int, default=3, help='consecutive timed windows of exactly --steps steps each; value = their median')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi power / clock probe of the two kernels (about 4 s)')
     ap.add_argument('--no-extras', action='store_true', help='skip frame_kernel / value_fp32_exact / pytorch_gpu_baseline')
     ap.add_argument('--mlp-precision', default='auto', choices=['auto', 'bf16x3', 'f16x3', 'f16f8', 'f16x2', 'fp32'],
                     help="arithmetic of the MLP GEMMs: auto = the library's choice (f16 + fp8 first pass with its discrete decisions verified by an f16x3 "
@@ -681,6 +721,17 @@ def main():
                 r_smp['frac'] = round(ginst / VALU_PEAK_GINST, 4)
                 r_smp['valu_insts_per_sample_slot'] = k.get('valu_insts_per_wave')
         result['stage_ms'] = {'mlp': round(mlp_ms[0], 4), 'samples': round(smp_ms[0], 4)}
+        if not args.no_extras and not args.no_power:
+            # what the power manager does under each kernel and under whole frames (the MLP kernel -- and the frame -- run at the
+            # socket's power limit with the shader clock pulled down; the sample stage does not)
+            try:
+                pw = {'mlp': power_probe(run_mlp), 'samples': power_probe(run_samples), 'frame': power_probe(render_frame)}
+                if all(v is not None for v in pw.values()):
+                    pw['what'] = ('rocm-smi (socket graphics package power, shader clock; medians over ~1 s each) while the MLP kernel, the sample kernel and '
+                                  'whole frames run back to back; outside every timed region')
+                    result['power'] = pw
+            except Exception as e:       # never the bench line's problem
+                result['power'] = {'error': str(e)[:200]}
         if model.frame_kernel_active() and not strong:
             # the step IS one kernel: time its launches with events, price it against the matrix cores (its MLP part is 97 % of
             # the frame's arithmetic) and quote the VALU issue fraction -- what actually limits it -- next to it
