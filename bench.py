@@ -502,6 +502,13 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if 'RANK' not in os.environ:       # HR_BENCH_FORCE_DIST=1 without a launcher: a one-rank job on the loopback
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            os.environ.update({'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1'})
+            os.environ.setdefault('MASTER_PORT', str(port))
         if FAKE:
             dist.init_process_group('gloo')
         else:
